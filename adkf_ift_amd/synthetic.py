@@ -1,0 +1,66 @@
+"""Synthetic few-shot tasks of SURVEY.md section 8(d).
+
+Per task ``t`` (``torch.Generator(seed = 1234 + t)``): ``X_s [N,d], X_q [N_q,d] ~ N(0,1)`` float32,
+features ``Z = X W / sqrt(d)`` with a shared ``W [d,d] ~ N(0,1)`` (seed 0) playing the role of the
+outer parameters theta (the stand-in for the GNN+fc of fs_mol/models/adaptive_dkt.py:141-160), labels
+drawn from ``f ~ GP(0, RBF(l = sqrt(d)))`` on ``[Z_s; Z_q]`` in float64: ``y = sign(f)`` (classification,
++-1 as fs_mol/models/adaptive_dkt.py:207-209) or ``f + 0.1 eps`` standardised with the support
+statistics (regression, fs_mol/data/dkt.py:91-97).  Everything is generated on the CPU so that the
+same tasks exist on every rank / box regardless of the device RNG.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+
+@dataclass
+class SyntheticTasks:
+    X_s: torch.Tensor  # [T, N, d]  float32
+    X_q: torch.Tensor  # [T, Nq, d] float32
+    y_s: torch.Tensor  # [T, N]     float32
+    y_q: torch.Tensor  # [T, Nq]    float32
+    W: torch.Tensor    # [d, d]     float32 (theta)
+
+    def features(self, W: Optional[torch.Tensor] = None):
+        W = self.W if W is None else W
+        d = W.shape[0]
+        return (self.X_s @ W) / math.sqrt(d), (self.X_q @ W) / math.sqrt(d)
+
+    def to(self, device):
+        return SyntheticTasks(*(t.to(device) for t in (self.X_s, self.X_q, self.y_s, self.y_q, self.W)))
+
+
+def make_outer_weight(d: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed(0)
+    return torch.randn(d, d, generator=g, dtype=torch.float32)
+
+
+def make_tasks(T: int, N: int, d: int, N_q: Optional[int] = None, regression: bool = False,
+               first_task: int = 0) -> SyntheticTasks:
+    N_q = N if N_q is None else N_q
+    W = make_outer_weight(d)
+    Xs, Xq, ys, yq = [], [], [], []
+    for t in range(first_task, first_task + T):
+        g = torch.Generator().manual_seed(1234 + t)
+        x_s = torch.randn(N, d, generator=g, dtype=torch.float32)
+        x_q = torch.randn(N_q, d, generator=g, dtype=torch.float32)
+        z = (torch.cat([x_s, x_q]) @ W / math.sqrt(d)).double()
+        d2 = torch.cdist(z, z) ** 2
+        K = torch.exp(-0.5 * d2 / d) + 1e-8 * torch.eye(N + N_q, dtype=torch.float64)
+        L = torch.linalg.cholesky(K)
+        f = L @ torch.randn(N + N_q, generator=g, dtype=torch.float64)
+        if regression:
+            f = f + 0.1 * torch.randn(N + N_q, generator=g, dtype=torch.float64)
+            mu, sd = f[:N].mean(), f[:N].std()
+            y = (f - mu) / sd
+        else:
+            y = torch.where(f >= 0, torch.ones_like(f), -torch.ones_like(f))
+        Xs.append(x_s)
+        Xq.append(x_q)
+        ys.append(y[:N].float())
+        yq.append(y[N:].float())
+    return SyntheticTasks(torch.stack(Xs), torch.stack(Xq), torch.stack(ys), torch.stack(yq), W)
