@@ -1,0 +1,76 @@
+"""ctypes binding of libadkf_gp.so (include/adkf_gp.h).  There is NO fallback: if the HIP library is not
+built, importing the GP operators raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadkf_gp.so")
+
+KERNEL_RBF = 0
+KERNEL_MATERN52 = 1
+IGNORE_GRAD_CORRECTION = 1
+IGNORE_DIRECT_GRAD = 2
+INFO_OUTER_BASE = 100000
+
+ERRORS = {-1: "bad argument", -2: "unsupported size (see adkf_max_points)", -3: "workspace too small",
+          -4: "HIP launch failed"}
+
+
+class Batch(C.Structure):
+    _fields_ = [("T", C.c_int32), ("ns_max", C.c_int32), ("nq_max", C.c_int32), ("d", C.c_int32),
+                ("kernel", C.c_int32), ("reserved", C.c_int32),
+                ("n_s", C.c_void_p), ("n_q", C.c_void_p), ("Z_s", C.c_void_p), ("y_s", C.c_void_p),
+                ("Z_q", C.c_void_p), ("y_q", C.c_void_p), ("priors", C.c_void_p)]
+
+
+class FitOptions(C.Structure):
+    _fields_ = [("max_evals", C.c_int32), ("exact_evals", C.c_int32), ("gtol", C.c_float), ("ftol", C.c_float)]
+
+
+_lib = None
+
+# name -> (restype, argtypes); kept in one table so tests can check every declared symbol is exported
+SIGNATURES = {
+    "adkf_version": (C.c_char_p, []),
+    "adkf_max_points": (C.c_int, []),
+    "adkf_workspace_bytes": (C.c_size_t, [C.c_int32] * 4),
+    "adkf_median_lengthscale": (C.c_int, [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "adkf_init_params": (C.c_int, [C.POINTER(Batch), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "adkf_mll_value_grad": (C.c_int, [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+    "adkf_fit": (C.c_int, [C.POINTER(Batch), C.c_void_p, C.POINTER(FitOptions), C.c_void_p, C.c_void_p, C.c_void_p,
+                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "adkf_predict": (C.c_int, [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_size_t, C.c_void_p]),
+    "adkf_outer_nll_value_grad": (C.c_int, [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "adkf_ift_hypergrad": (C.c_int, [C.POINTER(Batch), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]),
+    "adkf_check_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+}
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+            "The GP path has no CPU or PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = the library does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}")

@@ -1,0 +1,130 @@
+// Device-side helpers shared by every kernel of libadkf_gp (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace adkf {
+
+constexpr int WAVE = 64;
+constexpr float NOISE_LB = 1e-4f;       // gpytorch GaussianLikelihood GreaterThan(1e-4)
+constexpr float LOG_2PI = 1.8378770664093453f;
+constexpr float SQRT5 = 2.23606797749979f;
+
+// ---------------------------------------------------------------------------------------------------
+// per-task scalar slots (float) in the workspace
+// ---------------------------------------------------------------------------------------------------
+enum Scal : int {
+    S_NOISE = 0, S_OS, S_LS,            // transformed hyper-parameters
+    S_D1N, S_D1S, S_D1L,                // d transformed / d raw   (sigmoid)
+    S_D2N, S_D2S, S_D2L,                // second derivative
+    S_FIN, S_GIN0, S_GIN1, S_GIN2,      // f_inner and its raw gradient
+    S_GT0, S_GT1, S_GT2,                // d (nll - log priors) / d transformed
+    S_LOGDET, S_TRAINV, S_AA, S_YA, S_TRAINVG, S_AGA,
+    S_H0, S_H1, S_H2, S_H3, S_H4, S_H5, S_H6, S_H7, S_H8,
+    S_GOUT0, S_GOUT1, S_GOUT2,
+    S_V0, S_V1, S_V2,
+    S_CN, S_CS, S_CL,                   // coefficients of B_v = cn I + cs K + cl G
+    S_FOUT, S_LOGDETS,
+    S_QQ_TR, S_QQ_K, S_QQ_L,            // reductions of the W_qq kernel: tr(Om), <Om,kappa>, <Om,dK/dl>
+    S_COUNT_ = 64
+};
+constexpr int NSCAL = 64;
+
+// per-task vector slots (each nvec_ld floats)
+enum Vec : int { V_ALPHA = 0, V_BETA, V_GAMMA, V_DELTA, V_W, V_R, V_E, V_CTE, V_MU, V_RS_SS, V_CS_QS, V_RS_QS, V_RS_QQ, V_COUNT_ = 16 };
+constexpr int NVEC = 16;
+
+// ---------------------------------------------------------------------------------------------------
+// math
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float inv_softplus_f(float y) { return y > 20.f ? y : y + logf(-expm1f(-y)); }
+
+// kappa(u), kappa'(u), kappa''(u); u = squared scaled distance  (oracle/closed_form.py::kappa)
+template <int KIND>
+__device__ __forceinline__ void kappa3(float u, float& k0, float& k1, float& k2) {
+    if (KIND == 0) {
+        k0 = expf(-0.5f * u);
+        k1 = -0.5f * k0;
+        k2 = 0.25f * k0;
+    } else {
+        float r = sqrtf(u);
+        float e = expf(-SQRT5 * r);
+        k0 = (1.f + SQRT5 * r + (5.f / 3.f) * u) * e;
+        k1 = -(5.f / 6.f) * (1.f + SQRT5 * r) * e;
+        k2 = (25.f / 12.f) * e;
+    }
+}
+__device__ __forceinline__ void kappa3(int kind, float u, float& k0, float& k1, float& k2) {
+    if (kind == 0) kappa3<0>(u, k0, k1, k2); else kappa3<1>(u, k0, k1, k2);
+}
+__device__ __forceinline__ float kappa0(int kind, float u) {
+    if (kind == 0) return expf(-0.5f * u);
+    float r = sqrtf(u);
+    return (1.f + SQRT5 * r + (5.f / 3.f) * u) * expf(-SQRT5 * r);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reductions: wave shuffles first, one LDS hop across waves (deterministic order)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sums K values over the whole block; every thread gets the totals.  `red` needs K * (NT/64) floats.
+// Contains two barriers; safe to call repeatedly with the same scratch.
+template <int K, int NT>
+__device__ __forceinline__ void block_sum(float (&v)[K], float* red) {
+    constexpr int NW = NT / WAVE;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < K; ++q) v[q] = wave_sum(v[q]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) red[q * NW + w] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) s += red[q * NW + i];
+        v[q] = s;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ int block_sum_i(int v, int* red) {
+    constexpr int NW = NT / WAVE;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = wave_sum_i(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += red[i];
+    return s;
+}
+
+// XCD-aware block -> (task, tile) map: consecutive block ids are dealt round-robin to the 8 XCDs, so all
+// tiles of task t, in every kernel of the pipeline, run on the XCD labelled (t & 7) and find the task's
+// matrices in that XCD's L2.  Speed only: any placement is correct.  Grid = roundup8(T) * tiles.
+__device__ __forceinline__ bool task_tile(int T, int tiles, int& task, int& tile) {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, idx = b >> 3;
+    task = (idx / tiles) * 8 + xcd;
+    tile = idx % tiles;
+    return task < T;
+}
+
+}  // namespace adkf

@@ -1,0 +1,426 @@
+// The per-task (non-GEMM) kernels of the pipeline.  One workgroup per task unless noted.
+#pragma once
+#include "problems.h"
+#include "inner.h"
+
+namespace adkf {
+
+// ---- column mean of the support features (gpytorch centres both operands by x1.mean) -----------------
+__global__ __launch_bounds__(256) void k_colmean(const float* Zs, const int32_t* n_s, int ns_ld, int d, float* mean, int T) {
+    const int t = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    const int n = n_s ? n_s[t] : ns_ld;
+    const float* Z = Zs + (size_t)t * ns_ld * d;
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += Z[(size_t)i * d + c];
+    mean[(size_t)t * d + c] = n > 0 ? s / (float)n : 0.f;
+}
+
+// ---- squared norms of the centred rows: one wave per row ----------------------------------------------
+__global__ __launch_bounds__(256) void k_rownorm(const float* Z, const int32_t* n_arr, int ld, int d, const float* mean, float* nrm, int T) {
+    const int t = blockIdx.y;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = n_arr ? n_arr[t] : ld;
+    if (row >= ld) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    if (row < n) {
+        const float* z = Z + ((size_t)t * ld + row) * d;
+        const float* mu = mean + (size_t)t * d;
+        for (int c = lane; c < d; c += 64) { const float v = z[c] - mu[c]; s += v * v; }
+    }
+    s = wave_sum(s);
+    if (lane == 0) nrm[(size_t)t * ld + row] = s;
+}
+
+// ---- K1: squared distances in GEMM form on the fp32 MFMA ----------------------------------------------
+struct ProbDist {
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
+    static constexpr int NRED = 0;
+    const float *X, *Y, *mean, *nx, *ny; const int32_t *n_x, *n_y; int x_ld, y_ld, d; bool symmetric; float* D2;
+    int mx, my; const float *Xi, *Yi, *mu, *nxi, *nyi; float* Do;
+    __device__ bool setup(int t) {
+        mx = n_x ? n_x[t] : x_ld; my = n_y ? n_y[t] : y_ld;
+        Xi = X + (size_t)t * x_ld * d; Yi = Y + (size_t)t * y_ld * d; mu = mean + (size_t)t * d;
+        nxi = nx + (size_t)t * x_ld; nyi = ny + (size_t)t * y_ld; Do = D2 + (size_t)t * x_ld * y_ld;
+        return mx > 0 && my > 0;
+    }
+    __device__ int M() const { return mx; } __device__ int N() const { return my; } __device__ int K() const { return d; }
+    __device__ float a(int i, int k) const { return Xi[(size_t)i * d + k] - mu[k]; }
+    __device__ float b(int k, int j) const { return Yi[(size_t)j * d + k] - mu[k]; }
+    __device__ void epi(int i, int j, float acc, float*) const {
+        float v = fmaxf(nxi[i] + nyi[j] - 2.f * acc, 0.f);
+        if (symmetric && i == j) v = 0.f;
+        Do[(size_t)i * y_ld + j] = v;
+    }
+    __device__ void store_red(int, const float*) const {}
+};
+
+// ---- K10: median heuristic.  Exact lower median of the positive strict-upper-triangle entries by a
+// 31-step radix select on the float bit patterns (positive floats order like their bits). ---------------
+__global__ __launch_bounds__(256) void k_median(const float* D2ss, const int32_t* n_s, int ld, float* l0, int T) {
+    __shared__ int red[4];
+    int t, tile;
+    if (!task_tile(T, 1, t, tile)) return;
+    const int n = n_s ? n_s[t] : ld;
+    const uint32_t* D = reinterpret_cast<const uint32_t*>(D2ss + (size_t)t * ld * ld);
+    const int tid = threadIdx.x;
+    int cnt = 0;
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        if (j > i && D[(size_t)i * ld + j] != 0u) ++cnt;  // entries are clamped >= 0, so != 0 means > 0
+    }
+    const int total = block_sum_i<256>(cnt, red);
+    if (total == 0) { if (tid == 0) l0[t] = 0.f; return; }
+    int rank = (total - 1) / 2;  // torch.median: lower median
+    uint32_t prefix = 0;
+    for (int bit = 30; bit >= 0; --bit) {
+        const uint32_t hi_mask = ~((1u << bit) - 1u);  // bits >= bit
+        int c0 = 0;
+        for (int e = tid; e < n * n; e += 256) {
+            const int i = e / n, j = e - i * n;
+            if (j > i) {
+                const uint32_t v = D[(size_t)i * ld + j];
+                if (v != 0u && (v & hi_mask) == prefix) ++c0;  // matches prefix with this bit = 0
+            }
+        }
+        c0 = block_sum_i<256>(c0, red);
+        if (rank >= c0) { rank -= c0; prefix |= (1u << bit); }
+    }
+    if (tid == 0) l0[t] = sqrtf(0.5f * __uint_as_float(prefix));
+}
+
+// ---- a4: fresh phi and priors ---------------------------------------------------------------------------
+__global__ void k_init_params(const float* l0, int T, int numeric, int use_ls_prior, float* phi, float* priors) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const float scale = 0.25f;
+    const float mode = numeric ? 0.01f : 0.1f;
+    phi[t * 3 + 0] = inv_softplus_f(mode - NOISE_LB);
+    phi[t * 3 + 1] = 0.f;
+    phi[t * 3 + 2] = inv_softplus_f(l0[t]);
+    priors[t * 4 + 0] = logf(mode) + scale * scale;
+    priors[t * 4 + 1] = scale;
+    priors[t * 4 + 2] = use_ls_prior ? logf(l0[t]) + scale * scale : 0.f;
+    priors[t * 4 + 3] = use_ls_prior ? scale : -1.f;
+}
+
+// ---- Stage C: beta = G alpha, gamma = Ainv alpha, delta = Ainv beta, traces, 3x3 Hessian ------------------
+// (oracle/closed_form.py::inner_stage, want_hessian branch)
+struct HessArgs { TaskView tv; const float* Ainv; const float* P; const float* D2ss; const float* y_s; const float* priors; float* scal; float* vecs; int T; };
+
+__global__ __launch_bounds__(256) void k_hess(HessArgs a) {
+    __shared__ float red[9 * 4];
+    int t, tile;
+    if (!task_tile(a.T, 1, t, tile)) return;
+    const int n = a.tv.ns(t), ld = a.tv.ns_ld, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* sc = a.scal + (size_t)t * NSCAL;
+    const float noise = sc[S_NOISE], os = sc[S_OS], ls = sc[S_LS], il2 = 1.f / (ls * ls);
+    const float* Ai = a.Ainv + (size_t)t * ld * ld;
+    const float* Pi = a.P + (size_t)t * ld * ld;
+    const float* D2 = a.D2ss + (size_t)t * ld * ld;
+    float* al = a.vecs + ((size_t)t * NVEC + V_ALPHA) * a.tv.vld;
+    float* be = a.vecs + ((size_t)t * NVEC + V_BETA) * a.tv.vld;
+    float* ga = a.vecs + ((size_t)t * NVEC + V_GAMMA) * a.tv.vld;
+    float* de = a.vecs + ((size_t)t * NVEC + V_DELTA) * a.tv.vld;
+    const int kind = a.tv.kind;
+    // wave per row: beta_i = sum_j G_ij alpha_j ; gamma_i = sum_j Ainv_ij alpha_j
+    for (int i = wv; i < n; i += 4) {
+        float sb = 0.f, sg = 0.f;
+        for (int j = lane; j < n; j += 64) {
+            float k0, k1, k2; const float u = D2[(size_t)i * ld + j] * il2; kappa3(kind, u, k0, k1, k2);
+            const float aj = al[j];
+            sb += os * k1 * u * (-2.f / ls) * aj;
+            sg += Ai[(size_t)i * ld + j] * aj;
+        }
+        sb = wave_sum(sb); sg = wave_sum(sg);
+        if (lane == 0) { be[i] = sb; ga[i] = sg; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = wv; i < n; i += 4) {
+        float sd = 0.f;
+        for (int j = lane; j < n; j += 64) sd += Ai[(size_t)i * ld + j] * be[j];
+        sd = wave_sum(sd);
+        if (lane == 0) de[i] = sd;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // elementwise traces
+    float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // trA2, trPA, trPP, trAinvKll, aKlla, ag, bg, bd, ab
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        const float ai = Ai[(size_t)i * ld + j], pij = Pi[(size_t)i * ld + j], pji = Pi[(size_t)j * ld + i];
+        float k0, k1, k2; const float u = D2[(size_t)i * ld + j] * il2; kappa3(kind, u, k0, k1, k2);
+        const float Kll = os * (k2 * 4.f * u * u + k1 * 6.f * u) * il2;
+        acc[0] += ai * ai; acc[1] += pij * ai; acc[2] += pij * pji; acc[3] += ai * Kll; acc[4] += al[i] * al[j] * Kll;
+    }
+    if (tid < n) { acc[5] = al[tid] * ga[tid]; acc[6] = be[tid] * ga[tid]; acc[7] = be[tid] * de[tid]; acc[8] = al[tid] * be[tid]; }
+    for (int i = tid + 256; i < n; i += 256) { acc[5] += al[i] * ga[i]; acc[6] += be[i] * ga[i]; acc[7] += be[i] * de[i]; acc[8] += al[i] * be[i]; }
+    block_sum<9, 256>(acc, red);
+    if (tid == 0) {
+        const float trA2 = acc[0], trPA = acc[1], trPP = acc[2], trAinvKll = acc[3], aKlla = acc[4], ag = acc[5], bg = acc[6], bd = acc[7], ab = acc[8];
+        const float trAinv = sc[S_TRAINV], aa = sc[S_AA], ya = sc[S_YA], trAinvG = sc[S_TRAINVG], aGa = sc[S_AGA];
+        const float fn = (float)n;
+        float h00 = ag - 0.5f * trA2;
+        const float h01 = ((aa - noise * ag) - 0.5f * (trAinv - noise * trA2)) / os;
+        const float h02 = bg - 0.5f * trPA;
+        const float h11 = ((ya - 2.f * noise * aa + noise * noise * ag) - 0.5f * (fn - 2.f * noise * trAinv + noise * noise * trA2)) / (os * os);
+        const float h12 = ((ab - noise * bg) - 0.5f * (trAinvG - noise * trPA)) / os - (0.5f * aGa - 0.5f * trAinvG) / os;
+        float h22 = bd - 0.5f * aKlla - 0.5f * trPP + 0.5f * trAinvKll;
+        // prior curvature (oracle/closed_form.py::lognormal_terms d2)
+        const float* pri = a.priors + t * 4;
+        { const float lx = logf(noise), s2 = pri[1] * pri[1]; h00 -= (1.f + (lx - pri[0]) / s2 - 1.f / s2) / (noise * noise); }
+        if (pri[3] > 0.f) { const float lx = logf(ls), s2 = pri[3] * pri[3]; h22 -= (1.f + (lx - pri[2]) / s2 - 1.f / s2) / (ls * ls); }
+        const float d1[3] = {sc[S_D1N], sc[S_D1S], sc[S_D1L]}, d2[3] = {sc[S_D2N], sc[S_D2S], sc[S_D2L]};
+        const float gt[3] = {sc[S_GT0], sc[S_GT1], sc[S_GT2]};
+        const float h[3][3] = {{h00, h01, h02}, {h01, h11, h12}, {h02, h12, h22}};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) sc[S_H0 + i * 3 + j] = (h[i][j] * d1[i] * d1[j] + (i == j ? gt[i] * d2[i] : 0.f)) / fn;
+    }
+}
+
+// ---- Stage D core: mu = C y, r = y_q - mu, factor S, e = S^-1 r, f_out, Cte = C^T e --------------------
+struct OuterArgs { TaskView tv; const float* C; float* S; const float* y_s; const float* y_q; float* vecs; float* scal; float* f_out; int32_t* info; int T; };
+
+template <int NMAX, int NT>
+struct OuterSmem {
+    float buf0[FactorShape<NMAX>::ELEMS];
+    float buf1[FactorShape<NMAX>::ELEMS];
+    float r[NMAX];
+    float w[NMAX];
+    float e[NMAX];
+    float dinv[NMAX];
+    float red[8 * (NT / 64)];
+};
+
+template <int NMAX, int NT>
+__global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
+    constexpr int LD = FactorShape<NMAX>::LD;
+    __shared__ OuterSmem<NMAX, NT> sm;
+    int t, tile;
+    if (!task_tile(a.T, 1, t, tile)) return;
+    const int n = a.tv.ns(t), m = a.tv.nq(t), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = NT / 64;
+    const float* Ci = a.C + (size_t)t * a.tv.nq_ld * a.tv.ns_ld;
+    float* Si = a.S + (size_t)t * a.tv.nq_ld * a.tv.nq_ld;
+    const float* ys = a.y_s + (size_t)t * a.tv.ns_ld;
+    const float* yq = a.y_q + (size_t)t * a.tv.nq_ld;
+    float* vbase = a.vecs + (size_t)t * NVEC * a.tv.vld;
+    // residual
+    for (int i = wv; i < m; i += NW) {
+        float s = 0.f;
+        for (int j = lane; j < n; j += 64) s += Ci[(size_t)i * a.tv.ns_ld + j] * ys[j];
+        s = wave_sum(s);
+        if (lane == 0) { vbase[V_MU * a.tv.vld + i] = s; sm.r[i] = yq[i] - s; }
+    }
+    for (int e = tid; e < m * m; e += NT) {
+        const int i = e / m, j = e - i * m;
+        if (j <= i) sm.buf0[i * LD + j] = Si[(size_t)i * a.tv.nq_ld + j];
+    }
+    float logdet;
+    int info = ldl_sweep<NMAX, NT>(sm.buf0, sm.buf1, sm.dinv, m, logdet, sm.red);
+    if (tid < m) {
+        float s = 0.f;
+        for (int j = 0; j <= tid; ++j) s += sm.buf1[tid * LD + j] * sm.r[j];
+        sm.w[tid] = s;
+    }
+    __syncthreads();
+    float q[1] = {0.f};
+    if (tid < m) {
+        float s = 0.f;
+        for (int k = tid; k < m; ++k) s += sm.buf1[k * LD + tid] * sm.w[k];
+        sm.e[tid] = s;
+        vbase[V_E * a.tv.vld + tid] = s;
+        vbase[V_R * a.tv.vld + tid] = sm.r[tid];
+        q[0] = sm.w[tid] * sm.w[tid];
+    }
+    ata_lower<NMAX, NT>(sm.buf1, sm.buf0, m);
+    block_sum<1, NT>(q, sm.red);  // has the barriers ata_lower's consumers need
+    for (int e = tid; e < m * m; e += NT) {
+        const int i = e / m, j = e - i * m;
+        Si[(size_t)i * a.tv.nq_ld + j] = sm.buf0[i * LD + j];
+    }
+    // Cte_j = sum_i C_ij e_i  (thread per column: coalesced)
+    for (int j = tid; j < n; j += NT) {
+        float s = 0.f;
+        for (int i = 0; i < m; ++i) s += Ci[(size_t)i * a.tv.ns_ld + j] * sm.e[i];
+        vbase[V_CTE * a.tv.vld + j] = s;
+    }
+    if (tid == 0) {
+        const float f = 0.5f * q[0] + 0.5f * logdet + 0.5f * (float)m * LOG_2PI;
+        a.scal[(size_t)t * NSCAL + S_FOUT] = f;
+        a.scal[(size_t)t * NSCAL + S_LOGDETS] = logdet;
+        if (a.f_out) a.f_out[t] = (info == 0) ? f : NAN;
+        if (info != 0 && a.info[t] == 0) a.info[t] = 100000 + info;
+    }
+}
+
+// ---- W_qq = dir * Omega . s kappa'(u_qq)/l^2 and its three reductions -------------------------------------
+struct WqqArgs { TaskView tv; const float* Sinv; const float* D2qq; float* Wqq; float* scal; float dirscale; int T; };
+
+__global__ __launch_bounds__(256) void k_wqq(WqqArgs a) {
+    __shared__ float red[3 * 4];
+    int t, tile;
+    if (!task_tile(a.T, 1, t, tile)) return;
+    const int m = a.tv.nq(t), ld = a.tv.nq_ld, tid = threadIdx.x;
+    float* sc = a.scal + (size_t)t * NSCAL;
+    const float os = sc[S_OS], ls = sc[S_LS], il2 = 1.f / (ls * ls);
+    const float* Si = a.Sinv + (size_t)t * ld * ld;
+    const float* D2 = a.D2qq + (size_t)t * ld * ld;
+    float* Wo = a.Wqq + (size_t)t * ld * ld;
+    const float* ev = a.tv.vec(t, V_E);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int e = tid; e < m * m; e += 256) {
+        const int i = e / m, j = e - i * m;
+        const float om = 0.5f * (Si[(size_t)i * ld + j] - ev[i] * ev[j]);
+        float k0, k1, k2; const float u = D2[(size_t)i * ld + j] * il2; kappa3(a.tv.kind, u, k0, k1, k2);
+        Wo[(size_t)i * ld + j] = a.dirscale * om * os * k1 * il2;
+        if (i == j) acc[0] += om;
+        acc[1] += om * k0;
+        acc[2] += om * os * k1 * u * (-2.f / ls);
+    }
+    block_sum<3, 256>(acc, red);
+    if (tid == 0) { sc[S_QQ_TR] = acc[0]; sc[S_QQ_K] = acc[1]; sc[S_QQ_L] = acc[2]; }
+}
+
+// ---- W_ss for d f_in / dZ:  Q . s kappa'/l^2,  Q = (Ainv - alpha alpha^T) / (2n) -------------------------
+struct WinArgs { TaskView tv; const float* Ainv; const float* D2ss; float* Wss; const float* scal; int T; };
+
+__global__ __launch_bounds__(256) void k_win(WinArgs a) {
+    int t, tile;
+    if (!task_tile(a.T, 1, t, tile)) return;
+    const int n = a.tv.ns(t), ld = a.tv.ns_ld;
+    const float* sc = a.scal + (size_t)t * NSCAL;
+    const float os = sc[S_OS], ls = sc[S_LS], il2 = 1.f / (ls * ls);
+    const float* Ai = a.Ainv + (size_t)t * ld * ld;
+    const float* D2 = a.D2ss + (size_t)t * ld * ld;
+    const float* al = a.tv.vec(t, V_ALPHA);
+    float* Wo = a.Wss + (size_t)t * ld * ld;
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        float k0, k1, k2; kappa3(a.tv.kind, D2[(size_t)i * ld + j] * il2, k0, k1, k2);
+        Wo[(size_t)i * ld + j] = 0.5f * (Ai[(size_t)i * ld + j] - al[i] * al[j]) / (float)n * os * k1 * il2;
+    }
+}
+
+// ---- g_out, v = H^-1 g_out, coefficients and the vector w = A^-1 B_v alpha -------------------------------
+struct SolveArgs { TaskView tv; float* scal; float* vecs; const float* part_oc; const float* part_ma; int nt_oc, nt_ma; int flags; float* g_phi_out; float* v_out; float* H_out; int T; int with_hessian; };
+
+__global__ __launch_bounds__(64) void k_solve_v(SolveArgs a) {
+    const int t = blockIdx.x;
+    if (t >= a.T) return;
+    float* sc = a.scal + (size_t)t * NSCAL;
+    const int n = a.tv.ns(t), lane = threadIdx.x;
+    __shared__ float sh[8];
+    if (lane == 0) {
+        float oc0 = 0.f, oc1 = 0.f, ma0 = 0.f, ma1 = 0.f, ma2 = 0.f;
+        for (int q = 0; q < a.nt_oc; ++q) { oc0 += a.part_oc[((size_t)t * a.nt_oc + q) * 4 + 0]; oc1 += a.part_oc[((size_t)t * a.nt_oc + q) * 4 + 1]; }
+        for (int q = 0; q < a.nt_ma; ++q) { const float* p = a.part_ma + ((size_t)t * a.nt_ma + q) * 4; ma0 += p[0]; ma1 += p[1]; ma2 += p[2]; }
+        const float g_noise = sc[S_QQ_TR] + ma0;
+        const float g_s = ma1 + oc0 + sc[S_QQ_K];
+        const float g_l = ma2 + oc1 + sc[S_QQ_L];
+        float g[3] = {g_noise * sc[S_D1N], g_s * sc[S_D1S], g_l * sc[S_D1L]};
+        sc[S_GOUT0] = g[0]; sc[S_GOUT1] = g[1]; sc[S_GOUT2] = g[2];
+        if (a.g_phi_out) { a.g_phi_out[t * 3 + 0] = g[0]; a.g_phi_out[t * 3 + 1] = g[1]; a.g_phi_out[t * 3 + 2] = g[2]; }
+        float v[3] = {0.f, 0.f, 0.f};
+        if (a.with_hessian && !(a.flags & 1)) {
+            // 3x3 Gaussian elimination with partial pivoting (the reference: torch.linalg.solve,
+            // fs_mol/utils/cauchy_hypergradient.py:136)
+            float Mx[3][4];
+            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Mx[i][j] = sc[S_H0 + i * 3 + j]; Mx[i][3] = g[i]; }
+            for (int c = 0; c < 3; ++c) {
+                int pv = c;
+                for (int r = c + 1; r < 3; ++r) if (fabsf(Mx[r][c]) > fabsf(Mx[pv][c])) pv = r;
+                if (pv != c) for (int j = 0; j < 4; ++j) { const float tmp = Mx[c][j]; Mx[c][j] = Mx[pv][j]; Mx[pv][j] = tmp; }
+                const float ip = 1.f / Mx[c][c];
+                for (int r = c + 1; r < 3; ++r) { const float f = Mx[r][c] * ip; for (int j = c; j < 4; ++j) Mx[r][j] -= f * Mx[c][j]; }
+            }
+            for (int c = 2; c >= 0; --c) { float s = Mx[c][3]; for (int j = c + 1; j < 3; ++j) s -= Mx[c][j] * v[j]; v[c] = s / Mx[c][c]; }
+        }
+        sc[S_V0] = v[0]; sc[S_V1] = v[1]; sc[S_V2] = v[2];
+        const float cn = v[0] * sc[S_D1N], cs = v[1] * sc[S_D1S] / sc[S_OS], cl = v[2] * sc[S_D1L];
+        sc[S_CN] = cn; sc[S_CS] = cs; sc[S_CL] = cl;
+        sh[0] = cn; sh[1] = cs; sh[2] = cl; sh[3] = sc[S_NOISE];
+        if (a.v_out) { a.v_out[t * 3 + 0] = v[0]; a.v_out[t * 3 + 1] = v[1]; a.v_out[t * 3 + 2] = v[2]; }
+        if (a.H_out) for (int q = 0; q < 9; ++q) a.H_out[t * 9 + q] = a.with_hessian ? sc[S_H0 + q] : 0.f;
+    }
+    __syncthreads();
+    if (a.with_hessian) {
+        const float cn = sh[0], cs = sh[1], cl = sh[2], noise = sh[3];
+        float* vb = a.vecs + (size_t)t * NVEC * a.tv.vld;
+        for (int i = lane; i < n; i += 64) {
+            const float al = vb[V_ALPHA * a.tv.vld + i], ga = vb[V_GAMMA * a.tv.vld + i], de = vb[V_DELTA * a.tv.vld + i];
+            vb[V_W * a.tv.vld + i] = cn * ga + cs * (al - noise * ga) + cl * de;
+        }
+    }
+}
+
+// ---- row/column sums of the weight matrices -> the diagonal coefficients of the dZ GEMMs -----------------
+// coef_s[i] = 2 (2 rowsum(W_ss)[i] + colsum(W_qs)[i]);  coef_q[i] = 2 (rowsum(W_qs)[i] + 2 rowsum(W_qq)[i])
+struct RowsumArgs { TaskView tv; const float* Wss; const float* Wqs; const float* Wqq; float* vecs; int T; };
+
+__global__ __launch_bounds__(256) void k_rowsums(RowsumArgs a) {
+    int t, tile;
+    if (!task_tile(a.T, 1, t, tile)) return;
+    const int n = a.tv.ns(t), m = a.Wqs ? a.tv.nq(t) : 0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* Wss = a.Wss + (size_t)t * a.tv.ns_ld * a.tv.ns_ld;
+    const float* Wqs = a.Wqs ? a.Wqs + (size_t)t * a.tv.nq_ld * a.tv.ns_ld : nullptr;
+    const float* Wqq = a.Wqq ? a.Wqq + (size_t)t * a.tv.nq_ld * a.tv.nq_ld : nullptr;
+    float* vb = a.vecs + (size_t)t * NVEC * a.tv.vld;
+    __shared__ float cs[1];
+    (void)cs;
+    for (int i = wv; i < n; i += 4) {
+        float s = 0.f;
+        for (int j = lane; j < n; j += 64) s += Wss[(size_t)i * a.tv.ns_ld + j];
+        s = wave_sum(s);
+        if (lane == 0) vb[V_RS_SS * a.tv.vld + i] = 4.f * s;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (m > 0) {
+        for (int j = tid; j < n; j += 256) {
+            float s = 0.f;
+            for (int i = 0; i < m; ++i) s += Wqs[(size_t)i * a.tv.ns_ld + j];
+            vb[V_RS_SS * a.tv.vld + j] += 2.f * s;
+        }
+        for (int i = wv; i < m; i += 4) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int j = lane; j < n; j += 64) s1 += Wqs[(size_t)i * a.tv.ns_ld + j];
+            for (int j = lane; j < m; j += 64) s2 += Wqq[(size_t)i * a.tv.nq_ld + j];
+            s1 = wave_sum(s1); s2 = wave_sum(s2);
+            if (lane == 0) vb[V_RS_QS * a.tv.vld + i] = 2.f * s1 + 4.f * s2;
+        }
+    }
+}
+
+// ---- predictive variance diag: var_i = s - sum_j C_ij Kqs_ij + noise;  mean_i = sum_j C_ij y_j ------------
+struct PredArgs { TaskView tv; const float* C; const float* D2qs; const float* y_s; float* mean; float* var; const float* scal; int T; };
+
+__global__ __launch_bounds__(256) void k_predict(PredArgs a) {
+    int t, tile;
+    if (!task_tile(a.T, 1, t, tile)) return;
+    const int n = a.tv.ns(t), m = a.tv.nq(t), lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float* sc = a.scal + (size_t)t * NSCAL;
+    const float os = sc[S_OS], il2 = 1.f / (sc[S_LS] * sc[S_LS]), noise = sc[S_NOISE];
+    const float* Ci = a.C + (size_t)t * a.tv.nq_ld * a.tv.ns_ld;
+    const float* D2 = a.D2qs + (size_t)t * a.tv.nq_ld * a.tv.ns_ld;
+    const float* ys = a.y_s + (size_t)t * a.tv.ns_ld;
+    for (int i = wv; i < a.tv.nq_ld; i += 4) {
+        float s1 = 0.f, s2 = 0.f;
+        if (i < m)
+            for (int j = lane; j < n; j += 64) {
+                const float c = Ci[(size_t)i * a.tv.ns_ld + j];
+                s1 += c * ys[j];
+                s2 += c * os * kappa0(a.tv.kind, D2[(size_t)i * a.tv.ns_ld + j] * il2);
+            }
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) {
+            a.mean[(size_t)t * a.tv.nq_ld + i] = (i < m) ? s1 : 0.f;
+            if (a.var) a.var[(size_t)t * a.tv.nq_ld + i] = (i < m) ? (os - s2 + noise) : 0.f;
+        }
+    }
+}
+
+}  // namespace adkf

