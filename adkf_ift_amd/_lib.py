@@ -26,7 +26,8 @@ class Batch(C.Structure):
 
 
 class FitOptions(C.Structure):
-    _fields_ = [("max_evals", C.c_int32), ("exact_evals", C.c_int32), ("gtol", C.c_float), ("ftol", C.c_float)]
+    _fields_ = [("max_evals", C.c_int32), ("exact_evals", C.c_int32), ("gtol", C.c_float), ("ftol", C.c_float),
+                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
 
 
 _lib = None

@@ -276,7 +276,10 @@ int adkf_fit(const adkf_batch_t* b, float* phi, const adkf_fit_options_t* opt, f
     InnerArgs ia = inner_args(b, w, phi, info);
     ia.f_out = f_final; ia.gnorm_out = gnorm; ia.nevals_out = n_evals;
     ia.max_evals = opt->max_evals; ia.exact_evals = opt->exact_evals; ia.gtol = opt->gtol; ia.ftol = opt->ftol;
-    return launch_inner(ia, st);
+    if (opt->ev_start && hipEventRecord(static_cast<hipEvent_t>(opt->ev_start), st) != hipSuccess) return ADKF_E_LAUNCH;
+    rc = launch_inner(ia, st);
+    if (opt->ev_stop && hipEventRecord(static_cast<hipEvent_t>(opt->ev_stop), st) != hipSuccess) return ADKF_E_LAUNCH;
+    return rc;
 }
 
 int adkf_predict(const adkf_batch_t* b, const float* phi, float* mean, float* var, float* cov, int32_t* info, void* ws,

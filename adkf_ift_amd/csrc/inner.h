@@ -105,7 +105,7 @@ __device__ __forceinline__ int inner_eval(InnerSmem<NMAX, NT>& sm, const float (
     const float nll = 0.5f * ya + 0.5f * logdet + 0.5f * fn * LOG_2PI;
     // LogNormal priors on the transformed values (oracle/closed_form.py::lognormal_terms)
     float lp = 0.f, dpn = 0.f, dpl = 0.f;
-    {
+    if (pri[1] > 0.f) {
         const float lx = logf(noise), sc = pri[1], z = (lx - pri[0]) / (sc * sc);
         lp += -lx - logf(sc) - 0.5f * LOG_2PI - 0.5f * (lx - pri[0]) * z;
         dpn = (-1.f - z) / noise;

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_hess(HessArgs a) {
         float h22 = bd - 0.5f * aKlla - 0.5f * trPP + 0.5f * trAinvKll;
         // prior curvature (oracle/closed_form.py::lognormal_terms d2)
         const float* pri = a.priors + t * 4;
-        { const float lx = logf(noise), s2 = pri[1] * pri[1]; h00 -= (1.f + (lx - pri[0]) / s2 - 1.f / s2) / (noise * noise); }
+        if (pri[1] > 0.f) { const float lx = logf(noise), s2 = pri[1] * pri[1]; h00 -= (1.f + (lx - pri[0]) / s2 - 1.f / s2) / (noise * noise); }
         if (pri[3] > 0.f) { const float lx = logf(ls), s2 = pri[3] * pri[3]; h22 -= (1.f + (lx - pri[2]) / s2 - 1.f / s2) / (ls * ls); }
         const float d1[3] = {sc[S_D1N], sc[S_D1S], sc[S_D1L]}, d2[3] = {sc[S_D2N], sc[S_D2S], sc[S_D2L]};
         const float gt[3] = {sc[S_GT0], sc[S_GT1], sc[S_GT2]};

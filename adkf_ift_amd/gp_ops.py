@@ -168,13 +168,15 @@ def mll_value_grad(b: GPBatch, phi: torch.Tensor, want_grad_phi=True, want_dZ=Fa
 
 
 def fit(b: GPBatch, phi0: torch.Tensor, max_evals: int = 200, gtol: float = 1e-5, ftol: float = 1e-7,
-        exact_evals: bool = False):
-    """Batched inner optimisation; returns (phi*, f_final, gnorm, n_evals, info)."""
+        exact_evals: bool = False, events: Optional[Tuple[torch.cuda.Event, torch.cuda.Event]] = None):
+    """Batched inner optimisation; returns (phi*, f_final, gnorm, n_evals, info).  ``events`` = a pair of
+    already-created timing events recorded right around the optimiser kernel (bench.py's roofline clock)."""
     lib = _lib.load()
     phi = _f32(phi0, "phi0").clone()
     f, gn = _new(b, b.T), _new(b, b.T)
     ne, info = _new(b, b.T, dtype=torch.int32), _new(b, b.T, dtype=torch.int32)
-    opt = FitOptions(int(max_evals), int(exact_evals), float(gtol), float(ftol))
+    opt = FitOptions(int(max_evals), int(exact_evals), float(gtol), float(ftol),
+                     events[0].cuda_event if events else None, events[1].cuda_event if events else None)
     ws, nb = b.workspace()
     cb = b.c_struct()
     _lib.check(lib.adkf_fit(C.byref(cb), _ptr(phi), C.byref(opt), _ptr(f), _ptr(gn), _ptr(ne), _ptr(info), _ptr(ws), nb,

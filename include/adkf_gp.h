@@ -18,7 +18,8 @@
  *     (fs_mol/models/adaptive_dkt.py:81-86); noise = softplus(raw)+1e-4, outputscale / lengthscale =
  *     softplus(raw);
  *   - priors[t] = (noise_loc, noise_scale, ls_loc, ls_scale): LogNormal priors of
- *     fs_mol/models/adaptive_dkt.py:94-100,112-119; ls_scale <= 0 disables the lengthscale prior;
+ *     fs_mol/models/adaptive_dkt.py:94-100,112-119; a scale <= 0 disables that prior (DKLModel has no
+ *     noise prior, fs_mol/models/dkl.py:86; use_lengthscale_prior=False);
  *   - every function is ASYNCHRONOUS on `stream` (a hipStream_t passed as void*), re-entrant across
  *     streams, holds no global mutable state and performs no allocation or synchronisation, so it may be
  *     captured into a hipGraph;
@@ -73,6 +74,8 @@ typedef struct adkf_fit_options {
     int32_t exact_evals; /* != 0: spend exactly max_evals evaluations (benchmark mode, deterministic work) */
     float gtol;        /* stop when max|grad| <= gtol          (SciPy L-BFGS-B pgtol, default 1e-5) */
     float ftol;        /* stop when rel. decrease <= ftol      (SciPy factr*eps analogue) */
+    void* ev_start;    /* optional hipEvent_t recorded on `stream` immediately before the optimiser kernel */
+    void* ev_stop;     /* optional hipEvent_t recorded immediately after it (roofline timing in bench.py) */
 } adkf_fit_options_t;
 
 const char* adkf_version(void);

@@ -1,0 +1,71 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/adkf_gp.h declares.
+No compute call is made here (there is no GPU); host-only entry points are exercised."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    from adkf_ift_amd import _lib
+
+    ge.build()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from adkf_ift_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "adkf_gp.h")).read()
+    declared = set(re.findall(r"\b(adkf_[a-z_]+)\s*\(", header))
+    assert len(declared) >= 11
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_host_only_entry_points(lib):
+    assert b"gfx950" in lib.adkf_version()
+    assert lib.adkf_max_points() >= 128
+    assert lib.adkf_workspace_bytes(0, 8, 8, 4) == 0
+    small = lib.adkf_workspace_bytes(4, 16, 16, 8)
+    big = lib.adkf_workspace_bytes(256, 128, 128, 256)
+    assert 0 < small < big
+    assert big > 11 * 256 * 128 * 128 * 4  # the eleven N x N work matrices
+
+
+def test_bad_arguments_are_rejected_without_touching_the_gpu(lib):
+    import ctypes as C
+
+    from adkf_ift_amd._lib import Batch
+
+    b = Batch()
+    b.T, b.ns_max, b.nq_max, b.d, b.kernel = 0, 8, 8, 4, 0
+    assert lib.adkf_median_lengthscale(C.byref(b), None, None, 0, None) == -1
+    b.T, b.Z_s = 2, 1  # non-null dummy pointer; rejected before any launch
+    b.ns_max = 100000
+    assert lib.adkf_median_lengthscale(C.byref(b), None, None, 0, None) == -2
+    b.ns_max, b.kernel = 8, 7
+    assert lib.adkf_median_lengthscale(C.byref(b), None, None, 0, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from adkf_ift_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        _lib.load()
+
+
+def test_cpu_tensors_are_refused():
+    import torch
+
+    from adkf_ift_amd import gp_ops
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gp_ops.GPBatch(torch.zeros(1, 4, 2), torch.zeros(1, 4), torch.zeros(1, 4))

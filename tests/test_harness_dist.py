@@ -1,0 +1,102 @@
+"""CPU, world_size 2 (gloo): the data-parallel harness (adkf_ift_amd.trainer.meta_step) shards tasks over ranks,
+all-reduces the flat outer gradient ONCE, divides by the global task count, clips AFTER the all-reduce and applies the
+same optimiser step on every rank.  Expected numbers come from the harness fixture that make_golden.py produced with
+the REFERENCE's cauchy_hypergradient in a sequential per-task loop (fs_mol/utils/adaptive_dkt_utils.py:361-413).
+The GP arithmetic is supplied by an oracle-backed test double (tests may use the oracle; the product backend is HIP-only)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from adkf_ift_amd.synthetic import make_tasks
+from adkf_ift_amd.trainer import MetaStepConfig, meta_step
+from oracle import gp_oracle as O
+
+
+class OracleBackend:
+    """Same three methods as trainer.HipGPBackend, float64 oracle inside (TEST DOUBLE)."""
+
+    def __init__(self, kind):
+        self.kind = kind
+        self.pris = None
+
+    def init(self, Z_s, cfg, n_s=None):
+        phis, self.pris = [], []
+        for t in range(Z_s.shape[0]):
+            phi, pri = O.init_phi(Z_s[t].double(), cfg.use_numeric_labels, cfg.use_lengthscale_prior)
+            phis.append(phi)
+            self.pris.append(pri)
+        return torch.stack(phis), torch.tensor(np.stack([p.as_array() for p in self.pris]))
+
+    def fit(self, Z_s, y_s, priors, phi0, cfg, n_s=None, events=None):
+        out = [O.fit_phi(Z_s[t].double(), y_s[t].double(), phi0[t], self.pris[t], self.kind)[0] for t in range(Z_s.shape[0])]
+        return torch.stack(out), torch.zeros(Z_s.shape[0], dtype=torch.int32)
+
+    def hypergrad(self, Z_s, y_s, Z_q, y_q, priors, phi, cfg, n_s=None, n_q=None):
+        f, ds, dq = [], [], []
+        for t in range(Z_s.shape[0]):
+            q = O.full_reference_quantities(Z_s[t], y_s[t], Z_q[t], y_q[t], phi[t], self.pris[t], self.kind)
+            f.append(q["f_out"])
+            ds.append(torch.tensor(q["dZs_total"] if not cfg.ignore_grad_correction else q["dZs_direct"]))
+            dq.append(torch.tensor(q["dZq_total"]))
+        return torch.tensor(f), torch.stack(ds), torch.stack(dq), torch.zeros(len(f), dtype=torch.int32)
+
+
+def _run_rank(rank, world, port, fixture, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    g = np.load(fixture)
+    T, N, d, kind = int(g["T"]), int(g["N"]), int(g["d"]), int(g["kind"])
+    per = T // world
+    tasks = make_tasks(per, N, d, first_task=500 + rank * per)
+    W = tasks.W.double().clone().requires_grad_(True)
+    opt = torch.optim.SGD([W], lr=0.5)
+    cfg = MetaStepConfig(gp_kernel="rbf" if kind == 0 else "matern", clip_value=1.0)
+    Xs, Xq = tasks.X_s.double(), tasks.X_q.double()
+    feats = lambda: (Xs @ W / math.sqrt(d), Xq @ W / math.sqrt(d))
+    W0 = W.detach().clone()
+    losses, phi = meta_step(feats, [W], opt, tasks.y_s.double(), tasks.y_q.double(), cfg, backend=OracleBackend(kind),
+                            distributed=world > 1)
+    ret[rank] = dict(grad=W.grad.clone().numpy(), step=(W0 - W.detach()).numpy() / 0.5, losses=losses.numpy(), phi=phi.numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_meta_step_matches_reference_loop(golden_dir, world):
+    fixture = os.path.join(golden_dir, "harness_T4_N16_d8_k0.npz")
+    g = np.load(fixture)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000) + world
+    if world == 1:
+        _run_rank(0, 1, port, fixture, ret)
+    else:
+        mp.spawn(_run_rank, args=(world, port, fixture, ret), nprocs=world, join=True)
+    scale = np.abs(g["grad_clipped"]).max()
+    for r in range(world):
+        # after all-reduce + /T + clip every rank holds the reference's clipped task-mean gradient ...
+        assert np.abs(ret[r]["grad"] - g["grad_clipped"]).max() <= 2e-6 * scale, r
+        # ... and has taken the identical optimiser step
+        assert np.abs(ret[r]["step"] - g["grad_clipped"]).max() <= 2e-6 * scale, r
+    if world == 2:
+        assert np.array_equal(ret[0]["grad"], ret[1]["grad"])
+    per = int(g["T"]) // world
+    for r in range(world):
+        sl = slice(r * per, (r + 1) * per)
+        assert np.abs(ret[r]["losses"] * int(g["N"]) - g["f_out"][sl]).max() <= 1e-6 * np.abs(g["f_out"]).max()
+        assert np.abs(ret[r]["phi"] - g["phi"][sl]).max() <= 1e-5
+
+
+def test_clip_happens_after_the_all_reduce(golden_dir):
+    g = np.load(os.path.join(golden_dir, "harness_T4_N16_d8_k0.npz"))
+    # the fixture is only a meaningful clip test if clipping is active
+    assert float(g["grad_norm"]) > 1.0
+    assert abs(np.linalg.norm(g["grad_clipped"]) - 1.0) < 1e-5

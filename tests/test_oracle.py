@@ -1,0 +1,88 @@
+"""CPU: pins the oracle itself.  (i) the autograd oracle reproduces the committed golden vectors (guards against
+drift of oracle/gp_oracle.py after the fixtures were generated); (ii) the closed-form staged restatement
+(oracle/closed_form.py, the algebra the HIP kernels implement) agrees with them; (iii) GPyTorch-semantics
+spot checks that are derivable by hand."""
+import glob
+import math
+import os
+
+import numpy as np
+import torch
+
+from oracle import closed_form as C
+from oracle import gp_oracle as O
+
+
+def rel(a, ref):
+    a, ref = np.asarray(a, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-300)
+
+
+def test_closed_form_matches_golden(golden_dir):
+    files = sorted(glob.glob(os.path.join(golden_dir, "gp_*.npz")))
+    assert len(files) >= 30
+    for f in files:
+        g = np.load(f)
+        out = C.full_pipeline(g["Z_s"], g["y_s"], g["Z_q"], g["y_q"], g["phi"], g["priors"], int(g["kind"]))
+        for k, v in out.items():
+            if k in g.files:
+                tol = 1e-6 if g[k].dtype == np.float32 else 1e-8
+                if k == "g_in":
+                    assert np.abs(np.asarray(v) - g[k]).max() <= 1e-8, (f, k)
+                else:
+                    assert rel(v, g[k]) <= tol, (os.path.basename(f), k, rel(v, g[k]))
+
+
+def test_autograd_oracle_reproduces_small_golden(golden_dir):
+    for name in ("gp_N8_Nq8_d4_k0_r0_s1", "gp_N16_Nq32_d16_k1_r1_s1", "gp_N5_Nq3_d7_k0_r0_s2"):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        pri = O.Priors(*g["priors"].tolist())
+        q = O.full_reference_quantities(torch.tensor(g["Z_s"]), torch.tensor(g["y_s"]), torch.tensor(g["Z_q"]),
+                                        torch.tensor(g["y_q"]), torch.tensor(g["phi"]), pri, int(g["kind"]))
+        for k in ("f_in", "g_in", "H", "f_out", "g_out", "v", "dZs_total", "dZq_total", "pred_mean", "pred_var", "l0"):
+            assert rel(q[k], g[k]) <= 1e-9, (name, k)
+
+
+def test_gpytorch_semantics_by_hand():
+    # A1: softplus parametrisation with the 1e-4 noise floor, raw_outputscale = 0 -> ln 2
+    phi = torch.tensor([0.3, 0.0, -0.2], dtype=torch.float64)
+    noise, os_, ls = O.transform_phi(phi)
+    assert abs(noise.item() - (math.log1p(math.exp(0.3)) + 1e-4)) < 1e-12
+    assert abs(os_.item() - math.log(2.0)) < 1e-12
+    # inverse transform used by `.noise = 0.1` / `.lengthscale = l0`
+    assert abs(torch.nn.functional.softplus(O.inv_softplus(0.37)).item() - 0.37) < 1e-12
+    # A4: LogNormal(loc = log(mode) + s^2, s) has its mode at `mode`
+    loc, sc = O.noise_prior_params(False)
+    xs = torch.linspace(0.05, 0.2, 3001, dtype=torch.float64)
+    lp = torch.stack([O.lognormal_log_prob(x, loc, sc) for x in xs])
+    assert abs(xs[lp.argmax()].item() - 0.1) < 1e-4
+    # A3: kernels at zero distance equal the outputscale; Matern-5/2 closed form at r = 1
+    Z = torch.zeros(2, 3, dtype=torch.float64)
+    Z[1, 0] = 2.0
+    one, two = torch.tensor(1.0, dtype=torch.float64), torch.tensor([2.0], dtype=torch.float64)
+    K = O.kernel_matrix(Z, Z, 1.7 * one, two, O.KERNEL_MATERN52)
+    assert abs(K[0, 0].item() - 1.7) < 1e-12
+    r = 1.0
+    assert abs(K[0, 1].item() - 1.7 * (1 + math.sqrt(5) * r + 5.0 / 3.0 * r * r) * math.exp(-math.sqrt(5) * r)) < 1e-12
+    K = O.kernel_matrix(Z, Z, 1.7 * one, two, O.KERNEL_RBF)
+    assert abs(K[0, 1].item() - 1.7 * math.exp(-0.5)) < 1e-12
+    # a3: torch.median is the LOWER median, over strictly-positive upper-triangle entries
+    Z = torch.tensor([[0.0], [1.0], [3.0], [3.0]], dtype=torch.float64)   # d2 in {1, 9, 9, 4, 4, 0}: positives 1,4,4,9,9
+    assert abs(O.median_lengthscale_init(Z).item() - math.sqrt(0.5 * 4.0)) < 1e-12
+    Z = torch.tensor([[0.0], [1.0], [3.0]], dtype=torch.float64)          # d2 in {1, 9, 4}; lower median of 3 = 4
+    assert abs(O.median_lengthscale_init(Z).item() - math.sqrt(0.5 * 4.0)) < 1e-12
+    Z = torch.tensor([[0.0], [1.0]], dtype=torch.float64)
+    assert abs(O.median_lengthscale_init(Z).item() - math.sqrt(0.5)) < 1e-12
+
+
+def test_mll_is_divided_by_n_after_priors():
+    torch.manual_seed(0)
+    Z = torch.randn(6, 3, dtype=torch.float64)
+    y = torch.randn(6, dtype=torch.float64)
+    phi = torch.tensor([0.1, 0.2, 0.3], dtype=torch.float64)
+    pri = O.Priors(-2.2, 0.25, 0.4, 0.25)
+    noise, os_, ls = O.transform_phi(phi)
+    A = O.kernel_matrix(Z, Z, os_, ls, 0) + noise * torch.eye(6, dtype=torch.float64)
+    mvn = torch.distributions.MultivariateNormal(torch.zeros(6, dtype=torch.float64), A).log_prob(y)
+    expect = -(mvn + O.lognormal_log_prob(noise, -2.2, 0.25) + O.lognormal_log_prob(ls, 0.4, 0.25)) / 6
+    assert abs(O.f_inner(Z, y, phi, pri, 0).item() - expect.item()) < 1e-12
