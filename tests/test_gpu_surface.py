@@ -104,20 +104,24 @@ def test_adkt_model_modes_and_fused_hypergradient(dev, kernel, numeric):
     assert abs(vo.item() - ro.item()) <= 1e-4 * abs(ro.item())
     g_got = torch.autograd.grad(vo, po + pi)
     g_ref = torch.autograd.grad(ro, po64 + pi64)
+    # (the last-layer bias has an exactly-zero gradient - distances are translation invariant - so errors are
+    # measured against the largest gradient entry of the whole parameter set, not per tensor)
+    gscale = max(b.abs().max().item() for b in g_ref[: len(po)])
     for a, b in zip(g_got, g_ref):
-        assert (a.double().cpu() - b).abs().max() <= 2e-4 * max(b.abs().max().item(), 1e-3)
+        assert (a.double().cpu() - b).abs().max() <= 2e-4 * max(b.abs().max().item(), gscale)
     # the fused IFT hypergradient == the reference algorithm (dense) on the float64 restatement
     val = cauchy_hypergradient(f_outer, f_inner, po, pi, dev)
     ref_val = dense_ift_hypergradient(fo_ref, fi_ref, po64, pi64)
     assert abs(val.item() - ref_val.item()) <= 1e-4 * abs(ref_val.item())
+    hscale = max(b.grad.abs().max().item() for b in po64)
     for a, b in zip(po, po64):
-        assert (a.grad.double().cpu() - b.grad).abs().max() <= 1e-3 * b.grad.abs().max().item(), (a.shape,)
+        assert (a.grad.double().cpu() - b.grad).abs().max() <= 1e-3 * max(b.grad.abs().max().item(), hscale), (a.shape,)
     for a, b in zip(pi, pi64):
         assert (a.grad.double().cpu() - b.grad).abs().max() <= 1e-3 * max(b.grad.abs().max().item(), 1e-2)
     # first-order flag
     cauchy_hypergradient(f_outer, f_inner, po, pi, dev, ignore_grad_correction=True)
     for a, b in zip(po, g_ref[: len(po)]):
-        assert (a.grad.double().cpu() - b).abs().max() <= 2e-4 * max(b.abs().max().item(), 1e-3)
+        assert (a.grad.double().cpu() - b).abs().max() <= 2e-4 * max(b.abs().max().item(), gscale)
     # eval mode: posterior with noise
     model.eval()
     post = model(batch, train_loss=None)
@@ -146,8 +150,7 @@ def test_dkl_model_surface(dev):
     Zs = model._features(batch.support_features).detach().double().cpu()
     ys = (batch.support_labels.double().cpu() - 0.5) * 2
     phi = torch.cat([p.detach().reshape(-1) for p in model.mll.raw_params()]).double().cpu()
-    ref = O.f_inner(Zs, ys, phi, O.Priors(0.0, -1.0, 0.0, 0.25), 0)
-    # no noise prior in DKL: emulate by evaluating the oracle without it
+    # no noise prior in DKL (fs_mol/models/dkl.py:86): evaluate the oracle's terms without it
     noise, os_, ls = O.transform_phi(phi)
     A = O.kernel_matrix(Zs, Zs, os_, ls, 0) + noise * torch.eye(Zs.shape[0], dtype=torch.float64)
     ref = -(O.mvn_log_prob(ys, torch.zeros_like(ys), A) + O.lognormal_log_prob(ls, 0.0, 0.25)) / Zs.shape[0]
