@@ -20,7 +20,7 @@ ERRORS = {-1: "bad argument", -2: "unsupported size (see adkf_max_points)", -3: 
 
 class Batch(C.Structure):
     _fields_ = [("T", C.c_int32), ("ns_max", C.c_int32), ("nq_max", C.c_int32), ("d", C.c_int32),
-                ("kernel", C.c_int32), ("reserved", C.c_int32),
+                ("kernel", C.c_int32), ("flags", C.c_int32),
                 ("n_s", C.c_void_p), ("n_q", C.c_void_p), ("Z_s", C.c_void_p), ("y_s", C.c_void_p),
                 ("Z_q", C.c_void_p), ("y_q", C.c_void_p), ("priors", C.c_void_p)]
 

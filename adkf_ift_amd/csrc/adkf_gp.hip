@@ -75,8 +75,12 @@ TaskView make_tv(const adkf_batch_t* b, const Workspace& w, bool with_query) {
 
 #define LAUNCH_OK() do { if (hipGetLastError() != hipSuccess) return ADKF_E_LAUNCH; } while (0)
 
-// Stage A: centring, row norms, squared distances.
+inline bool has_query(const adkf_batch_t* b) { return b->nq_max > 0 && b->Z_q != nullptr; }
+
+// Stage A: centring, row norms, squared distances.  Skipped when the caller promises (ADKF_BATCH_REUSE_DIST) that
+// this workspace already holds them for exactly this batch.
 int stage_dist(const adkf_batch_t* b, const Workspace& w, bool with_query, hipStream_t st) {
+    if (b->flags & ADKF_BATCH_REUSE_DIST) return 0;
     const int T = b->T, ns = b->ns_max, nq = with_query ? b->nq_max : 0, d = b->d;
     k_colmean<<<dim3(ceil_div(d, 256), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, T);
     k_rownorm<<<dim3(ceil_div(ns, 4), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, w.nrm_s, T);
@@ -140,9 +144,14 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
     const int T = b->T, ns = b->ns_max, nq = b->nq_max, d = b->d;
     int rc = stage_dist(b, w, true, st);
     if (rc) return rc;
-    InnerArgs ia = inner_args(b, w, const_cast<float*>(phi), info);
-    rc = launch_inner(ia, st);
-    if (rc) return rc;
+    if (b->flags & ADKF_BATCH_REUSE_INNER) {
+        // A^-1, alpha and the per-task scalars of phi are already in the workspace (left by adkf_fit)
+        hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)T, st);
+    } else {
+        InnerArgs ia = inner_args(b, w, const_cast<float*>(phi), info);
+        rc = launch_inner(ia, st);
+        if (rc) return rc;
+    }
     TaskView tv = make_tv(b, w, true);
     const int tms = ceil_div(ns, GT), tmq = ceil_div(nq, GT);
     const float dirscale = (flags & ADKF_IGNORE_DIRECT_GRAD) ? 0.f : 1.f;
@@ -208,12 +217,12 @@ int adkf_median_lengthscale(const adkf_batch_t* b, float* l0, void* ws, size_t w
     int rc = check_batch(b, false);
     if (rc) return rc;
     if (!l0 || !ws) return ADKF_E_BADARG;
-    Workspace w = carve(ws, b->T, b->ns_max, 0, b->d);
+    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    rc = stage_dist(b, w, false, st);
+    rc = stage_dist(b, w, has_query(b), st);
     if (rc) return rc;
-    k_median<<<grid_for(b->T, 1), 256, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T);
+    k_median<<<grid_for(b->T, 1), 512, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T);
     LAUNCH_OK();
     return 0;
 }
@@ -223,7 +232,7 @@ int adkf_init_params(const adkf_batch_t* b, int32_t use_numeric_labels, int32_t 
     int rc = check_batch(b, false);
     if (rc) return rc;
     if (!phi || !priors || !ws) return ADKF_E_BADARG;
-    Workspace w = carve(ws, b->T, b->ns_max, 0, b->d);
+    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     float* l0p = l0 ? l0 : w.l0;
     rc = adkf_median_lengthscale(b, l0p, ws, ws_bytes, stream);
@@ -239,10 +248,10 @@ int adkf_mll_value_grad(const adkf_batch_t* b, const float* phi, float* f_in, fl
     int rc = check_batch(b, false);
     if (rc) return rc;
     if (!phi || !f_in || !info || !ws || !b->y_s || !b->priors) return ADKF_E_BADARG;
-    Workspace w = carve(ws, b->T, b->ns_max, 0, b->d);
+    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    rc = stage_dist(b, w, false, st);
+    rc = stage_dist(b, w, has_query(b), st);
     if (rc) return rc;
     InnerArgs ia = inner_args(b, w, const_cast<float*>(phi), info);
     ia.f_out = f_in; ia.g_out = g_phi;
@@ -268,10 +277,10 @@ int adkf_fit(const adkf_batch_t* b, float* phi, const adkf_fit_options_t* opt, f
     int rc = check_batch(b, false);
     if (rc) return rc;
     if (!phi || !opt || !info || !ws || !b->y_s || !b->priors || opt->max_evals < 2) return ADKF_E_BADARG;
-    Workspace w = carve(ws, b->T, b->ns_max, 0, b->d);
+    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    rc = stage_dist(b, w, false, st);
+    rc = stage_dist(b, w, has_query(b), st);
     if (rc) return rc;
     InnerArgs ia = inner_args(b, w, phi, info);
     ia.f_out = f_final; ia.gnorm_out = gnorm; ia.nevals_out = n_evals;
@@ -292,9 +301,13 @@ int adkf_predict(const adkf_batch_t* b, const float* phi, float* mean, float* va
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = stage_dist(b, w, true, st);
     if (rc) return rc;
-    InnerArgs ia = inner_args(b, w, const_cast<float*>(phi), info);
-    rc = launch_inner(ia, st);
-    if (rc) return rc;
+    if (b->flags & ADKF_BATCH_REUSE_INNER) {
+        hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)b->T, st);
+    } else {
+        InnerArgs ia = inner_args(b, w, const_cast<float*>(phi), info);
+        rc = launch_inner(ia, st);
+        if (rc) return rc;
+    }
     TaskView tv = make_tv(b, w, true);
     const int T = b->T, tms = ceil_div(b->ns_max, GT), tmq = ceil_div(b->nq_max, GT);
     ProbC pc; pc.tv = tv; pc.Ainv = w.Ainv; pc.D2qs = w.D2qs; pc.C = w.C;

@@ -1,109 +1,278 @@
-// Workgroup-cooperative, LDS-resident factorisation + inversion of one SPD matrix (n <= NMAX).
+// Workgroup-cooperative factorisation + inversion of one SPD matrix (n <= NMAX) with the matrix held in
+// REGISTERS: thread (br, bc) owns the RB x CB block  rows br*RB.., cols bc*CB..  of the full symmetric matrix.
 //
-// Square-root-free Cholesky (A = L D L^T, no pivoting: the pivots are exactly the squares of the
-// Cholesky diagonal, so "k-th pivot <= 0" is the reference's NotPSD condition) carried out as ONE
-// right-looking sweep over the augmented system [A | I]: after step k the rows below k hold the Schur
-// complement (buf0, lower triangle) and the running rows of the unit-lower inverse X = L^-1 (buf1).
-// Column k of buf0 and row k of buf1 are read-only during step k, so one barrier per step suffices.
-// Then A^-1 = X^T D^-1 X (register-tiled product), log|A| = sum log d_k.
+// Algorithm: the symmetric sweep operator (Gauss-Jordan without pivoting), blocked by B = CB pivots.  The pivots
+// p_k are exactly those of the LDL^T (the squared Cholesky diagonal), so "p_k <= 0" is the reference's
+// not-positive-definite condition and log|A| = sum_k log p_k; after sweeping every index M = -A^-1.
+//
+// One block step sweeps the B x B diagonal block D = M_PP (held by ONE thread).  With C = M_P. (the B pivot rows)
+// and F = D^-1 C the classical block sweep is
+//       M_RR -= C_R^T F_R,   M_RP = F_R^T,   M_PR = F_R,   M_PP = -D^-1.
+// All four cases collapse into ONE uniform rank-B update  M_ij -= sum_a F_a,i C_a,j  over the whole matrix - no
+// per-element select in the hot loop - if the holder of D first replaces, in its own registers, the C entries at
+// the pivot columns by D - I and M_PP by D - 2I (F = D^-1 C then gives I - D^-1 there by itself):
+//       i in R, j = P_b :  c_b,i - sum_a f_a,i (D_ab - d_ab)                     = f_b,i
+//       i = P_b, j in R :  c_b,j - sum_a (d_ab - Dinv_ab) c_a,j                  = f_b,j
+//       i = P_b, j = P_c:  (D_bc - 2 d_bc) - sum_a (d_ab - Dinv_ab)(D_ac - d_ac) = -Dinv_bc
+// Per block step only the B pivot rows (C) and their scaled copies (F) travel through LDS, published by the 1/NBR
+// of the threads that own them, double-buffered, with ONE barrier per B pivots; everything else is register FMAs.
+// The owners obtain D by v_readlane from the holder's lane and invert it redundantly (same instruction stream).
+// Rows/cols >= n are padded with the identity; sweeping them is a no-op that leaves -1 on the diagonal.
 #pragma once
+#include <limits.h>
+
 #include "device_utils.h"
 
 namespace adkf {
 
-template <int NMAX>
-struct FactorShape {
-    static constexpr int LD = NMAX + 1;  // odd leading dimension: column walks are bank-conflict-free
-    static constexpr int ELEMS = NMAX * LD;
+template <int NMAX, int NT> struct SweepCfg;
+template <> struct SweepCfg<128, 512> { static constexpr int RB = 8, CB = 4; };
+template <> struct SweepCfg<64, 256> { static constexpr int RB = 4, CB = 4; };
+template <> struct SweepCfg<32, 256> { static constexpr int RB = 2, CB = 2; };
+template <> struct SweepCfg<16, 256> { static constexpr int RB = 1, CB = 1; };
+
+template <int NMAX, int NT>
+struct SweepSmem {
+    static constexpr int B = SweepCfg<NMAX, NT>::CB;
+    alignas(16) float cross[2][B][NMAX];  // C: the B pivot rows (with D - I at the pivot columns)
+    alignas(16) float fvec[2][B][NMAX];   // F = D^-1 C
+    alignas(16) float pivs[NMAX];
+    alignas(16) float vec_in[NMAX];       // right-hand side of the solve (y or r)
+    alignas(16) float vec_out[NMAX];      // A^-1 * vec_in
+    float red[8 * (NT / 64)];
+    int redi[NT / 64];
 };
 
-// In: buf0 lower triangle (incl. diagonal) = A, buf1 = anything.  Out: buf1 rows = X scaled by
-// 1/sqrt(d_k) (so A^-1 = buf1^T buf1), dinv[k] = 1/d_k, returns info (0 or first bad pivot + 1) and
-// log-determinant through `logdet`.  All threads must call; all get the same return values.
-template <int NMAX, int NT>
-__device__ __forceinline__ int ldl_sweep(float* __restrict__ buf0, float* __restrict__ buf1, float* __restrict__ dinv,
-                                         int n, float& logdet, float* red) {
-    constexpr int LD = FactorShape<NMAX>::LD;
-    const int tid = threadIdx.x;
-    const int tx = tid & 31, ty = tid >> 5;
-    constexpr int NY = NT / 32;
-    // buf1 = I (lower part)
-    for (int e = tid; e < n * n; e += NT) {
-        const int i = e / n, j = e - i * n;
-        if (j <= i) buf1[i * LD + j] = (i == j) ? 1.f : 0.f;
-    }
-    int info = 0;
-    float ld_acc = 0.f;
-    for (int k = 0; k < n; ++k) {
-        __syncthreads();
-        const float p = buf0[k * LD + k];
-        if (!(p > 0.f)) {  // also catches NaN
-            if (info == 0) info = k + 1;
-        }
-        const float ip = 1.f / p;
-        if (tid == 0) dinv[k] = ip;
-        ld_acc += logf(p);
-        for (int i = k + 1 + ty; i < n; i += NY) {
-            const float f = buf0[i * LD + k] * ip;
-            // Schur complement, columns (k, i]
-            for (int j = k + 1 + tx; j <= i; j += 32) buf0[i * LD + j] -= f * buf0[j * LD + k];
-            // inverse rows, columns [0, k]
-            for (int j = tx; j <= k; j += 32) buf1[i * LD + j] -= f * buf1[k * LD + j];
-        }
-    }
-    __syncthreads();
-    // scale row k of X by sqrt(1/d_k)
-    for (int e = tid; e < n * n; e += NT) {
-        const int i = e / n, j = e - i * n;
-        if (j <= i) buf1[i * LD + j] *= sqrtf(dinv[i]);
-    }
-    __syncthreads();
-    logdet = ld_acc;
-    (void)red;
-    return info;
+__device__ __forceinline__ float fast_rcp(float p) {
+    float r = __builtin_amdgcn_rcpf(p);     // v_rcp_f32, 1 ulp
+    return fmaf(fmaf(-p, r, 1.f), r, r);    // one Newton step: ~0.5 ulp, 3 instructions instead of the 10 of a full divide
 }
 
-// out (full symmetric, LD) = Y^T Y with Y = buf1 lower-triangular [n x n]:  out_ij = sum_{k>=max(i,j)} Y_ki Y_kj
+// In-register inverse of the B x B SPD pivot block; piv = its successive LDL^T pivots.  This sits on the critical
+// path of the whole sweep (every block step waits for it), so it is written for instruction-level parallelism:
+// closed-form 2 x 2 inverses and one Schur complement - two dependent reciprocals instead of four.
+__device__ __forceinline__ void inv2(float a, float b, float c, float& ia, float& ib, float& ic, float& det) {
+    det = fmaf(a, c, -b * b);
+    const float r = fast_rcp(det);
+    ia = c * r; ib = -b * r; ic = a * r;
+}
+template <int B> struct InvSpd;
+template <> struct InvSpd<1> {
+    __device__ static __forceinline__ void run(float (&D)[1][1], float (&piv)[1]) { piv[0] = D[0][0]; D[0][0] = fast_rcp(D[0][0]); }
+};
+template <> struct InvSpd<2> {
+    __device__ static __forceinline__ void run(float (&D)[2][2], float (&piv)[2]) {
+        float ia, ib, ic, det;
+        const float a = D[0][0];
+        inv2(a, D[0][1], D[1][1], ia, ib, ic, det);
+        piv[0] = a; piv[1] = det * fast_rcp(a);
+        D[0][0] = ia; D[0][1] = ib; D[1][0] = ib; D[1][1] = ic;
+    }
+};
+template <> struct InvSpd<4> {
+    __device__ static __forceinline__ void run(float (&D)[4][4], float (&piv)[4]) {
+        // D = [[P, Q], [Q^T, R]]
+        float pa, pb, pc, detP;
+        inv2(D[0][0], D[0][1], D[1][1], pa, pb, pc, detP);                 // P^-1
+        const float q00 = D[0][2], q01 = D[0][3], q10 = D[1][2], q11 = D[1][3];
+        const float t00 = fmaf(pa, q00, pb * q10), t01 = fmaf(pa, q01, pb * q11);   // T = P^-1 Q
+        const float t10 = fmaf(pb, q00, pc * q10), t11 = fmaf(pb, q01, pc * q11);
+        const float s00 = D[2][2] - fmaf(q00, t00, q10 * t10);                        // S = R - Q^T T
+        const float s01 = D[2][3] - fmaf(q00, t01, q10 * t11);
+        const float s11 = D[3][3] - fmaf(q01, t01, q11 * t11);
+        float sa, sb, sc, detS;
+        inv2(s00, s01, s11, sa, sb, sc, detS);                             // S^-1
+        const float u00 = fmaf(t00, sa, t01 * sb), u01 = fmaf(t00, sb, t01 * sc);   // U = T S^-1
+        const float u10 = fmaf(t10, sa, t11 * sb), u11 = fmaf(t10, sb, t11 * sc);
+        piv[0] = D[0][0]; piv[1] = detP * fast_rcp(D[0][0]); piv[2] = s00; piv[3] = detS * fast_rcp(s00);
+        D[0][0] = pa + fmaf(u00, t00, u01 * t01); D[0][1] = pb + fmaf(u00, t10, u01 * t11); D[1][1] = pc + fmaf(u10, t10, u11 * t11);
+        D[1][0] = D[0][1];
+        D[0][2] = -u00; D[0][3] = -u01; D[1][2] = -u10; D[1][3] = -u11;
+        D[2][0] = -u00; D[3][0] = -u01; D[2][1] = -u10; D[3][1] = -u11;
+        D[2][2] = sa; D[2][3] = sb; D[3][2] = sb; D[3][3] = sc;
+    }
+};
+
 template <int NMAX, int NT>
-__device__ __forceinline__ void ata_lower(const float* __restrict__ Y, float* __restrict__ out, int n) {
-    constexpr int LD = FactorShape<NMAX>::LD;
-    const int nb = (n + 3) >> 2;               // 4x4 register tiles
-    const int ntiles = nb * (nb + 1) / 2;
-    for (int tl = threadIdx.x; tl < ntiles; tl += NT) {
-        // tl -> (bi >= bj)
-        int bi = (int)((sqrtf(8.f * tl + 1.f) - 1.f) * 0.5f);
-        while ((bi + 1) * (bi + 2) / 2 <= tl) ++bi;
-        while (bi * (bi + 1) / 2 > tl) --bi;
-        const int bj = tl - bi * (bi + 1) / 2;
-        const int i0 = bi * 4, j0 = bj * 4;
-        float acc[4][4];
+struct Sweep {
+    static constexpr int RB = SweepCfg<NMAX, NT>::RB, CB = SweepCfg<NMAX, NT>::CB, B = CB;
+    static constexpr int NBC = NMAX / CB, NBR = NMAX / RB;
+    static constexpr int QPB = RB / CB;  // pivot blocks per block row
+    static_assert(NBC * NBR == NT, "one block per thread");
+    static_assert(NBC <= 32, "a row of blocks must sit inside a 32-lane half wave (shuffle reduction)");
+    static_assert(RB % CB == 0, "CB must divide RB");
+
+    __device__ static __forceinline__ int bc() { return threadIdx.x % NBC; }
+    __device__ static __forceinline__ int br() { return threadIdx.x / NBC; }
+
+    // The owners of pivot block q (rows q*B .. q*B+B-1) publish C and F for block step q into buffer `buf`.
+    // QR = q % QPB is a compile-time constant (the loop is unrolled by QPB): all register indices are static.
+    template <int QR>
+    __device__ static __forceinline__ void publish(float (&m)[RB][CB], int q, int buf, SweepSmem<NMAX, NT>& sm) {
+        constexpr int RO = QR * CB;  // row offset of the pivot rows inside this thread's block
+        const int kb = q / QPB;      // block row that owns the pivot rows
+        const int plane = (kb * NBC + q) & 63;  // lane (in the owning wave) of the thread that holds D
+        float D[B][B];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < B; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-        for (int k = i0; k < n; ++k) {
-            float yi[4], yj[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                yi[a] = (i0 + a <= k) ? Y[k * LD + i0 + a] : 0.f;  // Y is lower-triangular: Y_k,c = 0 for c > k
-                yj[a] = Y[k * LD + j0 + a];                        // j0 + a <= i0 + 3; entries above the diagonal masked by yi
+            for (int b = 0; b <= a; ++b) {
+                D[a][b] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m[RO + a][b]), plane));
+                D[b][a] = D[a][b];
             }
+        if (br() == kb) {
+            const int j0 = bc() * CB;
+            float C[B][CB], F[B][CB], piv[B];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < B; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] += yi[a] * ((j0 + b <= k) ? yj[b] : 0.f);
-        }
+                for (int c = 0; c < CB; ++c) C[a][c] = m[RO + a][c];
+            if (bc() == q) {  // this thread holds D: C := D - I at the pivot columns, M_PP := D - 2I
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int i = i0 + a, j = j0 + b;
-                if (i < n && j < n) {
-                    out[i * LD + j] = acc[a][b];
-                    out[j * LD + i] = acc[a][b];
+                for (int a = 0; a < B; ++a) {
+                    C[a][a] -= 1.f;
+                    m[RO + a][a] -= 2.f;
                 }
             }
+            InvSpd<B>::run(D, piv);
+            if (bc() == q) {
+#pragma unroll
+                for (int a = 0; a < B; ++a) sm.pivs[q * B + a] = piv[a];
+            }
+#pragma unroll
+            for (int a = 0; a < B; ++a)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int b = 0; b < B; ++b) s = fmaf(D[a][b], C[b][c], s);
+                    F[a][c] = s;
+                }
+#pragma unroll
+            for (int a = 0; a < B; ++a)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    sm.cross[buf][a][j0 + c] = C[a][c];
+                    sm.fvec[buf][a][j0 + c] = F[a][c];
+                }
+        }
     }
-}
+
+    // rank-B update of rows [R0, R1) of this thread's block from the vectors of one block step
+    template <int R0, int R1>
+    __device__ static __forceinline__ void update_rows(float (&m)[RB][CB], const float (&fi)[B][RB], const float (&cj)[B][CB]) {
+#pragma unroll
+        for (int a = 0; a < B; ++a)
+#pragma unroll
+            for (int r = R0; r < R1; ++r)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) m[r][c] = fmaf(-fi[a][r], cj[a][c], m[r][c]);
+    }
+
+    __device__ static __forceinline__ void load_vectors(int q, SweepSmem<NMAX, NT>& sm, float (&fi)[B][RB], float (&cj)[B][CB]) {
+        const int i0 = br() * RB, j0 = bc() * CB, b = q & 1;
+#pragma unroll
+        for (int a = 0; a < B; ++a) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) fi[a][r] = sm.fvec[b][a][i0 + r];
+#pragma unroll
+            for (int c = 0; c < CB; ++c) cj[a][c] = sm.cross[b][a][j0 + c];
+        }
+    }
+
+    // (kept for the ablation harness tools/sweep_bench.hip)
+    __device__ static __forceinline__ void step(float (&m)[RB][CB], int q, SweepSmem<NMAX, NT>& sm) {
+        float fi[B][RB], cj[B][CB];
+        load_vectors(q, sm, fi, cj);
+        update_rows<0, RB>(m, fi, cj);
+    }
+
+    // One block step.  The chain  update(next pivot rows) -> D^-1 -> F -> LDS  of the wave that owns the NEXT pivot
+    // block is the critical path of the sweep (everybody waits for it at the next barrier), so that wave runs it
+    // first and at raised priority, and only then finishes the rest of its own update.
+    template <int QR>
+    __device__ static __forceinline__ void steps(float (&m)[RB][CB], int q0, int nq, SweepSmem<NMAX, NT>& sm) {
+        if constexpr (QR < QPB) {
+            constexpr int NQR = (QR + 1) % QPB;  // row group (inside a block row) of the next pivot rows
+            constexpr int N0 = NQR * CB, N1 = NQR * CB + CB;
+            const int q = q0 + QR;
+            __syncthreads();
+            float fi[B][RB], cj[B][CB];
+            load_vectors(q, sm, fi, cj);
+            const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            const int own_wave = (((q + 1) / QPB) * NBC) >> 6;  // wave that holds the next pivot rows
+            if (q + 1 < nq && wave == own_wave) {
+                update_rows<N0, N1>(m, fi, cj);
+                __builtin_amdgcn_s_setprio(3);
+                publish<NQR>(m, q + 1, (q + 1) & 1, sm);
+                __builtin_amdgcn_s_setprio(0);
+                update_rows<0, N0>(m, fi, cj);
+                update_rows<N1, RB>(m, fi, cj);
+            } else {
+                update_rows<0, RB>(m, fi, cj);
+            }
+            steps<QR + 1>(m, q0, nq, sm);
+        }
+    }
+
+    // In: m = this thread's block of the SPD matrix (identity-padded beyond n).  Out: m = -(A^-1); the pivots are
+    // left in sm.pivs[0..n) (finish() turns them into info and log-determinant).  All threads call.
+    __device__ static __forceinline__ void run(float (&m)[RB][CB], int n, SweepSmem<NMAX, NT>& sm) {
+        const int nrow = ((n + RB - 1) / RB) * RB;  // whole block rows: sweeping identity padding is a no-op
+        const int nq = nrow / B;
+        publish<0>(m, 0, 0, sm);
+        for (int q0 = 0; q0 < nq; q0 += QPB) steps<0>(m, q0, nq, sm);
+        __syncthreads();
+    }
+
+    // log-determinant and info from the pivots.  Contains barriers; all threads call; all get the same values.
+    __device__ static __forceinline__ int finish(int n, SweepSmem<NMAX, NT>& sm, float& logdet) {
+        const int tid = threadIdx.x;
+        float v[1] = {0.f};
+        int bad = INT_MAX;
+        for (int k = tid; k < n; k += NT) {
+            const float p = sm.pivs[k];
+            v[0] += logf(p);
+            if (!(p > 0.f) && k + 1 < bad) bad = k + 1;
+        }
+        block_sum<1, NT>(v, sm.red);
+        logdet = v[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(bad, o, 64); bad = other < bad ? other : bad; }
+        __syncthreads();
+        if ((tid & 63) == 0) sm.redi[tid >> 6] = bad;
+        __syncthreads();
+        int info = INT_MAX;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) info = sm.redi[w] < info ? sm.redi[w] : info;
+        return info == INT_MAX ? 0 : info;
+    }
+
+    // out[i] = sum_j (-m_ij) in[j]  for i < NMAX, i.e. A^-1 * in.  `in` must be visible (barrier before);
+    // `out` is visible to all threads on return (barrier inside).
+    __device__ static __forceinline__ void solve(const float (&m)[RB][CB], const float* in, float* out) {
+        const int i0 = br() * RB, j0 = bc() * CB;
+        float s[RB];
+        float x[CB];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) x[c] = in[j0 + c];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < CB; ++c) a -= m[r][c] * x[c];
+            s[r] = a;
+        }
+#pragma unroll
+        for (int o = NBC / 2; o > 0; o >>= 1)
+#pragma unroll
+            for (int r = 0; r < RB; ++r) s[r] += __shfl_xor(s[r], o, 64);
+        if (bc() == 0) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) out[i0 + r] = s[r];
+        }
+        __syncthreads();
+    }
+};
 
 }  // namespace adkf

@@ -1,8 +1,9 @@
 // k_inner: one workgroup per task.  Evaluates f_inner = -MLL/N with its exact gradient at phi
 // (oracle/closed_form.py::inner_stage) and, in fit mode, runs the whole quasi-Newton inner optimisation
-// (the reference's host-side SciPy L-BFGS-B, fs_mol/utils/adaptive_dkt_utils.py:91) inside this one launch:
-// the squared-distance matrix stays in registers for the entire fit, the kernel matrix / factor / inverse
-// live in LDS, and nothing touches the host between iterations.
+// (the reference's host-side SciPy L-BFGS-B, fs_mol/utils/adaptive_dkt_utils.py:91) inside this one launch.
+// Everything big lives in REGISTERS for the entire fit: each thread owns one RB x CB block of the squared
+// distances, of the kernel matrix being swept into -(A^-1) (factor.h) and of dK/dl; LDS only carries the pivot row
+// of the current sweep step, y, alpha and reduction scratch (< 4 KB), so several tasks can share a CU.
 #pragma once
 #include "factor.h"
 
@@ -28,235 +29,268 @@ struct InnerArgs {
     float gtol, ftol;
 };
 
-template <int NMAX, int NT>
-struct InnerSmem {
-    float buf0[FactorShape<NMAX>::ELEMS];
-    float buf1[FactorShape<NMAX>::ELEMS];
-    float y[NMAX];
-    float w[NMAX];
-    float alpha[NMAX];
-    float dinv[NMAX];
-    float red[8 * (NT / 64)];
-};
-
-// One evaluation.  d2r = this thread's register-resident slice of D2 (element e = r * NT + tid).
-// Returns f and raw-space gradient g[3]; leaves A^-1 in sm.buf0 (full symmetric), alpha in sm.alpha.
 template <int NMAX, int NT, int KIND>
-__device__ __forceinline__ int inner_eval(InnerSmem<NMAX, NT>& sm, const float (&d2r)[NMAX * NMAX / NT], int n,
-                                          const float* x, const float* pri, float& f, float* g, float* extra) {
-    constexpr int LD = FactorShape<NMAX>::LD;
-    constexpr int EPT = NMAX * NMAX / NT;
-    const int tid = threadIdx.x;
-    const float noise = softplus_f(x[0]) + NOISE_LB, os = softplus_f(x[1]), ls = softplus_f(x[2]);
-    const float d1n = sigmoid_f(x[0]), d1s = sigmoid_f(x[1]), d1l = sigmoid_f(x[2]);
-    const float il2 = 1.f / (ls * ls);
+struct InnerEval {
+    using SW = Sweep<NMAX, NT>;
+    static constexpr int RB = SW::RB, CB = SW::CB;
 
-    __syncthreads();  // previous users of buf0 are done
+    // One evaluation at raw parameters x.  d2 = this thread's block of squared distances.  On return m = -(A^-1)
+    // (this thread's block), sm.vec_out = alpha.  extra (9 floats) receives the scalars later stages reuse.
+    __device__ static __forceinline__ int run(SweepSmem<NMAX, NT>& sm, const float (&d2)[RB][CB], float (&m)[RB][CB], int n,
+                                              const float* x, const float* pri, float& f, float* g, float* extra,
+                                              bool fast) {
+        const int i0 = SW::br() * RB, j0 = SW::bc() * CB, tid = threadIdx.x;
+        const float noise = softplus_f(x[0]) + NOISE_LB, os = softplus_f(x[1]), ls = softplus_f(x[2]);
+        const float d1n = sigmoid_f(x[0]), d1s = sigmoid_f(x[1]), d1l = sigmoid_f(x[2]);
+        const float il2 = 1.f / (ls * ls), gl = -2.f / ls;
 #pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-        const int e = r * NT + tid;
-        const int i = e / NMAX, j = e % NMAX;
-        if (i < n && j <= i) {
-            float k0, k1, k2;
-            kappa3<KIND>(d2r[r] * il2, k0, k1, k2);
-            sm.buf0[i * LD + j] = os * k0 + (i == j ? noise : 0.f);
-        }
-    }
-    float logdet;
-    const int info = ldl_sweep<NMAX, NT>(sm.buf0, sm.buf1, sm.dinv, n, logdet, sm.red);
-    // w = Y y ; alpha = Y^T w ; y^T alpha = |w|^2 ; tr(A^-1) = |Y|_F^2
-    if (tid < n) {
-        float s = 0.f;
-        for (int j = 0; j <= tid; ++j) s += sm.buf1[tid * LD + j] * sm.y[j];
-        sm.w[tid] = s;
-    }
-    __syncthreads();
-    if (tid < n) {
-        float s = 0.f;
-        for (int k = tid; k < n; ++k) s += sm.buf1[k * LD + tid] * sm.w[k];
-        sm.alpha[tid] = s;
-    }
-    ata_lower<NMAX, NT>(sm.buf1, sm.buf0, n);
-    __syncthreads();
-    // traces
-    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // tr(Ainv G), a^T G a, tr(Ainv), a^T a, y^T a
-    const float gl = -2.f / ls;
+        for (int r = 0; r < RB; ++r)
 #pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-        const int e = r * NT + tid;
-        const int i = e / NMAX, j = e % NMAX;
-        if (i < n && j < n) {
-            float k0, k1, k2;
-            const float u = d2r[r] * il2;
-            kappa3<KIND>(u, k0, k1, k2);
-            const float G = os * k1 * u * gl;
-            acc[0] += sm.buf0[i * LD + j] * G;
-            acc[1] += sm.alpha[i] * sm.alpha[j] * G;
+            for (int c = 0; c < CB; ++c) {
+                const int i = i0 + r, j = j0 + c;
+                if (i < n && j < n) {
+                    const float u = d2[r][c] * il2;
+                    m[r][c] = os * (fast ? kappa0_t<KIND, true>(u) : kappa0_t<KIND, false>(u)) + (i == j ? noise : 0.f);
+                }
+                else m[r][c] = (i == j) ? 1.f : 0.f;
+            }
+        __syncthreads();  // previous readers of sm (cross/vec_out) are done
+        SW::run(m, n, sm);
+        SW::solve(m, sm.vec_in, sm.vec_out);  // alpha = A^-1 y
+        float logdet;
+        const int info = SW::finish(n, sm, logdet);
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // tr(Ainv G), a^T G a, tr(Ainv), a^T a, y^T a
+        float ai[RB], aj[CB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) ai[r] = sm.vec_out[i0 + r];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) aj[c] = sm.vec_out[j0 + c];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                // dK/dl regenerated from the distances (cheaper than 32 more live registers per lane);
+                // zero outside n x n because d2 is zero there
+                float k0, k1, k2;
+                const float u = d2[r][c] * il2;
+                if (fast) kappa3<KIND, true>(u, k0, k1, k2); else kappa3<KIND, false>(u, k0, k1, k2);
+                const float G = os * k1 * u * gl;
+                acc[0] -= m[r][c] * G;
+                acc[1] += ai[r] * aj[c] * G;
+                if (i0 + r == j0 + c && i0 + r < n) acc[2] -= m[r][c];
+            }
+        if (tid < n) {
+            const float a = sm.vec_out[tid];
+            acc[3] = a * a;
+            acc[4] = sm.vec_in[tid] * a;
         }
-    }
-    if (tid < n) {
-        acc[2] = sm.buf0[tid * LD + tid];
-        acc[3] = sm.alpha[tid] * sm.alpha[tid];
-        acc[4] = sm.y[tid] * sm.alpha[tid];
-    }
-    block_sum<5, NT>(acc, sm.red);
-    const float trAinvG = acc[0], aGa = acc[1], trAinv = acc[2], aa = acc[3], ya = acc[4];
-    const float fn = (float)n;
-    const float nll = 0.5f * ya + 0.5f * logdet + 0.5f * fn * LOG_2PI;
-    // LogNormal priors on the transformed values (oracle/closed_form.py::lognormal_terms)
-    float lp = 0.f, dpn = 0.f, dpl = 0.f;
-    if (pri[1] > 0.f) {
-        const float lx = logf(noise), sc = pri[1], z = (lx - pri[0]) / (sc * sc);
-        lp += -lx - logf(sc) - 0.5f * LOG_2PI - 0.5f * (lx - pri[0]) * z;
-        dpn = (-1.f - z) / noise;
-    }
-    if (pri[3] > 0.f) {
-        const float lx = logf(ls), sc = pri[3], z = (lx - pri[2]) / (sc * sc);
-        lp += -lx - logf(sc) - 0.5f * LOG_2PI - 0.5f * (lx - pri[2]) * z;
-        dpl = (-1.f - z) / ls;
-    }
-    f = (nll - lp) / fn;
-    const float gt0 = 0.5f * trAinv - 0.5f * aa - dpn;
-    const float gt1 = (0.5f * (fn - noise * trAinv) - 0.5f * (ya - noise * aa)) / os;
-    const float gt2 = 0.5f * trAinvG - 0.5f * aGa - dpl;
-    g[0] = gt0 * d1n / fn;
-    g[1] = gt1 * d1s / fn;
-    g[2] = gt2 * d1l / fn;
-    if (extra) {
+        block_sum<5, NT>(acc, sm.red);
+        const float trAinvG = acc[0], aGa = acc[1], trAinv = acc[2], aa = acc[3], ya = acc[4];
+        const float fn = (float)n;
+        const float nll = 0.5f * ya + 0.5f * logdet + 0.5f * fn * LOG_2PI;
+        // LogNormal priors on the transformed values (oracle/closed_form.py::lognormal_terms)
+        float lp = 0.f, dpn = 0.f, dpl = 0.f;
+        if (pri[1] > 0.f) {
+            const float lx = logf(noise), sc = pri[1], z = (lx - pri[0]) / (sc * sc);
+            lp += -lx - logf(sc) - 0.5f * LOG_2PI - 0.5f * (lx - pri[0]) * z;
+            dpn = (-1.f - z) / noise;
+        }
+        if (pri[3] > 0.f) {
+            const float lx = logf(ls), sc = pri[3], z = (lx - pri[2]) / (sc * sc);
+            lp += -lx - logf(sc) - 0.5f * LOG_2PI - 0.5f * (lx - pri[2]) * z;
+            dpl = (-1.f - z) / ls;
+        }
+        f = (nll - lp) / fn;
+        const float gt0 = 0.5f * trAinv - 0.5f * aa - dpn;
+        const float gt1 = (0.5f * (fn - noise * trAinv) - 0.5f * (ya - noise * aa)) / os;
+        const float gt2 = 0.5f * trAinvG - 0.5f * aGa - dpl;
+        g[0] = gt0 * d1n / fn;
+        g[1] = gt1 * d1s / fn;
+        g[2] = gt2 * d1l / fn;
         extra[0] = logdet; extra[1] = trAinv; extra[2] = aa; extra[3] = ya; extra[4] = trAinvG; extra[5] = aGa;
         extra[6] = gt0; extra[7] = gt1; extra[8] = gt2;
+        if (info != 0 || !(f == f)) {
+            f = INFINITY;
+            return info != 0 ? info : n + 1;
+        }
+        return 0;
     }
-    if (info != 0 || !(f == f)) {
-        f = INFINITY;
-        return info != 0 ? info : n + 1;
+};
+
+// Quasi-Newton driver state (identical in every lane: all inputs come from block-wide reductions).
+struct Bfgs {
+    float x[3], f, g[3];      // current accepted point
+    float Hi[3][3];           // inverse-Hessian approximation
+    float p[3], gp, step;     // search direction, directional derivative, trial step
+    int bt;                   // backtracks on the current direction
+    bool first;
+
+    __device__ __forceinline__ void reset_H() {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Hi[i][j] = (i == j) ? 1.f : 0.f;
+        first = true;
     }
-    return 0;
+    // new search direction from (g, Hi); false when the gradient vanishes
+    __device__ __forceinline__ bool direction() {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) p[i] = -(Hi[i][0] * g[0] + Hi[i][1] * g[1] + Hi[i][2] * g[2]);
+        gp = g[0] * p[0] + g[1] * p[1] + g[2] * p[2];
+        if (!(gp < 0.f)) {  // not a descent direction (or NaN): restart from steepest descent
+            reset_H();
+#pragma unroll
+            for (int i = 0; i < 3; ++i) p[i] = -g[i];
+            gp = -(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+            if (!(gp < 0.f)) return false;
+        }
+        step = first ? fminf(1.f, 1.f / (fabsf(g[0]) + fabsf(g[1]) + fabsf(g[2]))) : 1.f;
+        bt = 0;
+        return true;
+    }
+    __device__ __forceinline__ void trial(float* xe) const {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xe[i] = x[i] + step * p[i];
+    }
+    // accept (xn, fn, gn): BFGS update of Hi
+    __device__ __forceinline__ void accept(const float* xn, float fn, const float* gn) {
+        float s[3], yv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { s[i] = xn[i] - x[i]; yv[i] = gn[i] - g[i]; x[i] = xn[i]; g[i] = gn[i]; }
+        f = fn;
+        const float sy = s[0] * yv[0] + s[1] * yv[1] + s[2] * yv[2];
+        const float yy = yv[0] * yv[0] + yv[1] * yv[1] + yv[2] * yv[2];
+        const float ss = s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
+        if (sy > 1e-10f * sqrtf(ss * yy) && yy > 0.f) {
+            if (first) {
+                const float sc = sy / yy;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) Hi[i][j] = (i == j) ? sc : 0.f;
+                first = false;
+            }
+            const float rho = 1.f / sy;
+            float Hy[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) Hy[i] = Hi[i][0] * yv[0] + Hi[i][1] * yv[1] + Hi[i][2] * yv[2];
+            const float yHy = yv[0] * Hy[0] + yv[1] * Hy[1] + yv[2] * Hy[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    Hi[i][j] += -rho * (s[i] * Hy[j] + Hy[i] * s[j]) + rho * (rho * yHy + 1.f) * s[i] * s[j];
+        }
+    }
+};
+
+// Optimiser state shared by the workgroup.  It lives in LDS (not in every lane's registers: wave-uniform floats
+// cannot sit in SGPRs on CDNA, and ~40 of them per lane were pushing the 128-wide instance into scratch); lane 0
+// advances it between evaluations, everybody reads the next trial point.
+struct FitShared {
+    Bfgs st;
+    float xe[3];
+    int phase, evals;
+};
+
+enum { PH_INIT = 0, PH_SEARCH, PH_BURN, PH_FINAL };
+
+// Consumes the evaluation (fe, ge, ie) made at fs.xe and decides what is evaluated next (lane 0 only).
+__device__ __forceinline__ void fit_advance(FitShared& fs, const InnerArgs& a, float fe, const float* ge, int ie) {
+    Bfgs& st = fs.st;
+    const int budget = a.max_evals - 1;  // the last evaluation is the output evaluation
+    int phase = fs.phase;
+    const int evals = ++fs.evals;
+    bool stop = false;
+    if (phase == PH_INIT) {
+        st.f = fe;
+        for (int q = 0; q < 3; ++q) st.g[q] = ge[q];
+        if (ie != 0) stop = true;  // infeasible start: reported by the final evaluation
+        else if (!a.exact_evals && fmaxf(fabsf(ge[0]), fmaxf(fabsf(ge[1]), fabsf(ge[2]))) <= a.gtol) stop = true;
+        else if (!st.direction()) stop = true;
+        phase = PH_SEARCH;
+    } else if (phase == PH_SEARCH) {
+        if (fe <= st.f + 1e-4f * st.step * st.gp) {  // Armijo
+            const float fprev = st.f;
+            st.accept(fs.xe, fe, ge);
+            const float gmax = fmaxf(fabsf(ge[0]), fmaxf(fabsf(ge[1]), fabsf(ge[2])));
+            if (!a.exact_evals && (gmax <= a.gtol || fabsf(fprev - fe) <= a.ftol * fmaxf(fmaxf(fabsf(fprev), fabsf(fe)), 1.f))) stop = true;
+            else if (!st.direction()) stop = true;
+        } else {
+            // safeguarded quadratic interpolation of the step
+            const float denom = 2.f * (fe - st.f - st.gp * st.step);
+            const float sq = (denom > 0.f && fe < INFINITY) ? (-st.gp * st.step * st.step / denom) : 0.5f * st.step;
+            st.step = fminf(fmaxf(sq, 0.1f * st.step), 0.5f * st.step);
+            if (++st.bt >= 12) {  // line search failed: converged to working precision
+                if (!a.exact_evals) stop = true;
+                else { st.reset_H(); if (!st.direction()) stop = true; }
+            }
+        }
+    }
+    if (stop && a.exact_evals) phase = PH_BURN;  // spend the remaining budget at the current point
+    if (evals >= budget || (stop && !a.exact_evals)) {
+        phase = PH_FINAL;
+        for (int q = 0; q < 3; ++q) fs.xe[q] = st.x[q];
+    } else if (phase == PH_BURN) {
+        for (int q = 0; q < 3; ++q) fs.xe[q] = st.x[q];
+    } else {
+        st.trial(fs.xe);
+    }
+    fs.phase = phase;
 }
 
 template <int NMAX, int NT, int KIND>
 __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
-    constexpr int LD = FactorShape<NMAX>::LD;
-    constexpr int EPT = NMAX * NMAX / NT;
-    __shared__ InnerSmem<NMAX, NT> sm;
+    using EV = InnerEval<NMAX, NT, KIND>;
+    using SW = Sweep<NMAX, NT>;
+    constexpr int RB = SW::RB, CB = SW::CB;
+    __shared__ SweepSmem<NMAX, NT> sm;
+    __shared__ FitShared fs;
     int t, tile;
     if (!task_tile(a.T, 1, t, tile)) return;
     const int tid = threadIdx.x;
     const int n = a.n_s ? a.n_s[t] : a.ld;
     const float* D2 = a.D2ss + (size_t)t * a.ld * a.ld;
+    const int i0 = SW::br() * RB, j0 = SW::bc() * CB;
 
-    float d2r[EPT];
+    float d2[RB][CB], m[RB][CB];
 #pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-        const int e = r * NT + tid;
-        const int i = e / NMAX, j = e % NMAX;
-        d2r[r] = (i < n && j < n) ? D2[(size_t)i * a.ld + j] : 0.f;
-    }
-    if (tid < NMAX) sm.y[tid] = (tid < n) ? a.y_s[(size_t)t * a.ld + tid] : 0.f;
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int i = i0 + r, j = j0 + c;
+            const int hi = i > j ? i : j, lo = i > j ? j : i;  // exactly symmetric input to the sweep
+            d2[r][c] = (i < n && j < n) ? D2[(size_t)hi * a.ld + lo] : 0.f;
+        }
+    if (tid < NMAX) sm.vec_in[tid] = (tid < n) ? a.y_s[(size_t)t * a.ld + tid] : 0.f;
     float pri[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) pri[q] = a.priors[t * 4 + q];
-    float x[3] = {a.phi[t * 3 + 0], a.phi[t * 3 + 1], a.phi[t * 3 + 2]};
+    if (tid == 0) {
+        for (int q = 0; q < 3; ++q) { fs.st.x[q] = a.phi[t * 3 + q]; fs.xe[q] = fs.st.x[q]; }
+        fs.st.reset_H();
+        fs.st.f = INFINITY;
+        fs.phase = (a.max_evals > 0) ? PH_INIT : PH_FINAL;
+        fs.evals = 0;
+    }
     __syncthreads();
 
-    float f, g[3], extra[9];
-    int evals = 0;
-    int info = 0;
-
-    if (a.max_evals > 0) {
-        // ---------------- quasi-Newton (BFGS, backtracking Armijo) on 3 raw parameters ----------------
-        const int budget = a.max_evals - 1;  // the last evaluation is the output evaluation below
-        info = inner_eval<NMAX, NT, KIND>(sm, d2r, n, x, pri, f, g, nullptr);
-        ++evals;
-        float Hi[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}};
-        bool first = true, done = (info != 0);
-        while (!done && evals < budget) {
-            float gmax = fmaxf(fabsf(g[0]), fmaxf(fabsf(g[1]), fabsf(g[2])));
-            if (!a.exact_evals && gmax <= a.gtol) break;
-            float p[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) p[i] = -(Hi[i][0] * g[0] + Hi[i][1] * g[1] + Hi[i][2] * g[2]);
-            float gp = g[0] * p[0] + g[1] * p[1] + g[2] * p[2];
-            if (!(gp < 0.f)) {  // not a descent direction (or NaN): restart from steepest descent
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) Hi[i][j] = (i == j) ? 1.f : 0.f;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) p[i] = -g[i];
-                gp = -(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
-                first = true;
-                if (!(gp < 0.f)) break;  // zero gradient
-            }
-            float step = 1.f;
-            if (first) step = fminf(1.f, 1.f / (fabsf(g[0]) + fabsf(g[1]) + fabsf(g[2])));
-            float fn_ = f, gn[3], xn[3];
-            bool accepted = false;
-            for (int bt = 0; bt < 12 && evals < budget; ++bt) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) xn[i] = x[i] + step * p[i];
-                inner_eval<NMAX, NT, KIND>(sm, d2r, n, xn, pri, fn_, gn, nullptr);
-                ++evals;
-                if (fn_ <= f + 1e-4f * step * gp) { accepted = true; break; }
-                // safeguarded quadratic interpolation
-                float denom = 2.f * (fn_ - f - gp * step);
-                float st = (denom > 0.f && fn_ < INFINITY) ? (-gp * step * step / denom) : 0.5f * step;
-                step = fminf(fmaxf(st, 0.1f * step), 0.5f * step);
-            }
-            if (!accepted) {
-                if (!a.exact_evals) break;  // line search failed: converged to working precision
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) Hi[i][j] = (i == j) ? 1.f : 0.f;
-                first = true;
-                continue;
-            }
-            float s[3], yv[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { s[i] = xn[i] - x[i]; yv[i] = gn[i] - g[i]; }
-            const float sy = s[0] * yv[0] + s[1] * yv[1] + s[2] * yv[2];
-            const float yy = yv[0] * yv[0] + yv[1] * yv[1] + yv[2] * yv[2];
-            const float ss = s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
-            const float fprev = f;
-            f = fn_;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { x[i] = xn[i]; g[i] = gn[i]; }
-            if (sy > 1e-10f * sqrtf(ss * yy) && yy > 0.f) {
-                if (first) {
-                    const float sc = sy / yy;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) Hi[i][j] = (i == j) ? sc : 0.f;
-                    first = false;
-                }
-                const float rho = 1.f / sy;
-                float Hy[3];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) Hy[i] = Hi[i][0] * yv[0] + Hi[i][1] * yv[1] + Hi[i][2] * yv[2];
-                const float yHy = yv[0] * Hy[0] + yv[1] * Hy[1] + yv[2] * Hy[2];
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        Hi[i][j] += -rho * (s[i] * Hy[j] + Hy[i] * s[j]) + rho * (rho * yHy + 1.f) * s[i] * s[j];
-            }
-            if (!a.exact_evals && fabsf(fprev - f) <= a.ftol * fmaxf(fmaxf(fabsf(fprev), fabsf(f)), 1.f)) break;
-        }
-        if (a.exact_evals) {  // burn the remaining budget at the current point: deterministic work
-            while (evals < budget) {
-                float fd, gd[3];
-                inner_eval<NMAX, NT, KIND>(sm, d2r, n, x, pri, fd, gd, nullptr);
-                ++evals;
-            }
-        }
+    // One call site of the evaluator; the state machine in fit_advance() picks the next point.
+    float xe[3], fe, ge[3], extra[9];
+    int info = 0, evals = 0;
+    while (true) {
+        const int phase = fs.phase;
+        xe[0] = fs.xe[0]; xe[1] = fs.xe[1]; xe[2] = fs.xe[2];
+        const int ie = EV::run(sm, d2, m, n, xe, pri, fe, ge, extra, phase != PH_FINAL);
+        if (phase == PH_FINAL) { info = ie; evals = fs.evals + 1; break; }
+        if (tid == 0) fit_advance(fs, a, fe, ge, ie);
+        __syncthreads();
     }
-    // ---------------- output evaluation at the final point ----------------
-    info = inner_eval<NMAX, NT, KIND>(sm, d2r, n, x, pri, f, g, extra);
-    ++evals;
+    const float f = fe;
+    const float* g = ge;
 
-    if (a.max_evals > 0 && tid < 3) a.phi[t * 3 + tid] = x[tid];
     if (tid == 0) {
+        if (a.max_evals > 0) { a.phi[t * 3 + 0] = xe[0]; a.phi[t * 3 + 1] = xe[1]; a.phi[t * 3 + 2] = xe[2]; }
         a.info[t] = info;
         if (a.f_out) a.f_out[t] = f;
         if (a.g_out) { a.g_out[t * 3 + 0] = g[0]; a.g_out[t * 3 + 1] = g[1]; a.g_out[t * 3 + 2] = g[2]; }
@@ -264,8 +298,8 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
         if (a.nevals_out) a.nevals_out[t] = evals;
         if (a.scal) {
             float* sc = a.scal + (size_t)t * NSCAL;
-            sc[S_NOISE] = softplus_f(x[0]) + NOISE_LB; sc[S_OS] = softplus_f(x[1]); sc[S_LS] = softplus_f(x[2]);
-            const float sn = sigmoid_f(x[0]), ss_ = sigmoid_f(x[1]), sl = sigmoid_f(x[2]);
+            sc[S_NOISE] = softplus_f(xe[0]) + NOISE_LB; sc[S_OS] = softplus_f(xe[1]); sc[S_LS] = softplus_f(xe[2]);
+            const float sn = sigmoid_f(xe[0]), ss_ = sigmoid_f(xe[1]), sl = sigmoid_f(xe[2]);
             sc[S_D1N] = sn; sc[S_D1S] = ss_; sc[S_D1L] = sl;
             sc[S_D2N] = sn * (1.f - sn); sc[S_D2S] = ss_ * (1.f - ss_); sc[S_D2L] = sl * (1.f - sl);
             sc[S_FIN] = f; sc[S_GIN0] = g[0]; sc[S_GIN1] = g[1]; sc[S_GIN2] = g[2];
@@ -274,13 +308,16 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
             sc[S_GT0] = extra[6]; sc[S_GT1] = extra[7]; sc[S_GT2] = extra[8];
         }
     }
-    if (a.vecs && tid < n) a.vecs[((size_t)t * NVEC + V_ALPHA) * a.vld + tid] = sm.alpha[tid];
+    if (a.vecs && tid < n) a.vecs[((size_t)t * NVEC + V_ALPHA) * a.vld + tid] = sm.vec_out[tid];
     if (a.Ainv) {
         float* Ao = a.Ainv + (size_t)t * a.ld * a.ld;
-        for (int e = tid; e < n * n; e += NT) {
-            const int i = e / n, j = e - i * n;
-            Ao[(size_t)i * a.ld + j] = sm.buf0[i * LD + j];
-        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                const int i = i0 + r, j = j0 + c;
+                if (i < n && j < n) Ao[(size_t)i * a.ld + j] = -m[r][c];
+            }
     }
 }
 

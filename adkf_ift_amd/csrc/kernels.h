@@ -59,33 +59,35 @@ struct ProbDist {
 
 // ---- K10: median heuristic.  Exact lower median of the positive strict-upper-triangle entries by a
 // 31-step radix select on the float bit patterns (positive floats order like their bits). ---------------
-__global__ __launch_bounds__(256) void k_median(const float* D2ss, const int32_t* n_s, int ld, float* l0, int T) {
-    __shared__ int red[4];
+// One workgroup per task; the (at most 128 x 128) candidates are loaded ONCE into registers (32 per lane), every
+// radix step is then 32 compares + a wave/LDS count reduction, no memory traffic.
+__global__ __launch_bounds__(512) void k_median(const float* D2ss, const int32_t* n_s, int ld, float* l0, int T) {
+    constexpr int NT = 512, EPT = 32;  // 512 * 32 = 128 * 128
+    __shared__ int red[NT / 64];
     int t, tile;
     if (!task_tile(T, 1, t, tile)) return;
     const int n = n_s ? n_s[t] : ld;
     const uint32_t* D = reinterpret_cast<const uint32_t*>(D2ss + (size_t)t * ld * ld);
     const int tid = threadIdx.x;
+    uint32_t v[EPT];
     int cnt = 0;
-    for (int e = tid; e < n * n; e += 256) {
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        const int e = r * NT + tid;
         const int i = e / n, j = e - i * n;
-        if (j > i && D[(size_t)i * ld + j] != 0u) ++cnt;  // entries are clamped >= 0, so != 0 means > 0
+        v[r] = (e < n * n && j > i) ? D[(size_t)i * ld + j] : 0u;  // entries are clamped >= 0: 0 marks "not a candidate"
+        cnt += (v[r] != 0u);
     }
-    const int total = block_sum_i<256>(cnt, red);
+    const int total = block_sum_i<NT>(cnt, red);
     if (total == 0) { if (tid == 0) l0[t] = 0.f; return; }
     int rank = (total - 1) / 2;  // torch.median: lower median
     uint32_t prefix = 0;
     for (int bit = 30; bit >= 0; --bit) {
         const uint32_t hi_mask = ~((1u << bit) - 1u);  // bits >= bit
         int c0 = 0;
-        for (int e = tid; e < n * n; e += 256) {
-            const int i = e / n, j = e - i * n;
-            if (j > i) {
-                const uint32_t v = D[(size_t)i * ld + j];
-                if (v != 0u && (v & hi_mask) == prefix) ++c0;  // matches prefix with this bit = 0
-            }
-        }
-        c0 = block_sum_i<256>(c0, red);
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) c0 += (v[r] != 0u && (v[r] & hi_mask) == prefix);  // prefix matches, this bit = 0
+        c0 = block_sum_i<NT>(c0, red);
         if (rank >= c0) { rank -= c0; prefix |= (1u << bit); }
     }
     if (tid == 0) l0[t] = sqrtf(0.5f * __uint_as_float(prefix));
@@ -185,20 +187,10 @@ __global__ __launch_bounds__(256) void k_hess(HessArgs a) {
 struct OuterArgs { TaskView tv; const float* C; float* S; const float* y_s; const float* y_q; float* vecs; float* scal; float* f_out; int32_t* info; int T; };
 
 template <int NMAX, int NT>
-struct OuterSmem {
-    float buf0[FactorShape<NMAX>::ELEMS];
-    float buf1[FactorShape<NMAX>::ELEMS];
-    float r[NMAX];
-    float w[NMAX];
-    float e[NMAX];
-    float dinv[NMAX];
-    float red[8 * (NT / 64)];
-};
-
-template <int NMAX, int NT>
 __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
-    constexpr int LD = FactorShape<NMAX>::LD;
-    __shared__ OuterSmem<NMAX, NT> sm;
+    using SW = Sweep<NMAX, NT>;
+    constexpr int RB = SW::RB, CB = SW::CB;
+    __shared__ SweepSmem<NMAX, NT> sm;
     int t, tile;
     if (!task_tile(a.T, 1, t, tile)) return;
     const int n = a.tv.ns(t), m = a.tv.nq(t), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -208,44 +200,50 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
     const float* ys = a.y_s + (size_t)t * a.tv.ns_ld;
     const float* yq = a.y_q + (size_t)t * a.tv.nq_ld;
     float* vbase = a.vecs + (size_t)t * NVEC * a.tv.vld;
-    // residual
+    const int i0 = SW::br() * RB, j0 = SW::bc() * CB;
+    if (tid < NMAX) sm.vec_in[tid] = 0.f;
+    __syncthreads();
+    // residual r = y_q - C y_s  (wave per row)
     for (int i = wv; i < m; i += NW) {
         float s = 0.f;
         for (int j = lane; j < n; j += 64) s += Ci[(size_t)i * a.tv.ns_ld + j] * ys[j];
         s = wave_sum(s);
-        if (lane == 0) { vbase[V_MU * a.tv.vld + i] = s; sm.r[i] = yq[i] - s; }
+        if (lane == 0) { vbase[V_MU * a.tv.vld + i] = s; sm.vec_in[i] = yq[i] - s; }
     }
-    for (int e = tid; e < m * m; e += NT) {
-        const int i = e / m, j = e - i * m;
-        if (j <= i) sm.buf0[i * LD + j] = Si[(size_t)i * a.tv.nq_ld + j];
-    }
-    float logdet;
-    int info = ldl_sweep<NMAX, NT>(sm.buf0, sm.buf1, sm.dinv, m, logdet, sm.red);
-    if (tid < m) {
-        float s = 0.f;
-        for (int j = 0; j <= tid; ++j) s += sm.buf1[tid * LD + j] * sm.r[j];
-        sm.w[tid] = s;
-    }
+    // this thread's block of S, symmetrised from the lower triangle, identity-padded
+    float mm[RB][CB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int i = i0 + r, j = j0 + c;
+            const int hi = i > j ? i : j, lo = i > j ? j : i;
+            mm[r][c] = (i < m && j < m) ? Si[(size_t)hi * a.tv.nq_ld + lo] : (i == j ? 1.f : 0.f);
+        }
     __syncthreads();
+    SW::run(mm, m, sm);
+    float logdet;
+    const int info = SW::finish(m, sm, logdet);
+    SW::solve(mm, sm.vec_in, sm.vec_out);  // e = S^-1 r
     float q[1] = {0.f};
     if (tid < m) {
-        float s = 0.f;
-        for (int k = tid; k < m; ++k) s += sm.buf1[k * LD + tid] * sm.w[k];
-        sm.e[tid] = s;
-        vbase[V_E * a.tv.vld + tid] = s;
-        vbase[V_R * a.tv.vld + tid] = sm.r[tid];
-        q[0] = sm.w[tid] * sm.w[tid];
+        const float e = sm.vec_out[tid], r = sm.vec_in[tid];
+        vbase[V_E * a.tv.vld + tid] = e;
+        vbase[V_R * a.tv.vld + tid] = r;
+        q[0] = r * e;
     }
-    ata_lower<NMAX, NT>(sm.buf1, sm.buf0, m);
-    block_sum<1, NT>(q, sm.red);  // has the barriers ata_lower's consumers need
-    for (int e = tid; e < m * m; e += NT) {
-        const int i = e / m, j = e - i * m;
-        Si[(size_t)i * a.tv.nq_ld + j] = sm.buf0[i * LD + j];
-    }
+    block_sum<1, NT>(q, sm.red);
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int i = i0 + r, j = j0 + c;
+            if (i < m && j < m) Si[(size_t)i * a.tv.nq_ld + j] = -mm[r][c];
+        }
     // Cte_j = sum_i C_ij e_i  (thread per column: coalesced)
     for (int j = tid; j < n; j += NT) {
         float s = 0.f;
-        for (int i = 0; i < m; ++i) s += Ci[(size_t)i * a.tv.ns_ld + j] * sm.e[i];
+        for (int i = 0; i < m; ++i) s += Ci[(size_t)i * a.tv.ns_ld + j] * sm.vec_out[i];
         vbase[V_CTE * a.tv.vld + j] = s;
     }
     if (tid == 0) {

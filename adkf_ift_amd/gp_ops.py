@@ -17,6 +17,8 @@ from . import _lib
 from ._lib import KERNEL_MATERN52, KERNEL_RBF, Batch, FitOptions
 
 KERNELS = {"rbf": KERNEL_RBF, "RBF": KERNEL_RBF, "matern": KERNEL_MATERN52}
+REUSE_DIST = 1
+REUSE_INNER = 2
 
 _workspaces = {}
 
@@ -56,6 +58,7 @@ class GPBatch:
     y_q: Optional[torch.Tensor] = None
     n_s: Optional[torch.Tensor] = None
     n_q: Optional[torch.Tensor] = None
+    flags: int = 0  # REUSE_DIST / REUSE_INNER promises for consecutive calls on this batch (include/adkf_gp.h)
 
     def __post_init__(self):
         self.kernel = kernel_id(self.kernel)
@@ -93,7 +96,7 @@ class GPBatch:
 
     def c_struct(self) -> Batch:
         b = Batch()
-        b.T, b.ns_max, b.nq_max, b.d, b.kernel, b.reserved = self.T, self.ns, self.nq, self.d, self.kernel, 0
+        b.T, b.ns_max, b.nq_max, b.d, b.kernel, b.flags = self.T, self.ns, self.nq, self.d, self.kernel, int(self.flags)
         b.n_s, b.n_q = _ptr(self.n_s), _ptr(self.n_q)
         b.Z_s, b.y_s, b.Z_q, b.y_q, b.priors = _ptr(self.Z_s), _ptr(self.y_s), _ptr(self.Z_q), _ptr(self.y_q), _ptr(self.priors)
         return b
@@ -151,6 +154,19 @@ def init_params(Z_s: torch.Tensor, use_numeric_labels: bool = False, use_lengths
     _lib.check(lib.adkf_init_params(C.byref(cb), int(use_numeric_labels), int(use_lengthscale_prior), _ptr(phi),
                                     _ptr(priors), _ptr(l0), _ptr(ws), nb, _stream(b.device)), "adkf_init_params")
     return phi, priors, l0
+
+
+def init_params_batch(b: GPBatch, use_numeric_labels: bool = False, use_lengthscale_prior: bool = True):
+    """Like ``init_params`` but on an existing batch: fills ``b.priors`` in place and returns (phi0, l0).  The
+    squared distances it computes stay in the workspace, so the caller may set ``b.flags |= REUSE_DIST`` for the
+    following ``fit`` / ``ift_hypergrad`` calls on the same batch."""
+    lib = _lib.load()
+    phi, l0 = _new(b, b.T, 3), _new(b, b.T)
+    ws, nb = b.workspace()
+    cb = b.c_struct()
+    _lib.check(lib.adkf_init_params(C.byref(cb), int(use_numeric_labels), int(use_lengthscale_prior), _ptr(phi),
+                                    _ptr(b.priors), _ptr(l0), _ptr(ws), nb, _stream(b.device)), "adkf_init_params")
+    return phi, l0
 
 
 def mll_value_grad(b: GPBatch, phi: torch.Tensor, want_grad_phi=True, want_dZ=False):

@@ -32,26 +32,23 @@ class MetaStepConfig:
 
 
 class HipGPBackend:
-    """The product backend: every call lands in libadkf_gp.so.  (Tests may substitute an oracle-backed object
-    with the same three methods to exercise the harness/collective logic on CPU ranks.)"""
+    """The product backend: every call lands in libadkf_gp.so.  (Tests may substitute an oracle-backed object with
+    the same ``run`` method to exercise the harness/collective logic on CPU ranks.)"""
 
-    def init(self, Z_s, cfg: MetaStepConfig, n_s=None):
+    def run(self, Z_s, y_s, Z_q, y_q, cfg: MetaStepConfig, n_s=None, n_q=None, fit_events=None):
+        """a3/a4 re-initialisation -> a7 inner fit -> a9 IFT hypergradient for every task of the meta-batch.
+        One GPBatch / one workspace for the three calls, so the squared distances are built once and the
+        hypergradient reuses the A^-1, alpha the fit left behind."""
         from . import gp_ops
-        phi0, priors, _ = gp_ops.init_params(Z_s, cfg.use_numeric_labels, cfg.use_lengthscale_prior, n_s=n_s)
-        return phi0, priors
-
-    def fit(self, Z_s, y_s, priors, phi0, cfg: MetaStepConfig, n_s=None, events=None):
-        from . import gp_ops
-        b = gp_ops.GPBatch(Z_s, y_s, priors, cfg.gp_kernel, n_s=n_s)
-        phi, f, gnorm, nev, info = gp_ops.fit(b, phi0, cfg.inner_max_evals, cfg.inner_gtol, cfg.inner_ftol,
-                                              cfg.inner_exact_evals, events=events)
-        return phi, info
-
-    def hypergrad(self, Z_s, y_s, Z_q, y_q, priors, phi, cfg: MetaStepConfig, n_s=None, n_q=None):
-        from . import gp_ops
+        priors = torch.empty(Z_s.shape[0], 4, dtype=torch.float32, device=Z_s.device)
         b = gp_ops.GPBatch(Z_s, y_s, priors, cfg.gp_kernel, Z_q=Z_q, y_q=y_q, n_s=n_s, n_q=n_q)
+        phi0, _ = gp_ops.init_params_batch(b, cfg.use_numeric_labels, cfg.use_lengthscale_prior)
+        b.flags = gp_ops.REUSE_DIST
+        phi, f_in, gnorm, nev, info_fit = gp_ops.fit(b, phi0, cfg.inner_max_evals, cfg.inner_gtol, cfg.inner_ftol,
+                                                     cfg.inner_exact_evals, events=fit_events)
+        b.flags = gp_ops.REUSE_DIST | gp_ops.REUSE_INNER
         out = gp_ops.ift_hypergrad(b, phi, ignore_grad_correction=cfg.ignore_grad_correction)
-        return out["f_out"], out["dZ_s"], out["dZ_q"], out["info"]
+        return phi, out["f_out"], out["dZ_s"], out["dZ_q"], info_fit, out["info"]
 
 
 def allreduce_flat_grads(params: Sequence[torch.Tensor], group=None) -> None:
@@ -79,22 +76,22 @@ def meta_step(features_fn: Callable[[], Tuple[torch.Tensor, torch.Tensor]], para
     Z_s, Z_q = features_fn()
     T_local = Z_s.shape[0]
     world = dist.get_world_size() if distributed else 1
-    Zs_d, Zq_d = Z_s.detach(), Z_q.detach()
-    # a3/a4: fresh GP parameters per task from the detached support features (adaptive_dkt.py:178-179)
-    phi0, priors = backend.init(Zs_d, cfg, n_s=n_s)
-    # a7: inner fit
-    phi, info_fit = backend.fit(Zs_d, y_s, priors, phi0, cfg, n_s=n_s, events=fit_events)
-    # a9: hypergradient at the feature level
-    f_out, dZ_s, dZ_q, info = backend.hypergrad(Zs_d, y_s, Zq_d, y_q, priors, phi, cfg, n_s=n_s, n_q=n_q)
+    # a3/a4 fresh GP parameters from the detached support features (adaptive_dkt.py:178-179), a7 inner fit,
+    # a9 hypergradient at the feature level
+    phi, f_out, dZ_s, dZ_q, info_fit, info = backend.run(Z_s.detach(), y_s, Z_q.detach(), y_q, cfg, n_s=n_s, n_q=n_q,
+                                                         fit_events=fit_events)
     if check:
         from . import gp_ops
         gp_ops.check_info(info_fit, "inner fit")
         gp_ops.check_info(info, "IFT hypergradient")
     # one backward through the feature extractor; task-mean over the GLOBAL meta-batch (adaptive_dkt_utils.py:402-407)
     scale = 1.0 / float(T_local * world)
-    torch.autograd.backward([Z_s, Z_q], [dZ_s.to(Z_s.dtype) * scale, dZ_q.to(Z_q.dtype) * scale])
+    torch.autograd.backward([Z_s, Z_q], [dZ_s.to(Z_s.dtype), dZ_q.to(Z_q.dtype)])
     if distributed and world > 1:
         allreduce_flat_grads(params)
+    for p in params:  # the task-mean: scaling |theta| numbers once is cheaper than scaling both dZ tensors
+        if p.grad is not None:
+            p.grad.mul_(scale)
     if cfg.clip_value is not None:
         torch.nn.utils.clip_grad_norm_(params, cfg.clip_value)
     if optimizer is not None:

@@ -49,6 +49,13 @@ extern "C" {
 
 #define ADKF_INFO_OUTER_BASE 100000
 
+/* adkf_batch_t.flags: promises that let consecutive calls on the SAME batch (same pointers, shape, kernel) and the
+ * SAME workspace skip work that is already there.  The usual meta-step sequence is
+ *   adkf_init_params (flags 0) -> adkf_fit (REUSE_DIST) -> adkf_ift_hypergrad (REUSE_DIST | REUSE_INNER). */
+#define ADKF_BATCH_REUSE_DIST 1  /* squared distances (incl. query blocks when Z_q was given) are in the workspace */
+#define ADKF_BATCH_REUSE_INNER 2 /* A^-1, alpha and the scalars of exactly this phi are in the workspace (adkf_fit
+                                    leaves them for its result; adkf_mll_value_grad for its argument) */
+
 /* flags of adkf_ift_hypergrad: fs_mol/utils/cauchy_hypergradient.py:11-13 */
 #define ADKF_IGNORE_GRAD_CORRECTION 1
 #define ADKF_IGNORE_DIRECT_GRAD 2
@@ -59,7 +66,7 @@ typedef struct adkf_batch {
     int32_t nq_max;     /* padded query rows (0 when no query set is involved) */
     int32_t d;          /* feature dimension */
     int32_t kernel;     /* ADKF_KERNEL_* */
-    int32_t reserved;
+    int32_t flags;      /* ADKF_BATCH_* reuse promises (0 = recompute everything) */
     const int32_t* n_s; /* [T] or NULL */
     const int32_t* n_q; /* [T] or NULL */
     const float* Z_s;   /* [T, ns_max, d] */

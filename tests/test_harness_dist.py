@@ -18,32 +18,23 @@ from oracle import gp_oracle as O
 
 
 class OracleBackend:
-    """Same three methods as trainer.HipGPBackend, float64 oracle inside (TEST DOUBLE)."""
+    """Same ``run`` method as trainer.HipGPBackend, float64 oracle inside (TEST DOUBLE)."""
 
     def __init__(self, kind):
         self.kind = kind
-        self.pris = None
 
-    def init(self, Z_s, cfg, n_s=None):
-        phis, self.pris = [], []
+    def run(self, Z_s, y_s, Z_q, y_q, cfg, n_s=None, n_q=None, fit_events=None):
+        phis, f, ds, dq = [], [], [], []
         for t in range(Z_s.shape[0]):
-            phi, pri = O.init_phi(Z_s[t].double(), cfg.use_numeric_labels, cfg.use_lengthscale_prior)
+            phi0, pri = O.init_phi(Z_s[t].double(), cfg.use_numeric_labels, cfg.use_lengthscale_prior)
+            phi = O.fit_phi(Z_s[t].double(), y_s[t].double(), phi0, pri, self.kind)[0]
+            q = O.full_reference_quantities(Z_s[t], y_s[t], Z_q[t], y_q[t], phi, pri, self.kind)
             phis.append(phi)
-            self.pris.append(pri)
-        return torch.stack(phis), torch.tensor(np.stack([p.as_array() for p in self.pris]))
-
-    def fit(self, Z_s, y_s, priors, phi0, cfg, n_s=None, events=None):
-        out = [O.fit_phi(Z_s[t].double(), y_s[t].double(), phi0[t], self.pris[t], self.kind)[0] for t in range(Z_s.shape[0])]
-        return torch.stack(out), torch.zeros(Z_s.shape[0], dtype=torch.int32)
-
-    def hypergrad(self, Z_s, y_s, Z_q, y_q, priors, phi, cfg, n_s=None, n_q=None):
-        f, ds, dq = [], [], []
-        for t in range(Z_s.shape[0]):
-            q = O.full_reference_quantities(Z_s[t], y_s[t], Z_q[t], y_q[t], phi[t], self.pris[t], self.kind)
             f.append(q["f_out"])
             ds.append(torch.tensor(q["dZs_total"] if not cfg.ignore_grad_correction else q["dZs_direct"]))
             dq.append(torch.tensor(q["dZq_total"]))
-        return torch.tensor(f), torch.stack(ds), torch.stack(dq), torch.zeros(len(f), dtype=torch.int32)
+        zero = torch.zeros(len(f), dtype=torch.int32)
+        return torch.stack(phis), torch.tensor(f), torch.stack(ds), torch.stack(dq), zero, zero
 
 
 def _run_rank(rank, world, port, fixture, ret):

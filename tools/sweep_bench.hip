@@ -1,0 +1,63 @@
+// Micro-benchmark / ablation harness for the register-resident sweep (factor.h).  Not part of the library.
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I adkf_ift_amd/csrc tools/sweep_bench.hip -o /tmp/sweep_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "factor.h"
+using namespace adkf;
+
+template <int NMAX, int NT, int VAR>
+__global__ __launch_bounds__(NT) void k_sweep(const float* A, float* out, int n, int reps) {
+    using SW = Sweep<NMAX, NT>;
+    constexpr int RB = SW::RB, CB = SW::CB;
+    __shared__ SweepSmem<NMAX, NT> sm;
+    const int i0 = SW::br() * RB, j0 = SW::bc() * CB;
+    const float* At = A + (size_t)blockIdx.x * n * n;
+    float a[RB][CB], m[RB][CB];
+    for (int r = 0; r < RB; ++r) for (int c = 0; c < CB; ++c) a[r][c] = At[(i0 + r) * n + j0 + c];
+    float acc = 0.f;
+    for (int it = 0; it < reps; ++it) {
+        for (int r = 0; r < RB; ++r) for (int c = 0; c < CB; ++c) m[r][c] = a[r][c];
+        __syncthreads();
+        if (VAR == 0) SW::run(m, n, sm);
+        if (VAR == 1) {  // update only: no publish (stale vectors), same barriers
+            const int nq = n / SW::B;
+            for (int q = 0; q < nq; ++q) { __syncthreads(); SW::step(m, q, sm); }
+        }
+        if (VAR == 2) {  // publish only + barriers
+            const int nq = n / SW::B;
+            for (int q = 0; q < nq; q += 2) { __syncthreads(); SW::template publish<0>(m, q, q & 1, sm); __syncthreads(); SW::template publish<1>(m, q + 1, (q + 1) & 1, sm); }
+        }
+        if (VAR == 3) {  // barriers only
+            const int nq = n / SW::B;
+            for (int q = 0; q < nq; ++q) { __syncthreads(); asm volatile("" ::: "memory"); }
+        }
+        acc += m[0][0];
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = acc + m[1][1];
+}
+
+template <int VAR>
+float run(const float* dA, float* dout, int T, int n, int reps) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k_sweep<128, 512, VAR><<<T, 512>>>(dA, dout, n, 2);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k_sweep<128, 512, VAR><<<T, 512>>>(dA, dout, n, reps);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e3f / reps;
+}
+
+int main(int argc, char** argv) {
+    const int T = argc > 1 ? atoi(argv[1]) : 256, n = 128, reps = 20;
+    std::vector<float> A((size_t)T * n * n);
+    for (int t = 0; t < T; ++t) for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+        float d = (float)(i - j); A[((size_t)t * n + i) * n + j] = 0.7f * expf(-d * d / 50.f) + (i == j ? 0.1f : 0.f);
+    }
+    float *dA, *dout; hipMalloc(&dA, A.size() * 4); hipMalloc(&dout, T * 4);
+    hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
+    printf("T=%d  us per sweep:  full %.1f | update-only %.1f | publish-only %.1f | barriers-only %.1f\n", T,
+           run<0>(dA, dout, T, n, reps), run<1>(dA, dout, T, n, reps), run<2>(dA, dout, T, n, reps), run<3>(dA, dout, T, n, reps));
+    return 0;
+}
