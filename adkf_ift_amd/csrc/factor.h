@@ -15,11 +15,22 @@
 //       i = P_b, j in R :  c_b,j - sum_a (d_ab - Dinv_ab) c_a,j                  = f_b,j
 //       i = P_b, j = P_c:  (D_bc - 2 d_bc) - sum_a (d_ab - Dinv_ab)(D_ac - d_ac) = -Dinv_bc
 // Per block step only the B pivot rows (C) and their scaled copies (F) travel through LDS, published by the 1/NBR
-// of the threads that own them, double-buffered, with ONE barrier per B pivots; everything else is register FMAs.
+// of the threads that own them, with ONE barrier per B pivots; everything else is register FMAs.
 // The owners obtain D by v_readlane from the holder's lane and invert it redundantly (same instruction stream).
 // Rows/cols >= n are padded with the identity; sweeping them is a no-op that leaves -1 on the diagonal.
+//
+// Scheduling.  The chain  update(next pivot rows) -> D^-1 -> F -> LDS  is the critical path (every block step
+// waits for it; measured ~0.4 us against ~0.23 us of bulk FMAs per step, tools/chain_bench.hip), so:
+//   * a thread's RB rows are G = RB/CB groups of B rows that lie NMAX/G apart, and consecutive logical block
+//     rows live in DIFFERENT waves: the ownership of the chain rotates over the waves from step to step;
+//   * the owning wave updates only the next pivot rows, runs the chain at raised priority and goes straight to
+//     the barrier; it applies the REST of that step's update one step later, when another wave is on the chain
+//     (vector slots are triple-buffered so the old vectors are still there).
 #pragma once
 #include <limits.h>
+#ifndef ADKF_ABLATE
+#define ADKF_ABLATE 0  // timing-only ablation switches for tools/sweep_bench.hip (1: no inverse, 2: no readlane, 4: no F, 8: no deferral)
+#endif
 
 #include "device_utils.h"
 
@@ -34,8 +45,8 @@ template <> struct SweepCfg<16, 256> { static constexpr int RB = 1, CB = 1; };
 template <int NMAX, int NT>
 struct SweepSmem {
     static constexpr int B = SweepCfg<NMAX, NT>::CB;
-    alignas(16) float cross[2][B][NMAX];  // C: the B pivot rows (with D - I at the pivot columns)
-    alignas(16) float fvec[2][B][NMAX];   // F = D^-1 C
+    alignas(16) float cross[3][B][NMAX];  // C: the B pivot rows (with D - I at the pivot columns); 3 slots, see steps()
+    alignas(16) float fvec[3][B][NMAX];   // F = D^-1 C
     alignas(16) float pivs[NMAX];
     alignas(16) float vec_in[NMAX];       // right-hand side of the solve (y or r)
     alignas(16) float vec_out[NMAX];      // A^-1 * vec_in
@@ -97,30 +108,46 @@ template <int NMAX, int NT>
 struct Sweep {
     static constexpr int RB = SweepCfg<NMAX, NT>::RB, CB = SweepCfg<NMAX, NT>::CB, B = CB;
     static constexpr int NBC = NMAX / CB, NBR = NMAX / RB;
-    static constexpr int QPB = RB / CB;  // pivot blocks per block row
+    static constexpr int G = RB / CB;          // row groups per thread
+    static constexpr int GSTRIDE = NMAX / G;   // distance between the row groups (= NBR * CB)
+    static constexpr int NW = NT / 64;         // waves
+    static constexpr int BPW = 64 / NBC;       // physical block rows per wave
     static_assert(NBC * NBR == NT, "one block per thread");
-    static_assert(NBC <= 32, "a row of blocks must sit inside a 32-lane half wave (shuffle reduction)");
+    static_assert(NBC <= 32 && 64 % NBC == 0, "a row of blocks must sit inside a 32-lane half wave (shuffle reduction)");
     static_assert(RB % CB == 0, "CB must divide RB");
+    static_assert(NBR == NW * BPW, "block rows must tile the waves");
 
     __device__ static __forceinline__ int bc() { return threadIdx.x % NBC; }
-    __device__ static __forceinline__ int br() { return threadIdx.x / NBC; }
+    // logical block row: physical block row (wave * BPW + h) holds logical row (wave + NW * h), so that logical
+    // rows bl, bl + 1, ... sit in waves bl % NW, (bl + 1) % NW, ...
+    __device__ static __forceinline__ int br() {
+        const int brr = threadIdx.x / NBC;
+        return (brr / BPW) + NW * (brr % BPW);
+    }
+    __device__ static __forceinline__ int row(int r) { return (r / CB) * GSTRIDE + br() * CB + (r % CB); }
+    __device__ static __forceinline__ int col(int c) { return bc() * CB + c; }
+    __device__ static __forceinline__ int owner_wave(int bl) { return bl % NW; }
 
-    // The owners of pivot block q (rows q*B .. q*B+B-1) publish C and F for block step q into buffer `buf`.
-    // QR = q % QPB is a compile-time constant (the loop is unrolled by QPB): all register indices are static.
-    template <int QR>
-    __device__ static __forceinline__ void publish(float (&m)[RB][CB], int q, int buf, SweepSmem<NMAX, NT>& sm) {
-        constexpr int RO = QR * CB;  // row offset of the pivot rows inside this thread's block
-        const int kb = q / QPB;      // block row that owns the pivot rows
-        const int plane = (kb * NBC + q) & 63;  // lane (in the owning wave) of the thread that holds D
+    // The owners of pivot block q = GI * NBR + bl (matrix rows q*B .. q*B+B-1 = local rows GI*CB.. of logical block
+    // row bl) publish C and F for block step q into `slot`.  GI is a compile-time constant: static register indices.
+    template <int GI>
+    __device__ static __forceinline__ void publish(float (&m)[RB][CB], int bl, int slot, SweepSmem<NMAX, NT>& sm) {
+        constexpr int RO = GI * CB;
+        const int q = GI * NBR + bl;
+        const int plane = ((bl / NW) * NBC + q) & 63;  // lane, in the owning wave, of the thread (bl, bc = q) that holds D
         float D[B][B];
 #pragma unroll
         for (int a = 0; a < B; ++a)
 #pragma unroll
             for (int b = 0; b <= a; ++b) {
+#if ADKF_ABLATE & 2
+                D[a][b] = m[RO + a][b] + (a == b ? 1.f : 0.f);
+#else
                 D[a][b] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m[RO + a][b]), plane));
+#endif
                 D[b][a] = D[a][b];
             }
-        if (br() == kb) {
+        if (br() == bl) {
             const int j0 = bc() * CB;
             float C[B][CB], F[B][CB], piv[B];
 #pragma unroll
@@ -134,7 +161,11 @@ struct Sweep {
                     m[RO + a][a] -= 2.f;
                 }
             }
+#if ADKF_ABLATE & 1
+            for (int a = 0; a < B; ++a) piv[a] = D[a][a];
+#else
             InvSpd<B>::run(D, piv);
+#endif
             if (bc() == q) {
 #pragma unroll
                 for (int a = 0; a < B; ++a) sm.pivs[q * B + a] = piv[a];
@@ -143,22 +174,30 @@ struct Sweep {
             for (int a = 0; a < B; ++a)
 #pragma unroll
                 for (int c = 0; c < CB; ++c) {
+#if ADKF_ABLATE & 4
+                    F[a][c] = C[a][c] * D[a][a];
+#else
                     float s = 0.f;
 #pragma unroll
                     for (int b = 0; b < B; ++b) s = fmaf(D[a][b], C[b][c], s);
                     F[a][c] = s;
+#endif
                 }
 #pragma unroll
             for (int a = 0; a < B; ++a)
 #pragma unroll
                 for (int c = 0; c < CB; ++c) {
-                    sm.cross[buf][a][j0 + c] = C[a][c];
-                    sm.fvec[buf][a][j0 + c] = F[a][c];
+#if ADKF_ABLATE & 16
+                    if (C[a][c] == 123.456f) sm.cross[slot][a][j0 + c] = F[a][c];
+#else
+                    sm.cross[slot][a][j0 + c] = C[a][c];
+                    sm.fvec[slot][a][j0 + c] = F[a][c];
+#endif
                 }
         }
     }
 
-    // rank-B update of rows [R0, R1) of this thread's block from the vectors of one block step
+    // rank-B update of local rows [R0, R1) of this thread's block from the vectors of one block step
     template <int R0, int R1>
     __device__ static __forceinline__ void update_rows(float (&m)[RB][CB], const float (&fi)[B][RB], const float (&cj)[B][CB]) {
 #pragma unroll
@@ -169,59 +208,82 @@ struct Sweep {
                 for (int c = 0; c < CB; ++c) m[r][c] = fmaf(-fi[a][r], cj[a][c], m[r][c]);
     }
 
-    __device__ static __forceinline__ void load_vectors(int q, SweepSmem<NMAX, NT>& sm, float (&fi)[B][RB], float (&cj)[B][CB]) {
-        const int i0 = br() * RB, j0 = bc() * CB, b = q & 1;
+    __device__ static __forceinline__ void load_vectors(int slot, SweepSmem<NMAX, NT>& sm, float (&fi)[B][RB], float (&cj)[B][CB]) {
+        const int j0 = bc() * CB;
 #pragma unroll
         for (int a = 0; a < B; ++a) {
 #pragma unroll
-            for (int r = 0; r < RB; ++r) fi[a][r] = sm.fvec[b][a][i0 + r];
+            for (int r = 0; r < RB; ++r) fi[a][r] = sm.fvec[slot][a][row(r)];
 #pragma unroll
-            for (int c = 0; c < CB; ++c) cj[a][c] = sm.cross[b][a][j0 + c];
+            for (int c = 0; c < CB; ++c) cj[a][c] = sm.cross[slot][a][j0 + c];
         }
     }
 
-    // (kept for the ablation harness tools/sweep_bench.hip)
+    // (for the ablation harness tools/sweep_bench.hip)
     __device__ static __forceinline__ void step(float (&m)[RB][CB], int q, SweepSmem<NMAX, NT>& sm) {
         float fi[B][RB], cj[B][CB];
-        load_vectors(q, sm, fi, cj);
+        load_vectors(q % 3, sm, fi, cj);
         update_rows<0, RB>(m, fi, cj);
     }
 
-    // One block step.  The chain  update(next pivot rows) -> D^-1 -> F -> LDS  of the wave that owns the NEXT pivot
-    // block is the critical path of the sweep (everybody waits for it at the next barrier), so that wave runs it
-    // first and at raised priority, and only then finishes the rest of its own update.
-    template <int QR>
-    __device__ static __forceinline__ void steps(float (&m)[RB][CB], int q0, int nq, SweepSmem<NMAX, NT>& sm) {
-        if constexpr (QR < QPB) {
-            constexpr int NQR = (QR + 1) % QPB;  // row group (inside a block row) of the next pivot rows
-            constexpr int N0 = NQR * CB, N1 = NQR * CB + CB;
-            const int q = q0 + QR;
-            __syncthreads();
-            float fi[B][RB], cj[B][CB];
-            load_vectors(q, sm, fi, cj);
+    // All block steps whose pivot rows are local row group GI.
+    template <int GI>
+    __device__ static __forceinline__ void phase(float (&m)[RB][CB], int nq, SweepSmem<NMAX, NT>& sm) {
+        if constexpr (GI < G) {
             const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-            const int own_wave = (((q + 1) / QPB) * NBC) >> 6;  // wave that holds the next pivot rows
-            if (q + 1 < nq && wave == own_wave) {
-                update_rows<N0, N1>(m, fi, cj);
-                __builtin_amdgcn_s_setprio(3);
-                publish<NQR>(m, q + 1, (q + 1) & 1, sm);
-                __builtin_amdgcn_s_setprio(0);
-                update_rows<0, N0>(m, fi, cj);
-                update_rows<N1, RB>(m, fi, cj);
-            } else {
-                update_rows<0, RB>(m, fi, cj);
+            for (int bl = 0; bl < NBR; ++bl) {
+                const int q = GI * NBR + bl;
+                if (q >= nq) break;
+                __syncthreads();
+                float fi[B][RB], cj[B][CB];
+                if (!(ADKF_ABLATE & 8) && q > 0 && wave == owner_wave(bl)) {
+                    // this wave ran the chain for block q during the previous step and postponed the rest of that
+                    // step's update (everything but its pivot rows GI*CB..): do it now, off the critical path
+                    load_vectors((q + 2) % 3, sm, fi, cj);  // slot of step q - 1
+                    update_rows<0, GI * CB>(m, fi, cj);
+                    update_rows<GI * CB + CB, RB>(m, fi, cj);
+                }
+                if (!(ADKF_ABLATE & 64) || wave == owner_wave(bl + 1)) load_vectors(q % 3, sm, fi, cj);
+                const bool has_next = q + 1 < nq;
+                if (bl + 1 < NBR) {
+                    if (has_next && wave == owner_wave(bl + 1)) {
+                        update_rows<GI * CB, GI * CB + CB>(m, fi, cj);
+                        if (!(ADKF_ABLATE & 32)) __builtin_amdgcn_s_setprio(3);
+                        publish<GI>(m, bl + 1, (q + 1) % 3, sm);
+                        __builtin_amdgcn_s_setprio(0);
+                        if (ADKF_ABLATE & 8) { update_rows<0, GI * CB>(m, fi, cj); update_rows<GI * CB + CB, RB>(m, fi, cj); }
+                    } else {
+                        if (!(ADKF_ABLATE & 64)) update_rows<0, RB>(m, fi, cj);
+                    }
+                } else {
+                    if constexpr (GI + 1 < G) {
+                        if (has_next && wave == owner_wave(0)) {
+                            update_rows<(GI + 1) * CB, (GI + 1) * CB + CB>(m, fi, cj);
+                            if (!(ADKF_ABLATE & 32)) __builtin_amdgcn_s_setprio(3);
+                            publish<GI + 1>(m, 0, (q + 1) % 3, sm);
+                            __builtin_amdgcn_s_setprio(0);
+                        } else {
+                            update_rows<0, RB>(m, fi, cj);
+                        }
+                    } else {
+                        update_rows<0, RB>(m, fi, cj);
+                    }
+                }
             }
-            steps<QR + 1>(m, q0, nq, sm);
+            // the postponed part of the LAST step of this phase, if its chain ran in the previous step of this phase,
+            // is picked up by the first step of the next phase (same code path: q > 0 && owner); after the final
+            // phase nothing is pending because the last block step has no successor to publish.
+            phase<GI + 1>(m, nq, sm);
         }
     }
 
     // In: m = this thread's block of the SPD matrix (identity-padded beyond n).  Out: m = -(A^-1); the pivots are
     // left in sm.pivs[0..n) (finish() turns them into info and log-determinant).  All threads call.
     __device__ static __forceinline__ void run(float (&m)[RB][CB], int n, SweepSmem<NMAX, NT>& sm) {
-        const int nrow = ((n + RB - 1) / RB) * RB;  // whole block rows: sweeping identity padding is a no-op
-        const int nq = nrow / B;
-        publish<0>(m, 0, 0, sm);
-        for (int q0 = 0; q0 < nq; q0 += QPB) steps<0>(m, q0, nq, sm);
+        const int nq = (n + B - 1) / B;  // pivot blocks that contain a real row; sweeping identity padding is a no-op
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (wave == owner_wave(0)) publish<0>(m, 0, 0, sm);
+        phase<0>(m, nq, sm);
         __syncthreads();
     }
 
@@ -251,7 +313,7 @@ struct Sweep {
     // out[i] = sum_j (-m_ij) in[j]  for i < NMAX, i.e. A^-1 * in.  `in` must be visible (barrier before);
     // `out` is visible to all threads on return (barrier inside).
     __device__ static __forceinline__ void solve(const float (&m)[RB][CB], const float* in, float* out) {
-        const int i0 = br() * RB, j0 = bc() * CB;
+        const int j0 = bc() * CB;
         float s[RB];
         float x[CB];
 #pragma unroll
@@ -269,7 +331,7 @@ struct Sweep {
             for (int r = 0; r < RB; ++r) s[r] += __shfl_xor(s[r], o, 64);
         if (bc() == 0) {
 #pragma unroll
-            for (int r = 0; r < RB; ++r) out[i0 + r] = s[r];
+            for (int r = 0; r < RB; ++r) out[row(r)] = s[r];
         }
         __syncthreads();
     }

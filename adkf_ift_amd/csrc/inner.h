@@ -39,7 +39,7 @@ struct InnerEval {
     __device__ static __forceinline__ int run(SweepSmem<NMAX, NT>& sm, const float (&d2)[RB][CB], float (&m)[RB][CB], int n,
                                               const float* x, const float* pri, float& f, float* g, float* extra,
                                               bool fast) {
-        const int i0 = SW::br() * RB, j0 = SW::bc() * CB, tid = threadIdx.x;
+        const int j0 = SW::bc() * CB, tid = threadIdx.x;
         const float noise = softplus_f(x[0]) + NOISE_LB, os = softplus_f(x[1]), ls = softplus_f(x[2]);
         const float d1n = sigmoid_f(x[0]), d1s = sigmoid_f(x[1]), d1l = sigmoid_f(x[2]);
         const float il2 = 1.f / (ls * ls), gl = -2.f / ls;
@@ -47,7 +47,7 @@ struct InnerEval {
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int c = 0; c < CB; ++c) {
-                const int i = i0 + r, j = j0 + c;
+                const int i = SW::row(r), j = j0 + c;
                 if (i < n && j < n) {
                     const float u = d2[r][c] * il2;
                     m[r][c] = os * (fast ? kappa0_t<KIND, true>(u) : kappa0_t<KIND, false>(u)) + (i == j ? noise : 0.f);
@@ -62,7 +62,7 @@ struct InnerEval {
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // tr(Ainv G), a^T G a, tr(Ainv), a^T a, y^T a
         float ai[RB], aj[CB];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) ai[r] = sm.vec_out[i0 + r];
+        for (int r = 0; r < RB; ++r) ai[r] = sm.vec_out[SW::row(r)];
 #pragma unroll
         for (int c = 0; c < CB; ++c) aj[c] = sm.vec_out[j0 + c];
 #pragma unroll
@@ -77,7 +77,7 @@ struct InnerEval {
                 const float G = os * k1 * u * gl;
                 acc[0] -= m[r][c] * G;
                 acc[1] += ai[r] * aj[c] * G;
-                if (i0 + r == j0 + c && i0 + r < n) acc[2] -= m[r][c];
+                if (SW::row(r) == j0 + c && SW::row(r) < n) acc[2] -= m[r][c];
             }
         if (tid < n) {
             const float a = sm.vec_out[tid];
@@ -251,14 +251,14 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
     const int tid = threadIdx.x;
     const int n = a.n_s ? a.n_s[t] : a.ld;
     const float* D2 = a.D2ss + (size_t)t * a.ld * a.ld;
-    const int i0 = SW::br() * RB, j0 = SW::bc() * CB;
+    const int j0 = SW::bc() * CB;
 
     float d2[RB][CB], m[RB][CB];
 #pragma unroll
     for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
-            const int i = i0 + r, j = j0 + c;
+            const int i = SW::row(r), j = j0 + c;
             const int hi = i > j ? i : j, lo = i > j ? j : i;  // exactly symmetric input to the sweep
             d2[r][c] = (i < n && j < n) ? D2[(size_t)hi * a.ld + lo] : 0.f;
         }
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int c = 0; c < CB; ++c) {
-                const int i = i0 + r, j = j0 + c;
+                const int i = SW::row(r), j = j0 + c;
                 if (i < n && j < n) Ao[(size_t)i * a.ld + j] = -m[r][c];
             }
     }

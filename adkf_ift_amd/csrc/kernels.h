@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
     const float* ys = a.y_s + (size_t)t * a.tv.ns_ld;
     const float* yq = a.y_q + (size_t)t * a.tv.nq_ld;
     float* vbase = a.vecs + (size_t)t * NVEC * a.tv.vld;
-    const int i0 = SW::br() * RB, j0 = SW::bc() * CB;
+    const int j0 = SW::bc() * CB;
     if (tid < NMAX) sm.vec_in[tid] = 0.f;
     __syncthreads();
     // residual r = y_q - C y_s  (wave per row)
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
     for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
-            const int i = i0 + r, j = j0 + c;
+            const int i = SW::row(r), j = j0 + c;
             const int hi = i > j ? i : j, lo = i > j ? j : i;
             mm[r][c] = (i < m && j < m) ? Si[(size_t)hi * a.tv.nq_ld + lo] : (i == j ? 1.f : 0.f);
         }
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
     for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
-            const int i = i0 + r, j = j0 + c;
+            const int i = SW::row(r), j = j0 + c;
             if (i < m && j < m) Si[(size_t)i * a.tv.nq_ld + j] = -mm[r][c];
         }
     // Cte_j = sum_i C_ij e_i  (thread per column: coalesced)

@@ -11,10 +11,10 @@ __global__ __launch_bounds__(NT) void k_sweep(const float* A, float* out, int n,
     using SW = Sweep<NMAX, NT>;
     constexpr int RB = SW::RB, CB = SW::CB;
     __shared__ SweepSmem<NMAX, NT> sm;
-    const int i0 = SW::br() * RB, j0 = SW::bc() * CB;
+    const int j0 = SW::bc() * CB;
     const float* At = A + (size_t)blockIdx.x * n * n;
     float a[RB][CB], m[RB][CB];
-    for (int r = 0; r < RB; ++r) for (int c = 0; c < CB; ++c) a[r][c] = At[(i0 + r) * n + j0 + c];
+    for (int r = 0; r < RB; ++r) for (int c = 0; c < CB; ++c) a[r][c] = At[SW::row(r) * n + j0 + c];
     float acc = 0.f;
     for (int it = 0; it < reps; ++it) {
         for (int r = 0; r < RB; ++r) for (int c = 0; c < CB; ++c) m[r][c] = a[r][c];
@@ -23,10 +23,6 @@ __global__ __launch_bounds__(NT) void k_sweep(const float* A, float* out, int n,
         if (VAR == 1) {  // update only: no publish (stale vectors), same barriers
             const int nq = n / SW::B;
             for (int q = 0; q < nq; ++q) { __syncthreads(); SW::step(m, q, sm); }
-        }
-        if (VAR == 2) {  // publish only + barriers
-            const int nq = n / SW::B;
-            for (int q = 0; q < nq; q += 2) { __syncthreads(); SW::template publish<0>(m, q, q & 1, sm); __syncthreads(); SW::template publish<1>(m, q + 1, (q + 1) & 1, sm); }
         }
         if (VAR == 3) {  // barriers only
             const int nq = n / SW::B;
@@ -57,7 +53,7 @@ int main(int argc, char** argv) {
     }
     float *dA, *dout; hipMalloc(&dA, A.size() * 4); hipMalloc(&dout, T * 4);
     hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
-    printf("T=%d  us per sweep:  full %.1f | update-only %.1f | publish-only %.1f | barriers-only %.1f\n", T,
-           run<0>(dA, dout, T, n, reps), run<1>(dA, dout, T, n, reps), run<2>(dA, dout, T, n, reps), run<3>(dA, dout, T, n, reps));
+    printf("T=%d  us per sweep:  full %.1f | update-only %.1f | barriers-only %.1f\n", T,
+           run<0>(dA, dout, T, n, reps), run<1>(dA, dout, T, n, reps), run<3>(dA, dout, T, n, reps));
     return 0;
 }
