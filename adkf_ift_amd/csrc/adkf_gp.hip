@@ -65,11 +65,21 @@ int check_batch(const adkf_batch_t* b, bool need_query) {
 inline int grid_for(int T, int tiles) { return ((T + 7) / 8) * 8 * tiles; }
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// 16-byte vector loads are legal when every leading dimension is a multiple of 4 floats and every base is aligned
+// (the workspace carve keeps 256-byte alignment; per-task offsets are then multiples of 16 bytes too).
+bool vec_ok(const adkf_batch_t* b, const Workspace& w) {
+    if ((b->ns_max & 3) || (b->nq_max & 3) || (b->d & 3) || (w.vld & 3)) return false;
+    return aligned16(b->Z_s) && aligned16(b->Z_q) && aligned16(w.mean);
+}
+
 TaskView make_tv(const adkf_batch_t* b, const Workspace& w, bool with_query) {
     TaskView tv;
     tv.n_s = b->n_s; tv.n_q = with_query ? b->n_q : nullptr;
     tv.ns_ld = b->ns_max; tv.nq_ld = with_query ? b->nq_max : 0; tv.vld = w.vld; tv.kind = b->kernel;
     tv.scal = w.scal; tv.vecs = w.vecs;
+    tv.vec = vec_ok(b, w);
     return tv;
 }
 
@@ -82,11 +92,11 @@ inline bool has_query(const adkf_batch_t* b) { return b->nq_max > 0 && b->Z_q !=
 int stage_dist(const adkf_batch_t* b, const Workspace& w, bool with_query, hipStream_t st) {
     if (b->flags & ADKF_BATCH_REUSE_DIST) return 0;
     const int T = b->T, ns = b->ns_max, nq = with_query ? b->nq_max : 0, d = b->d;
-    k_colmean<<<dim3(ceil_div(d, 256), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, T);
+    k_colmean<<<dim3(ceil_div(d, 64), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, T);
     k_rownorm<<<dim3(ceil_div(ns, 4), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, w.nrm_s, T);
     if (with_query) k_rownorm<<<dim3(ceil_div(nq, 4), T), 256, 0, st>>>(b->Z_q, b->n_q, nq, d, w.mean, w.nrm_q, T);
     ProbDist p;
-    p.mean = w.mean; p.d = d;
+    p.mean = w.mean; p.d = d; p.vec = vec_ok(b, w);
     {
         p.X = b->Z_s; p.Y = b->Z_s; p.nx = w.nrm_s; p.ny = w.nrm_s; p.n_x = b->n_s; p.n_y = b->n_s; p.x_ld = ns; p.y_ld = ns; p.symmetric = true; p.D2 = w.D2ss;
         const int tm = ceil_div(ns, GT);
@@ -160,7 +170,7 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         ProbP pp; pp.tv = tv; pp.Ainv = w.Ainv; pp.D2ss = w.D2ss; pp.P = w.P;
         k_bgemm<ProbP><<<grid_for(T, tms * tms), 256, 0, st>>>(pp, T, tms, tms);
         HessArgs ha{tv, w.Ainv, w.P, w.D2ss, b->y_s, b->priors, w.scal, w.vecs, T};
-        k_hess<<<grid_for(T, 1), 256, 0, st>>>(ha);
+        k_hess<<<grid_for(T, 1), SMALL_NT, 0, st>>>(ha);
     }
     ProbC pc; pc.tv = tv; pc.Ainv = w.Ainv; pc.D2qs = w.D2qs; pc.C = w.C;
     k_bgemm<ProbC><<<grid_for(T, tmq * tms), 256, 0, st>>>(pc, T, tmq, tms);
@@ -174,7 +184,7 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
     ProbMA pm; pm.tv = tv; pm.C = w.C; pm.OC = w.OC; pm.D2ss = w.D2ss; pm.Wss = w.Wss; pm.part = w.part_ma; pm.ntiles = w.nt_ma; pm.dirscale = dirscale;
     k_bgemm<ProbMA><<<grid_for(T, tms * tms), 256, 0, st>>>(pm, T, tms, tms);
     WqqArgs wq{tv, w.S, w.D2qq, w.Wqq, w.scal, dirscale, T};
-    k_wqq<<<grid_for(T, 1), 256, 0, st>>>(wq);
+    k_wqq<<<grid_for(T, 1), SMALL_NT, 0, st>>>(wq);
     SolveArgs sa{tv, w.scal, w.vecs, w.part_oc, w.part_ma, w.nt_oc, w.nt_ma, flags, g_phi_out, v_out, H_out, T, with_hessian ? 1 : 0};
     k_solve_v<<<T, 64, 0, st>>>(sa);
     if (corrscale != 0.f) {
@@ -183,7 +193,7 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
     }
     if (dZ_s || dZ_q) {
         RowsumArgs ra{tv, w.Wss, w.Wqs, w.Wqq, w.vecs, T};
-        k_rowsums<<<grid_for(T, 1), 256, 0, st>>>(ra);
+        k_rowsums<<<grid_for(T, 1), SMALL_NT, 0, st>>>(ra);
         const int tn = ceil_div(d, GT);
         if (dZ_s) {
             hipMemsetAsync(dZ_s, 0, (size_t)T * ns * d * sizeof(float), st);
@@ -262,7 +272,7 @@ int adkf_mll_value_grad(const adkf_batch_t* b, const float* phi, float* f_in, fl
         WinArgs wa{tv, w.Ainv, w.D2ss, w.Wss, w.scal, b->T};
         k_win<<<grid_for(b->T, 1), 256, 0, st>>>(wa);
         RowsumArgs ra{tv, w.Wss, nullptr, nullptr, w.vecs, b->T};
-        k_rowsums<<<grid_for(b->T, 1), 256, 0, st>>>(ra);
+        k_rowsums<<<grid_for(b->T, 1), SMALL_NT, 0, st>>>(ra);
         hipMemsetAsync(dZ_s, 0, (size_t)b->T * b->ns_max * b->d * sizeof(float), st);
         ProbDZ<false> pz; pz.tv = tv; pz.Wss = w.Wss; pz.Wqs = nullptr; pz.Wqq = nullptr; pz.Zs = b->Z_s; pz.Zq = nullptr; pz.dZ = dZ_s; pz.d = b->d;
         const int tms = ceil_div(b->ns_max, GT), tn = ceil_div(b->d, GT);

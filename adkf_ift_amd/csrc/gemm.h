@@ -3,6 +3,11 @@
 // squared distances, Omega from S^-1 and e, ...) and a fused epilogue functor (elementwise chain rule +
 // reductions), so no intermediate kernel matrix is ever written to HBM.
 //
+// Pipeline: K is consumed in chunks of 32; the global loads (and the functor arithmetic, e.g. exp) of chunk c+1
+// are issued into registers before the MFMAs of chunk c and written to LDS after them, so memory latency and the
+// VALU work of operand generation hide under the matrix pipe.  LDS layouts are conflict-free for the b32
+// fragment reads: [mn][34] for K-contiguous operands (bank = 2 i + k), [k][80] for MN-contiguous ones.
+//
 // A problem type P provides
 //   static constexpr bool A_KCONTIG / B_KCONTIG : is the operand contiguous in memory along k?  (chooses
 //                                                  the coalesced thread->element map and the LDS layout)
@@ -18,11 +23,56 @@
 namespace adkf {
 
 constexpr int GT = 64;        // tile edge
-constexpr int GK = 16;        // k chunk
-constexpr int LD_MN = GK + 1; // [mn][k] layout, K-contiguous operands (conflict-free b32 fragment reads)
+constexpr int GK = 32;        // k chunk
+constexpr int LD_MN = GK + 2; // [mn][k] layout, K-contiguous operands
 constexpr int LD_K = GT + 16; // [k][mn] layout, MN-contiguous operands (LD % 32 == 16)
+constexpr int GPT = GT * GK / 256;  // operand elements staged per thread per chunk
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Each thread stages GPT = 8 operand entries per chunk as two groups of 4 that are consecutive along the operand's
+// contiguous direction: K-contiguous -> (row r, k4..k4+3), MN-contiguous -> (k, mn4..mn4+3).
+template <class P, bool IS_A>
+__device__ __forceinline__ void gemm_fetch(const P& p, float (&reg)[GPT], int base, int k0, int lim, int K) {
+    constexpr bool KC = IS_A ? P::A_KCONTIG : P::B_KCONTIG;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int ps = 0; ps < GPT / 4; ++ps) {
+        float v[4];
+        if (KC) {
+            const int g = base + (tid >> 3) + ps * 32, gk = k0 + (tid & 7) * 4;
+            if (p.vec && g < lim && gk + 3 < K) {
+                if (IS_A) p.a4(g, gk, v); else p.b4(gk, g, v);
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) v[x] = (g < lim && gk + x < K) ? (IS_A ? p.a(g, gk + x) : p.b(gk + x, g)) : 0.f;
+            }
+        } else {
+            const int g = base + (tid & 15) * 4, gk = k0 + (tid >> 4) + ps * 16;
+            if (p.vec && g + 3 < lim && gk < K) {
+                if (IS_A) p.a4(g, gk, v); else p.b4(gk, g, v);
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) v[x] = (g + x < lim && gk < K) ? (IS_A ? p.a(g + x, gk) : p.b(gk, g + x)) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) reg[ps * 4 + x] = v[x];
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void gemm_stage(float* S, const float (&reg)[GPT]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int ps = 0; ps < GPT / 4; ++ps) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            if (KC) S[((tid >> 3) + ps * 32) * LD_MN + (tid & 7) * 4 + x] = reg[ps * 4 + x];
+            else S[((tid >> 4) + ps * 16) * LD_K + (tid & 15) * 4 + x] = reg[ps * 4 + x];
+        }
+    }
+}
 
 template <class P>
 __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tiles_n) {
@@ -54,44 +104,17 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    float ra[GPT], rb[GPT];
+    gemm_fetch<P, true>(p, ra, m0, 0, M, K);
+    gemm_fetch<P, false>(p, rb, n0, 0, N, K);
     for (int k0 = 0; k0 < K; k0 += GK) {
-        // ---- stage A tile (64 x 16) ----
-        if (P::A_KCONTIG) {
-            const int kk = tid & 15, r0 = tid >> 4;
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const int r = r0 + ps * 16;
-                const int gi = m0 + r, gk = k0 + kk;
-                As[r * LD_MN + kk] = (gi < M && gk < K) ? p.a(gi, gk) : 0.f;
-            }
-        } else {
-            const int mm = tid & 63, kq = tid >> 6;
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const int kk = kq + ps * 4;
-                const int gi = m0 + mm, gk = k0 + kk;
-                As[kk * LD_K + mm] = (gi < M && gk < K) ? p.a(gi, gk) : 0.f;
-            }
-        }
-        // ---- stage B tile (16 x 64) ----
-        if (P::B_KCONTIG) {
-            const int kk = tid & 15, r0 = tid >> 4;
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const int r = r0 + ps * 16;
-                const int gj = n0 + r, gk = k0 + kk;
-                Bs[r * LD_MN + kk] = (gj < N && gk < K) ? p.b(gk, gj) : 0.f;
-            }
-        } else {
-            const int nn = tid & 63, kq = tid >> 6;
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const int kk = kq + ps * 4;
-                const int gj = n0 + nn, gk = k0 + kk;
-                Bs[kk * LD_K + nn] = (gj < N && gk < K) ? p.b(gk, gj) : 0.f;
-            }
-        }
+        gemm_stage<P::A_KCONTIG>(As, ra);
+        gemm_stage<P::B_KCONTIG>(Bs, rb);
         __syncthreads();
+        if (k0 + GK < K) {  // next chunk's loads fly while this chunk is multiplied
+            gemm_fetch<P, true>(p, ra, m0, k0 + GK, M, K);
+            gemm_fetch<P, false>(p, rb, n0, k0 + GK, N, K);
+        }
 #pragma unroll
         for (int s = 0; s < GK / 4; ++s) {
             float af[2], bf[2];

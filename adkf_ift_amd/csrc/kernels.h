@@ -6,15 +6,24 @@
 namespace adkf {
 
 // ---- column mean of the support features (gpytorch centres both operands by x1.mean) -----------------
+// block = 64 columns x 4 row groups (grid: ceil(d/64) x T): 4x the workgroups and a quarter of the serial loop of
+// a thread-per-column kernel; rows are read in coalesced 256-B segments.
 __global__ __launch_bounds__(256) void k_colmean(const float* Zs, const int32_t* n_s, int ns_ld, int d, float* mean, int T) {
+    __shared__ float part[4][64];
     const int t = blockIdx.y;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= d) return;
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     const int n = n_s ? n_s[t] : ns_ld;
     const float* Z = Zs + (size_t)t * ns_ld * d;
     float s = 0.f;
-    for (int i = 0; i < n; ++i) s += Z[(size_t)i * d + c];
-    mean[(size_t)t * d + c] = n > 0 ? s / (float)n : 0.f;
+    if (c < d)
+        for (int i = g; i < n; i += 4) s += Z[(size_t)i * d + c];
+    part[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && c < d) {
+        s = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+        mean[(size_t)t * d + c] = n > 0 ? s / (float)n : 0.f;
+    }
 }
 
 // ---- squared norms of the centred rows: one wave per row ----------------------------------------------
@@ -39,7 +48,7 @@ struct ProbDist {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
     static constexpr int NRED = 0;
     const float *X, *Y, *mean, *nx, *ny; const int32_t *n_x, *n_y; int x_ld, y_ld, d; bool symmetric; float* D2;
-    int mx, my; const float *Xi, *Yi, *mu, *nxi, *nyi; float* Do;
+    int mx, my; const float *Xi, *Yi, *mu, *nxi, *nyi; float* Do; bool vec;
     __device__ bool setup(int t) {
         mx = n_x ? n_x[t] : x_ld; my = n_y ? n_y[t] : y_ld;
         Xi = X + (size_t)t * x_ld * d; Yi = Y + (size_t)t * y_ld * d; mu = mean + (size_t)t * d;
@@ -49,6 +58,20 @@ struct ProbDist {
     __device__ int M() const { return mx; } __device__ int N() const { return my; } __device__ int K() const { return d; }
     __device__ float a(int i, int k) const { return Xi[(size_t)i * d + k] - mu[k]; }
     __device__ float b(int k, int j) const { return Yi[(size_t)j * d + k] - mu[k]; }
+    __device__ void a4(int i, int k, float (&v)[4]) const {
+        float m4[4];
+        ld4(Xi + (size_t)i * d + k, v);
+        ld4(mu + k, m4);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[x] -= m4[x];
+    }
+    __device__ void b4(int k, int j, float (&v)[4]) const {
+        float m4[4];
+        ld4(Yi + (size_t)j * d + k, v);
+        ld4(mu + k, m4);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[x] -= m4[x];
+    }
     __device__ void epi(int i, int j, float acc, float*) const {
         float v = fmaxf(nxi[i] + nyi[j] - 2.f * acc, 0.f);
         if (symmetric && i == j) v = 0.f;
@@ -112,8 +135,11 @@ __global__ void k_init_params(const float* l0, int T, int numeric, int use_ls_pr
 // (oracle/closed_form.py::inner_stage, want_hessian branch)
 struct HessArgs { TaskView tv; const float* Ainv; const float* P; const float* D2ss; const float* y_s; const float* priors; float* scal; float* vecs; int T; };
 
-__global__ __launch_bounds__(256) void k_hess(HessArgs a) {
-    __shared__ float red[9 * 4];
+constexpr int SMALL_NT = 1024;  // the per-task elementwise/mat-vec kernels: 16 waves per task
+
+__global__ __launch_bounds__(SMALL_NT) void k_hess(HessArgs a) {
+    constexpr int NT = SMALL_NT, NW = NT / 64;
+    __shared__ float red[9 * NW];
     int t, tile;
     if (!task_tile(a.T, 1, t, tile)) return;
     const int n = a.tv.ns(t), ld = a.tv.ns_ld, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -128,7 +154,7 @@ __global__ __launch_bounds__(256) void k_hess(HessArgs a) {
     float* de = a.vecs + ((size_t)t * NVEC + V_DELTA) * a.tv.vld;
     const int kind = a.tv.kind;
     // wave per row: beta_i = sum_j G_ij alpha_j ; gamma_i = sum_j Ainv_ij alpha_j
-    for (int i = wv; i < n; i += 4) {
+    for (int i = wv; i < n; i += NW) {
         float sb = 0.f, sg = 0.f;
         for (int j = lane; j < n; j += 64) {
             float k0, k1, k2; const float u = D2[(size_t)i * ld + j] * il2; kappa3(kind, u, k0, k1, k2);
@@ -141,7 +167,7 @@ __global__ __launch_bounds__(256) void k_hess(HessArgs a) {
     }
     __threadfence_block();
     __syncthreads();
-    for (int i = wv; i < n; i += 4) {
+    for (int i = wv; i < n; i += NW) {
         float sd = 0.f;
         for (int j = lane; j < n; j += 64) sd += Ai[(size_t)i * ld + j] * be[j];
         sd = wave_sum(sd);
@@ -151,7 +177,7 @@ __global__ __launch_bounds__(256) void k_hess(HessArgs a) {
     __syncthreads();
     // elementwise traces
     float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // trA2, trPA, trPP, trAinvKll, aKlla, ag, bg, bd, ab
-    for (int e = tid; e < n * n; e += 256) {
+    for (int e = tid; e < n * n; e += NT) {
         const int i = e / n, j = e - i * n;
         const float ai = Ai[(size_t)i * ld + j], pij = Pi[(size_t)i * ld + j], pji = Pi[(size_t)j * ld + i];
         float k0, k1, k2; const float u = D2[(size_t)i * ld + j] * il2; kappa3(kind, u, k0, k1, k2);
@@ -159,8 +185,8 @@ __global__ __launch_bounds__(256) void k_hess(HessArgs a) {
         acc[0] += ai * ai; acc[1] += pij * ai; acc[2] += pij * pji; acc[3] += ai * Kll; acc[4] += al[i] * al[j] * Kll;
     }
     if (tid < n) { acc[5] = al[tid] * ga[tid]; acc[6] = be[tid] * ga[tid]; acc[7] = be[tid] * de[tid]; acc[8] = al[tid] * be[tid]; }
-    for (int i = tid + 256; i < n; i += 256) { acc[5] += al[i] * ga[i]; acc[6] += be[i] * ga[i]; acc[7] += be[i] * de[i]; acc[8] += al[i] * be[i]; }
-    block_sum<9, 256>(acc, red);
+    for (int i = tid + NT; i < n; i += NT) { acc[5] += al[i] * ga[i]; acc[6] += be[i] * ga[i]; acc[7] += be[i] * de[i]; acc[8] += al[i] * be[i]; }
+    block_sum<9, NT>(acc, red);
     if (tid == 0) {
         const float trA2 = acc[0], trPA = acc[1], trPP = acc[2], trAinvKll = acc[3], aKlla = acc[4], ag = acc[5], bg = acc[6], bd = acc[7], ab = acc[8];
         const float trAinv = sc[S_TRAINV], aa = sc[S_AA], ya = sc[S_YA], trAinvG = sc[S_TRAINVG], aGa = sc[S_AGA];
@@ -258,8 +284,9 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
 // ---- W_qq = dir * Omega . s kappa'(u_qq)/l^2 and its three reductions -------------------------------------
 struct WqqArgs { TaskView tv; const float* Sinv; const float* D2qq; float* Wqq; float* scal; float dirscale; int T; };
 
-__global__ __launch_bounds__(256) void k_wqq(WqqArgs a) {
-    __shared__ float red[3 * 4];
+__global__ __launch_bounds__(SMALL_NT) void k_wqq(WqqArgs a) {
+    constexpr int NT = SMALL_NT;
+    __shared__ float red[3 * (NT / 64)];
     int t, tile;
     if (!task_tile(a.T, 1, t, tile)) return;
     const int m = a.tv.nq(t), ld = a.tv.nq_ld, tid = threadIdx.x;
@@ -268,9 +295,9 @@ __global__ __launch_bounds__(256) void k_wqq(WqqArgs a) {
     const float* Si = a.Sinv + (size_t)t * ld * ld;
     const float* D2 = a.D2qq + (size_t)t * ld * ld;
     float* Wo = a.Wqq + (size_t)t * ld * ld;
-    const float* ev = a.tv.vec(t, V_E);
+    const float* ev = a.tv.vec_ptr(t, V_E);
     float acc[3] = {0.f, 0.f, 0.f};
-    for (int e = tid; e < m * m; e += 256) {
+    for (int e = tid; e < m * m; e += NT) {
         const int i = e / m, j = e - i * m;
         const float om = 0.5f * (Si[(size_t)i * ld + j] - ev[i] * ev[j]);
         float k0, k1, k2; const float u = D2[(size_t)i * ld + j] * il2; kappa3(a.tv.kind, u, k0, k1, k2);
@@ -279,7 +306,7 @@ __global__ __launch_bounds__(256) void k_wqq(WqqArgs a) {
         acc[1] += om * k0;
         acc[2] += om * os * k1 * u * (-2.f / ls);
     }
-    block_sum<3, 256>(acc, red);
+    block_sum<3, NT>(acc, red);
     if (tid == 0) { sc[S_QQ_TR] = acc[0]; sc[S_QQ_K] = acc[1]; sc[S_QQ_L] = acc[2]; }
 }
 
@@ -294,7 +321,7 @@ __global__ __launch_bounds__(256) void k_win(WinArgs a) {
     const float os = sc[S_OS], ls = sc[S_LS], il2 = 1.f / (ls * ls);
     const float* Ai = a.Ainv + (size_t)t * ld * ld;
     const float* D2 = a.D2ss + (size_t)t * ld * ld;
-    const float* al = a.tv.vec(t, V_ALPHA);
+    const float* al = a.tv.vec_ptr(t, V_ALPHA);
     float* Wo = a.Wss + (size_t)t * ld * ld;
     for (int e = threadIdx.x; e < n * n; e += 256) {
         const int i = e / n, j = e - i * n;
@@ -359,7 +386,8 @@ __global__ __launch_bounds__(64) void k_solve_v(SolveArgs a) {
 // coef_s[i] = 2 (2 rowsum(W_ss)[i] + colsum(W_qs)[i]);  coef_q[i] = 2 (rowsum(W_qs)[i] + 2 rowsum(W_qq)[i])
 struct RowsumArgs { TaskView tv; const float* Wss; const float* Wqs; const float* Wqq; float* vecs; int T; };
 
-__global__ __launch_bounds__(256) void k_rowsums(RowsumArgs a) {
+__global__ __launch_bounds__(SMALL_NT) void k_rowsums(RowsumArgs a) {
+    constexpr int NT = SMALL_NT, NW = NT / 64;
     int t, tile;
     if (!task_tile(a.T, 1, t, tile)) return;
     const int n = a.tv.ns(t), m = a.Wqs ? a.tv.nq(t) : 0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -367,23 +395,30 @@ __global__ __launch_bounds__(256) void k_rowsums(RowsumArgs a) {
     const float* Wqs = a.Wqs ? a.Wqs + (size_t)t * a.tv.nq_ld * a.tv.ns_ld : nullptr;
     const float* Wqq = a.Wqq ? a.Wqq + (size_t)t * a.tv.nq_ld * a.tv.nq_ld : nullptr;
     float* vb = a.vecs + (size_t)t * NVEC * a.tv.vld;
-    __shared__ float cs[1];
-    (void)cs;
-    for (int i = wv; i < n; i += 4) {
+    // column sums of W_qs: every wave sums its share of the rows for all columns (coalesced), partials meet in LDS
+    constexpr int CMAX = 128;  // >= adkf_max_points()
+    __shared__ float cpart[NW][CMAX];
+    if (m > 0) {
+        for (int j = lane; j < n; j += 64) {
+            float s = 0.f;
+            for (int i = wv; i < m; i += NW) s += Wqs[(size_t)i * a.tv.ns_ld + j];
+            cpart[wv][j] = s;
+        }
+    }
+    __syncthreads();
+    for (int i = wv; i < n; i += NW) {
         float s = 0.f;
         for (int j = lane; j < n; j += 64) s += Wss[(size_t)i * a.tv.ns_ld + j];
         s = wave_sum(s);
-        if (lane == 0) vb[V_RS_SS * a.tv.vld + i] = 4.f * s;
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (m > 0) {
-        for (int j = tid; j < n; j += 256) {
-            float s = 0.f;
-            for (int i = 0; i < m; ++i) s += Wqs[(size_t)i * a.tv.ns_ld + j];
-            vb[V_RS_SS * a.tv.vld + j] += 2.f * s;
+        if (lane == 0) {
+            float cs = 0.f;
+            if (m > 0)
+                for (int w = 0; w < NW; ++w) cs += cpart[w][i];
+            vb[V_RS_SS * a.tv.vld + i] = 4.f * s + 2.f * cs;
         }
-        for (int i = wv; i < m; i += 4) {
+    }
+    if (m > 0) {
+        for (int i = wv; i < m; i += NW) {
             float s1 = 0.f, s2 = 0.f;
             for (int j = lane; j < n; j += 64) s1 += Wqs[(size_t)i * a.tv.ns_ld + j];
             for (int j = lane; j < m; j += 64) s2 += Wqq[(size_t)i * a.tv.nq_ld + j];

@@ -1,6 +1,11 @@
 // Problem functors for k_bgemm: every matrix product of the outer-NLL / Hessian / mixed-partial / dZ stages
 // (oracle/closed_form.py names the same stages).  Operands that are elementwise functions of the squared
 // distances (K_qs, dK/dl, Omega, A^-1 B_v ...) are generated while staging the tile, never stored.
+//
+// Every functor offers scalar accessors a(i,k) / b(k,j) and 4-wide ones a4 / b4 that fetch four consecutive
+// entries along the operand's contiguous direction with ONE 16-byte load per source array (the tile loader uses
+// them whenever TaskView::vec says all leading dimensions are multiples of 4 and the bases 16-byte aligned):
+// the vector-memory pipe, not the matrix pipe, was the limiter with dword loads.
 #pragma once
 #include "gemm.h"
 
@@ -13,28 +18,38 @@ struct TaskView {
     int ns_ld, nq_ld, vld, kind;
     const float* scal;  // [T, NSCAL]
     const float* vecs;  // [T, NVEC, vld]
+    bool vec;           // 16-byte loads are legal on every array of this batch
     __device__ __forceinline__ int ns(int t) const { return n_s ? n_s[t] : ns_ld; }
     __device__ __forceinline__ int nq(int t) const { return n_q ? n_q[t] : nq_ld; }
-    __device__ __forceinline__ const float* vec(int t, int which) const { return vecs + ((size_t)t * NVEC + which) * vld; }
+    __device__ __forceinline__ const float* vec_ptr(int t, int which) const { return vecs + ((size_t)t * NVEC + which) * vld; }
 };
+
+__device__ __forceinline__ void ld4(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
 
 // ---- G1: P = Ainv * G,   G = dK_ss/dl = s kappa'(u) (-2u/l) ------------------------------------------
 struct ProbP {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
     static constexpr int NRED = 0;
     TaskView tv; const float* Ainv; const float* D2ss; float* P;
-    int n; float os, ls, il2; const float *Ai, *D2; float* Po;
+    int n; float os, ls, il2; const float *Ai, *D2; float* Po; bool vec;
     __device__ bool setup(int t) {
-        n = tv.ns(t); const float* sc = tv.scal + (size_t)t * NSCAL;
+        n = tv.ns(t); const float* sc = tv.scal + (size_t)t * NSCAL; vec = tv.vec;
         os = sc[S_OS]; ls = sc[S_LS]; il2 = 1.f / (ls * ls);
         Ai = Ainv + (size_t)t * tv.ns_ld * tv.ns_ld; D2 = D2ss + (size_t)t * tv.ns_ld * tv.ns_ld; Po = P + (size_t)t * tv.ns_ld * tv.ns_ld;
         return n > 0;
     }
     __device__ int M() const { return n; } __device__ int N() const { return n; } __device__ int K() const { return n; }
+    __device__ float gfun(float d2) const { float k0, k1, k2; const float u = d2 * il2; kappa3(tv.kind, u, k0, k1, k2); return os * k1 * u * (-2.f / ls); }
     __device__ float a(int i, int k) const { return Ai[(size_t)i * tv.ns_ld + k]; }
-    __device__ float b(int k, int j) const {  // G symmetric: read row j (contiguous in k)
-        float k0, k1, k2; const float u = D2[(size_t)j * tv.ns_ld + k] * il2; kappa3(tv.kind, u, k0, k1, k2);
-        return os * k1 * u * (-2.f / ls);
+    __device__ float b(int k, int j) const { return gfun(D2[(size_t)j * tv.ns_ld + k]); }  // G symmetric: row j, contiguous in k
+    __device__ void a4(int i, int k, float (&v)[4]) const { ld4(Ai + (size_t)i * tv.ns_ld + k, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const {
+        ld4(D2 + (size_t)j * tv.ns_ld + k, v);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[x] = gfun(v[x]);
     }
     __device__ void epi(int i, int j, float acc, float*) const { Po[(size_t)i * tv.ns_ld + j] = acc; }
     __device__ void store_red(int, const float*) const {}
@@ -45,9 +60,9 @@ struct ProbC {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
     static constexpr int NRED = 0;
     TaskView tv; const float* Ainv; const float* D2qs; float* C;
-    int n, m; float os, il2; const float *Ai, *D2; float* Co;
+    int n, m; float os, il2; const float *Ai, *D2; float* Co; bool vec;
     __device__ bool setup(int t) {
-        n = tv.ns(t); m = tv.nq(t); const float* sc = tv.scal + (size_t)t * NSCAL;
+        n = tv.ns(t); m = tv.nq(t); const float* sc = tv.scal + (size_t)t * NSCAL; vec = tv.vec;
         os = sc[S_OS]; il2 = 1.f / (sc[S_LS] * sc[S_LS]);
         Ai = Ainv + (size_t)t * tv.ns_ld * tv.ns_ld; D2 = D2qs + (size_t)t * tv.nq_ld * tv.ns_ld; Co = C + (size_t)t * tv.nq_ld * tv.ns_ld;
         return n > 0 && m > 0;
@@ -55,6 +70,12 @@ struct ProbC {
     __device__ int M() const { return m; } __device__ int N() const { return n; } __device__ int K() const { return n; }
     __device__ float a(int i, int k) const { return os * kappa0(tv.kind, D2[(size_t)i * tv.ns_ld + k] * il2); }
     __device__ float b(int k, int j) const { return Ai[(size_t)j * tv.ns_ld + k]; }
+    __device__ void a4(int i, int k, float (&v)[4]) const {
+        ld4(D2 + (size_t)i * tv.ns_ld + k, v);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[x] = os * kappa0(tv.kind, v[x] * il2);
+    }
+    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(Ai + (size_t)j * tv.ns_ld + k, v); }
     __device__ void epi(int i, int j, float acc, float*) const { Co[(size_t)i * tv.ns_ld + j] = acc; }
     __device__ void store_red(int, const float*) const {}
 };
@@ -64,9 +85,9 @@ struct ProbS {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
     static constexpr int NRED = 0;
     TaskView tv; const float* C; const float* D2qs; const float* D2qq; float* S;
-    int n, m; float os, il2, noise; const float *Ci, *Dqs, *Dqq; float* So;
+    int n, m; float os, il2, noise; const float *Ci, *Dqs, *Dqq; float* So; bool vec;
     __device__ bool setup(int t) {
-        n = tv.ns(t); m = tv.nq(t); const float* sc = tv.scal + (size_t)t * NSCAL;
+        n = tv.ns(t); m = tv.nq(t); const float* sc = tv.scal + (size_t)t * NSCAL; vec = tv.vec;
         os = sc[S_OS]; il2 = 1.f / (sc[S_LS] * sc[S_LS]); noise = sc[S_NOISE];
         Ci = C + (size_t)t * tv.nq_ld * tv.ns_ld; Dqs = D2qs + (size_t)t * tv.nq_ld * tv.ns_ld;
         Dqq = D2qq + (size_t)t * tv.nq_ld * tv.nq_ld; So = S + (size_t)t * tv.nq_ld * tv.nq_ld;
@@ -75,6 +96,12 @@ struct ProbS {
     __device__ int M() const { return m; } __device__ int N() const { return m; } __device__ int K() const { return n; }
     __device__ float a(int i, int k) const { return Ci[(size_t)i * tv.ns_ld + k]; }
     __device__ float b(int k, int j) const { return os * kappa0(tv.kind, Dqs[(size_t)j * tv.ns_ld + k] * il2); }
+    __device__ void a4(int i, int k, float (&v)[4]) const { ld4(Ci + (size_t)i * tv.ns_ld + k, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const {
+        ld4(Dqs + (size_t)j * tv.ns_ld + k, v);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[x] = os * kappa0(tv.kind, v[x] * il2);
+    }
     __device__ void epi(int i, int j, float acc, float*) const {
         So[(size_t)i * tv.nq_ld + j] = os * kappa0(tv.kind, Dqq[(size_t)i * tv.nq_ld + j] * il2) - acc + (i == j ? noise : 0.f);
     }
@@ -86,18 +113,27 @@ struct ProbOC {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = false;
     static constexpr int NRED = 2;
     TaskView tv; const float* Sinv; const float* C; const float* D2qs; float* OC; float* Wqs; float* part; int ntiles; float dirscale;
-    int n, m, t_; float os, ls, il2; const float *Si, *Ci, *Dqs, *ev, *al; float *OCo, *Wo;
+    int n, m, t_; float os, ls, il2; const float *Si, *Ci, *Dqs, *ev, *al; float *OCo, *Wo; bool vec;
     __device__ bool setup(int t) {
-        t_ = t; n = tv.ns(t); m = tv.nq(t); const float* sc = tv.scal + (size_t)t * NSCAL;
+        t_ = t; n = tv.ns(t); m = tv.nq(t); const float* sc = tv.scal + (size_t)t * NSCAL; vec = tv.vec;
         os = sc[S_OS]; ls = sc[S_LS]; il2 = 1.f / (ls * ls);
         Si = Sinv + (size_t)t * tv.nq_ld * tv.nq_ld; Ci = C + (size_t)t * tv.nq_ld * tv.ns_ld; Dqs = D2qs + (size_t)t * tv.nq_ld * tv.ns_ld;
         OCo = OC + (size_t)t * tv.nq_ld * tv.ns_ld; Wo = Wqs + (size_t)t * tv.nq_ld * tv.ns_ld;
-        ev = tv.vec(t, V_E); al = tv.vec(t, V_ALPHA);
+        ev = tv.vec_ptr(t, V_E); al = tv.vec_ptr(t, V_ALPHA);
         return n > 0 && m > 0;
     }
     __device__ int M() const { return m; } __device__ int N() const { return n; } __device__ int K() const { return m; }
     __device__ float a(int i, int k) const { return 0.5f * (Si[(size_t)i * tv.nq_ld + k] - ev[i] * ev[k]); }
     __device__ float b(int k, int j) const { return Ci[(size_t)k * tv.ns_ld + j]; }
+    __device__ void a4(int i, int k, float (&v)[4]) const {
+        float e4[4];
+        ld4(Si + (size_t)i * tv.nq_ld + k, v);
+        ld4(ev + k, e4);
+        const float ei = ev[i];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[x] = 0.5f * (v[x] - ei * e4[x]);
+    }
+    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(Ci + (size_t)k * tv.ns_ld + j, v); }
     __device__ void epi(int i, int j, float acc, float* red) const {
         OCo[(size_t)i * tv.ns_ld + j] = acc;
         const float MB = -2.f * acc - ev[i] * al[j];
@@ -116,17 +152,19 @@ struct ProbMA {
     static constexpr bool A_KCONTIG = false, B_KCONTIG = false;
     static constexpr int NRED = 3;
     TaskView tv; const float* C; const float* OC; const float* D2ss; float* Wss; float* part; int ntiles; float dirscale;
-    int n, m, t_; float os, ls, il2; const float *Ci, *OCi, *Dss, *cte, *al; float* Wo;
+    int n, m, t_; float os, ls, il2; const float *Ci, *OCi, *Dss, *cte, *al; float* Wo; bool vec;
     __device__ bool setup(int t) {
-        t_ = t; n = tv.ns(t); m = tv.nq(t); const float* sc = tv.scal + (size_t)t * NSCAL;
+        t_ = t; n = tv.ns(t); m = tv.nq(t); const float* sc = tv.scal + (size_t)t * NSCAL; vec = tv.vec;
         os = sc[S_OS]; ls = sc[S_LS]; il2 = 1.f / (ls * ls);
         Ci = C + (size_t)t * tv.nq_ld * tv.ns_ld; OCi = OC + (size_t)t * tv.nq_ld * tv.ns_ld; Dss = D2ss + (size_t)t * tv.ns_ld * tv.ns_ld;
-        Wo = Wss + (size_t)t * tv.ns_ld * tv.ns_ld; cte = tv.vec(t, V_CTE); al = tv.vec(t, V_ALPHA);
+        Wo = Wss + (size_t)t * tv.ns_ld * tv.ns_ld; cte = tv.vec_ptr(t, V_CTE); al = tv.vec_ptr(t, V_ALPHA);
         return n > 0 && m > 0;
     }
     __device__ int M() const { return n; } __device__ int N() const { return n; } __device__ int K() const { return m; }
     __device__ float a(int i, int k) const { return Ci[(size_t)k * tv.ns_ld + i]; }
     __device__ float b(int k, int j) const { return OCi[(size_t)k * tv.ns_ld + j]; }
+    __device__ void a4(int i, int k, float (&v)[4]) const { ld4(Ci + (size_t)k * tv.ns_ld + i, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(OCi + (size_t)k * tv.ns_ld + j, v); }
     __device__ void epi(int i, int j, float acc, float* red) const {
         const float MA = acc + 0.5f * (cte[i] * al[j] + al[i] * cte[j]);
         float k0, k1, k2; const float u = Dss[(size_t)i * tv.ns_ld + j] * il2; kappa3(tv.kind, u, k0, k1, k2);
@@ -146,12 +184,12 @@ struct ProbMixed {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
     static constexpr int NRED = 0;
     TaskView tv; const float* Ainv; const float* P; const float* D2ss; float* Wss; float corrscale;
-    int n; float os, ls, il2, noise, cn, cs, cl; const float *Ai, *Pi, *Dss, *al, *wv; float* Wo;
+    int n; float os, ls, il2, noise, cn, cs, cl; const float *Ai, *Pi, *Dss, *al, *wv; float* Wo; bool vec;
     __device__ bool setup(int t) {
-        n = tv.ns(t); const float* sc = tv.scal + (size_t)t * NSCAL;
+        n = tv.ns(t); const float* sc = tv.scal + (size_t)t * NSCAL; vec = tv.vec;
         os = sc[S_OS]; ls = sc[S_LS]; il2 = 1.f / (ls * ls); noise = sc[S_NOISE]; cn = sc[S_CN]; cs = sc[S_CS]; cl = sc[S_CL];
         Ai = Ainv + (size_t)t * tv.ns_ld * tv.ns_ld; Pi = P + (size_t)t * tv.ns_ld * tv.ns_ld; Dss = D2ss + (size_t)t * tv.ns_ld * tv.ns_ld;
-        Wo = Wss + (size_t)t * tv.ns_ld * tv.ns_ld; al = tv.vec(t, V_ALPHA); wv = tv.vec(t, V_W);
+        Wo = Wss + (size_t)t * tv.ns_ld * tv.ns_ld; al = tv.vec_ptr(t, V_ALPHA); wv = tv.vec_ptr(t, V_W);
         return n > 0;
     }
     __device__ int M() const { return n; } __device__ int N() const { return n; } __device__ int K() const { return n; }
@@ -160,6 +198,14 @@ struct ProbMixed {
         return (cn - cs * noise) * ai + (i == k ? cs : 0.f) + cl * Pi[(size_t)i * tv.ns_ld + k];
     }
     __device__ float b(int k, int j) const { return Ai[(size_t)j * tv.ns_ld + k]; }
+    __device__ void a4(int i, int k, float (&v)[4]) const {
+        float p4[4];
+        ld4(Ai + (size_t)i * tv.ns_ld + k, v);
+        ld4(Pi + (size_t)i * tv.ns_ld + k, p4);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[x] = (cn - cs * noise) * v[x] + (i == k + x ? cs : 0.f) + cl * p4[x];
+    }
+    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(Ai + (size_t)j * tv.ns_ld + k, v); }
     __device__ void epi(int i, int j, float acc, float*) const {
         const float fn = (float)n;
         const float dgdA = (-0.5f * acc + 0.5f * (wv[i] * al[j] + al[i] * wv[j])) / fn;
@@ -179,15 +225,15 @@ struct ProbDZ {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = false;
     static constexpr int NRED = 0;
     TaskView tv; const float* Wss; const float* Wqs; const float* Wqq; const float* Zs; const float* Zq; float* dZ; int d;
-    int n, m; const float *Wssi, *Wqsi, *Wqqi, *Zsi, *Zqi, *coef; float* dZo;
+    int n, m; const float *Wssi, *Wqsi, *Wqqi, *Zsi, *Zqi, *coef; float* dZo; bool vec;
     __device__ bool setup(int t) {
-        n = tv.ns(t); m = Wqs ? tv.nq(t) : 0;
+        n = tv.ns(t); m = Wqs ? tv.nq(t) : 0; vec = tv.vec;
         Wssi = Wss ? Wss + (size_t)t * tv.ns_ld * tv.ns_ld : nullptr;
         Wqsi = Wqs ? Wqs + (size_t)t * tv.nq_ld * tv.ns_ld : nullptr;
         Wqqi = Wqq ? Wqq + (size_t)t * tv.nq_ld * tv.nq_ld : nullptr;
         Zsi = Zs + (size_t)t * tv.ns_ld * d; Zqi = Zq ? Zq + (size_t)t * tv.nq_ld * d : nullptr;
         dZo = dZ + (size_t)t * (QUERY ? tv.nq_ld : tv.ns_ld) * d;
-        coef = tv.vec(t, QUERY ? V_RS_QS : V_RS_SS);  // coefficient vectors prepared by k_rowsums
+        coef = tv.vec_ptr(t, QUERY ? V_RS_QS : V_RS_SS);  // coefficient vectors prepared by k_rowsums
         return QUERY ? (m > 0) : (n > 0);
     }
     __device__ int M() const { return QUERY ? m : n; } __device__ int N() const { return d; } __device__ int K() const { return n + m; }
@@ -196,6 +242,22 @@ struct ProbDZ {
         return k < n ? 2.f * Wqsi[(size_t)i * tv.ns_ld + k] : 4.f * Wqqi[(size_t)i * tv.nq_ld + (k - n)];
     }
     __device__ float b(int k, int j) const { return k < n ? Zsi[(size_t)k * d + j] : Zqi[(size_t)(k - n) * d + j]; }
+    __device__ void a4(int i, int k, float (&v)[4]) const {
+        if (k + 3 < n) {
+            ld4((QUERY ? Wqsi : Wssi) + (size_t)i * tv.ns_ld + k, v);
+            const float f = QUERY ? 2.f : 4.f;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) v[x] *= f;
+        } else if (QUERY && k >= n && ((n & 3) == 0)) {
+            ld4(Wqqi + (size_t)i * tv.nq_ld + (k - n), v);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) v[x] *= 4.f;
+        } else {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) v[x] = a(i, k + x);  // W_qs^T segment (strided) or a group straddling the segments
+        }
+    }
+    __device__ void b4(int k, int j, float (&v)[4]) const { ld4((k < n ? Zsi + (size_t)k * d : Zqi + (size_t)(k - n) * d) + j, v); }
     __device__ void epi(int i, int j, float acc, float*) const {
         const float z = QUERY ? Zqi[(size_t)i * d + j] : Zsi[(size_t)i * d + j];
         dZo[(size_t)i * d + j] = coef[i] * z - acc;
