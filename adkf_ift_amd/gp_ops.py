@@ -229,12 +229,19 @@ def outer_nll_value_grad(b: GPBatch, phi: torch.Tensor, want_grads=True):
     return f, g, dZs, dZq, info
 
 
-def ift_hypergrad(b: GPBatch, phi: torch.Tensor, ignore_grad_correction=False, ignore_direct_grad=False):
-    """Returns dict(f_out, dZ_s, dZ_q, g_phi, v, H, info): the IFT hypergradient at the feature level."""
+def ift_hypergrad(b: GPBatch, phi: torch.Tensor, ignore_grad_correction=False, ignore_direct_grad=False, out_dZ=None):
+    """Returns dict(f_out, dZ_s, dZ_q, g_phi, v, H, info): the IFT hypergradient at the feature level.
+    ``out_dZ = (dZ_s, dZ_q)``: optional preallocated contiguous float32 outputs (e.g. two halves of one buffer)."""
     lib = _lib.load()
     phi = _f32(phi, "phi")
     flags = (_lib.IGNORE_GRAD_CORRECTION if ignore_grad_correction else 0) | (_lib.IGNORE_DIRECT_GRAD if ignore_direct_grad else 0)
-    out = dict(f_out=_new(b, b.T), dZ_s=_new(b, b.T, b.ns, b.d), dZ_q=_new(b, b.T, b.nq, b.d), g_phi=_new(b, b.T, 3),
+    if out_dZ is not None:
+        dZ_s, dZ_q = out_dZ
+        assert dZ_s.is_contiguous() and dZ_q.is_contiguous() and dZ_s.dtype == torch.float32 and dZ_q.dtype == torch.float32
+        assert dZ_s.shape == b.Z_s.shape and dZ_q.shape == b.Z_q.shape
+    else:
+        dZ_s, dZ_q = _new(b, b.T, b.ns, b.d), _new(b, b.T, b.nq, b.d)
+    out = dict(f_out=_new(b, b.T), dZ_s=dZ_s, dZ_q=dZ_q, g_phi=_new(b, b.T, 3),
                v=_new(b, b.T, 3), H=_new(b, b.T, 9), info=_new(b, b.T, dtype=torch.int32))
     ws, nb = b.workspace()
     cb = b.c_struct()

@@ -35,7 +35,7 @@ class HipGPBackend:
     """The product backend: every call lands in libadkf_gp.so.  (Tests may substitute an oracle-backed object with
     the same ``run`` method to exercise the harness/collective logic on CPU ranks.)"""
 
-    def run(self, Z_s, y_s, Z_q, y_q, cfg: MetaStepConfig, n_s=None, n_q=None, fit_events=None):
+    def run(self, Z_s, y_s, Z_q, y_q, cfg: MetaStepConfig, n_s=None, n_q=None, fit_events=None, out_dZ=None):
         """a3/a4 re-initialisation -> a7 inner fit -> a9 IFT hypergradient for every task of the meta-batch.
         One GPBatch / one workspace for the three calls, so the squared distances are built once and the
         hypergradient reuses the A^-1, alpha the fit left behind."""
@@ -47,7 +47,7 @@ class HipGPBackend:
         phi, f_in, gnorm, nev, info_fit = gp_ops.fit(b, phi0, cfg.inner_max_evals, cfg.inner_gtol, cfg.inner_ftol,
                                                      cfg.inner_exact_evals, events=fit_events)
         b.flags = gp_ops.REUSE_DIST | gp_ops.REUSE_INNER
-        out = gp_ops.ift_hypergrad(b, phi, ignore_grad_correction=cfg.ignore_grad_correction)
+        out = gp_ops.ift_hypergrad(b, phi, ignore_grad_correction=cfg.ignore_grad_correction, out_dZ=out_dZ)
         return phi, out["f_out"], out["dZ_s"], out["dZ_q"], info_fit, out["info"]
 
 
@@ -68,25 +68,39 @@ def meta_step(features_fn: Callable[[], Tuple[torch.Tensor, torch.Tensor]], para
               optimizer: Optional[torch.optim.Optimizer], y_s: torch.Tensor, y_q: torch.Tensor, cfg: MetaStepConfig,
               backend=None, n_s=None, n_q=None, distributed: bool = False, fit_events=None, check: bool = False):
     """One outer step.  ``features_fn()`` runs the feature extractor on this rank's tasks and returns
-    ``(Z_s [T,N,d], Z_q [T,Nq,d])`` attached to ``params``.  Returns per-task per-sample losses
-    ``f_out / N_q`` (fs_mol/utils/adaptive_dkt_utils.py:398)."""
+    ``(Z_s [T,N,d], Z_q [T,Nq,d])`` attached to ``params`` - or, when support and query sets have the same padded
+    size, ONE stacked tensor ``[2,T,N,d]`` (support, query), in which case the library writes both cotangents into
+    one buffer and a single ``backward`` call consumes it without any gather/scatter copies.  Returns per-task
+    per-sample losses ``f_out / N_q`` (fs_mol/utils/adaptive_dkt_utils.py:398)."""
     backend = backend or HipGPBackend()
     if optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
-    Z_s, Z_q = features_fn()
+    feats = features_fn()
+    stacked = isinstance(feats, torch.Tensor)
+    if stacked:
+        Z_s, Z_q = feats[0], feats[1]
+    else:
+        Z_s, Z_q = feats
     T_local = Z_s.shape[0]
     world = dist.get_world_size() if distributed else 1
     # a3/a4 fresh GP parameters from the detached support features (adaptive_dkt.py:178-179), a7 inner fit,
     # a9 hypergradient at the feature level
+    kw = {}
+    if stacked and feats.dtype == torch.float32 and feats.is_contiguous():
+        dZ_all = torch.empty_like(feats)
+        kw["out_dZ"] = (dZ_all[0], dZ_all[1])
     phi, f_out, dZ_s, dZ_q, info_fit, info = backend.run(Z_s.detach(), y_s, Z_q.detach(), y_q, cfg, n_s=n_s, n_q=n_q,
-                                                         fit_events=fit_events)
+                                                         fit_events=fit_events, **kw)
     if check:
         from . import gp_ops
         gp_ops.check_info(info_fit, "inner fit")
         gp_ops.check_info(info, "IFT hypergradient")
     # one backward through the feature extractor; task-mean over the GLOBAL meta-batch (adaptive_dkt_utils.py:402-407)
     scale = 1.0 / float(T_local * world)
-    torch.autograd.backward([Z_s, Z_q], [dZ_s.to(Z_s.dtype), dZ_q.to(Z_q.dtype)])
+    if "out_dZ" in kw:
+        feats.backward(dZ_all)
+    else:
+        torch.autograd.backward([Z_s, Z_q], [dZ_s.to(Z_s.dtype), dZ_q.to(Z_q.dtype)])
     if distributed and world > 1:
         allreduce_flat_grads(params)
     for p in params:  # the task-mean: scaling |theta| numbers once is cheaper than scaling both dZ tensors

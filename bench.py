@@ -48,7 +48,7 @@ def main():
 
     import __graft_entry__ as ge
     from adkf_ift_amd import gp_ops, roofline
-    from adkf_ift_amd.synthetic import make_tasks
+    from adkf_ift_amd.synthetic import LinearFeatureMap, make_tasks
     from adkf_ift_amd.trainer import MetaStepConfig, meta_step
 
     rank = int(os.environ.get("RANK", "0"))
@@ -77,15 +77,7 @@ def main():
                          inner_exact_evals=not args.converge, clip_value=1.0)
     inv_sqrt_d = 1.0 / math.sqrt(d)
 
-    if N == Nq:  # one GEMM for support and query rows (the stand-in feature extractor runs once per meta-batch)
-        X_all = torch.stack([X_s, X_q]).contiguous()
-
-        def features():
-            Z_all = torch.matmul(X_all, W * inv_sqrt_d)
-            return Z_all[0], Z_all[1]
-    else:
-        def features():
-            return (X_s @ W) * inv_sqrt_d, (X_q @ W) * inv_sqrt_d
+    features = LinearFeatureMap(X_s, X_q, W)  # one GEMM for support+query rows; chunked-bmm backward
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b_ in ev:  # create the underlying hipEvents
@@ -117,7 +109,8 @@ def main():
     if rank == 0 and not args.no_parity:
         from oracle import gp_oracle as O
         with torch.no_grad():
-            Zs, Zq = features()
+            Zall = features()
+            Zs, Zq = Zall[0], Zall[1]
         phi0, pri, _ = gp_ops.init_params(Zs)
         b = gp_ops.GPBatch(Zs, y_s, pri, args.kernel, Z_q=Zq, y_q=y_q)
         phi_f, f_in, gn, nev, info = gp_ops.fit(b, phi0, cfg.inner_max_evals, exact_evals=cfg.inner_exact_evals)

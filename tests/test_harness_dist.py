@@ -23,7 +23,7 @@ class OracleBackend:
     def __init__(self, kind):
         self.kind = kind
 
-    def run(self, Z_s, y_s, Z_q, y_q, cfg, n_s=None, n_q=None, fit_events=None):
+    def run(self, Z_s, y_s, Z_q, y_q, cfg, n_s=None, n_q=None, fit_events=None, out_dZ=None):
         phis, f, ds, dq = [], [], [], []
         for t in range(Z_s.shape[0]):
             phi0, pri = O.init_phi(Z_s[t].double(), cfg.use_numeric_labels, cfg.use_lengthscale_prior)
