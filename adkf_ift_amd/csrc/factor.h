@@ -28,6 +28,14 @@
 //     (vector slots are triple-buffered so the old vectors are still there).
 #pragma once
 #include <limits.h>
+#ifndef ADKF_STAMP
+#define ADKF_STAMP 0  // diagnostic build only (tools/sweep_bench.hip): s_memtime stamps of one block step into sm.stamp[]
+#endif
+#if ADKF_STAMP
+#define ADKF_TS(slot) do { if (q_stamp == ADKF_STAMP && (threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); sm.stamp[(threadIdx.x >> 6) * 16 + (slot)] = t_; } } while (0)
+#else
+#define ADKF_TS(slot) do {} while (0)
+#endif
 #ifndef ADKF_ABLATE
 #define ADKF_ABLATE 0  // timing-only ablation switches for tools/sweep_bench.hip (1: no inverse, 2: no readlane, 4: no F, 8: no deferral)
 #endif
@@ -37,7 +45,11 @@
 namespace adkf {
 
 template <int NMAX, int NT> struct SweepCfg;
-template <> struct SweepCfg<128, 512> { static constexpr int RB = 8, CB = 4; };
+#ifndef ADKF_CFG128_RB
+#define ADKF_CFG128_RB 8
+#define ADKF_CFG128_CB 4
+#endif
+template <> struct SweepCfg<128, 512> { static constexpr int RB = ADKF_CFG128_RB, CB = ADKF_CFG128_CB; };
 template <> struct SweepCfg<64, 256> { static constexpr int RB = 4, CB = 4; };
 template <> struct SweepCfg<32, 256> { static constexpr int RB = 2, CB = 2; };
 template <> struct SweepCfg<16, 256> { static constexpr int RB = 1, CB = 1; };
@@ -52,6 +64,9 @@ struct SweepSmem {
     alignas(16) float vec_out[NMAX];      // A^-1 * vec_in
     float red[8 * (NT / 64)];
     int redi[NT / 64];
+#if ADKF_STAMP
+    unsigned long long stamp[(NT / 64) * 16];
+#endif
 };
 
 __device__ __forceinline__ float fast_rcp(float p) {
@@ -64,7 +79,11 @@ __device__ __forceinline__ float fast_rcp(float p) {
 // closed-form 2 x 2 inverses and one Schur complement - two dependent reciprocals instead of four.
 __device__ __forceinline__ void inv2(float a, float b, float c, float& ia, float& ib, float& ic, float& det) {
     det = fmaf(a, c, -b * b);
+#ifdef ADKF_RAW_RCP
+    const float r = __builtin_amdgcn_rcpf(det);
+#else
     const float r = fast_rcp(det);
+#endif
     ia = c * r; ib = -b * r; ic = a * r;
 }
 template <int B> struct InvSpd;
@@ -113,7 +132,7 @@ struct Sweep {
     static constexpr int NW = NT / 64;         // waves
     static constexpr int BPW = 64 / NBC;       // physical block rows per wave
     static_assert(NBC * NBR == NT, "one block per thread");
-    static_assert(NBC <= 32 && 64 % NBC == 0, "a row of blocks must sit inside a 32-lane half wave (shuffle reduction)");
+    static_assert(NBC <= 64 && 64 % NBC == 0, "a row of blocks must sit inside one wave (shuffle reduction, pivot broadcast)");
     static_assert(RB % CB == 0, "CB must divide RB");
     static_assert(NBR == NW * BPW, "block rows must tile the waves");
 
@@ -134,6 +153,7 @@ struct Sweep {
     __device__ static __forceinline__ void publish(float (&m)[RB][CB], int bl, int slot, SweepSmem<NMAX, NT>& sm) {
         constexpr int RO = GI * CB;
         const int q = GI * NBR + bl;
+        const int q_stamp = q - 1; (void)q_stamp;
         const int plane = ((bl / NW) * NBC + q) & 63;  // lane, in the owning wave, of the thread (bl, bc = q) that holds D
         float D[B][B];
 #pragma unroll
@@ -142,11 +162,16 @@ struct Sweep {
             for (int b = 0; b <= a; ++b) {
 #if ADKF_ABLATE & 2
                 D[a][b] = m[RO + a][b] + (a == b ? 1.f : 0.f);
-#else
+#elif ADKF_ABLATE & 128
                 D[a][b] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m[RO + a][b]), plane));
+#else
+                // ds_bpermute: the ten transfers pipeline through the LDS crossbar behind one wait; ten v_readlane
+                // (SGPR round trips with their hazard waits) measured ~390 cycles on this critical path
+                D[a][b] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(plane << 2, __builtin_bit_cast(int, m[RO + a][b])));
 #endif
                 D[b][a] = D[a][b];
             }
+        ADKF_TS(3);
         if (br() == bl) {
             const int j0 = bc() * CB;
             float C[B][CB], F[B][CB], piv[B];
@@ -161,11 +186,16 @@ struct Sweep {
                     m[RO + a][a] -= 2.f;
                 }
             }
+#pragma unroll
+            for (int a = 0; a < B; ++a)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) sm.cross[slot][a][j0 + c] = C[a][c];  // C is final: its stores fly under the inverse
 #if ADKF_ABLATE & 1
             for (int a = 0; a < B; ++a) piv[a] = D[a][a];
 #else
             InvSpd<B>::run(D, piv);
 #endif
+            ADKF_TS(4);
             if (bc() == q) {
 #pragma unroll
                 for (int a = 0; a < B; ++a) sm.pivs[q * B + a] = piv[a];
@@ -187,12 +217,8 @@ struct Sweep {
             for (int a = 0; a < B; ++a)
 #pragma unroll
                 for (int c = 0; c < CB; ++c) {
-#if ADKF_ABLATE & 16
-                    if (C[a][c] == 123.456f) sm.cross[slot][a][j0 + c] = F[a][c];
-#else
-                    sm.cross[slot][a][j0 + c] = C[a][c];
                     sm.fvec[slot][a][j0 + c] = F[a][c];
-#endif
+            ADKF_TS(6);
                 }
         }
     }
@@ -226,6 +252,33 @@ struct Sweep {
         update_rows<0, RB>(m, fi, cj);
     }
 
+    // The critical path of one block step, run by the wave that owns the NEXT pivot block qn = NGI * NBR + nbl:
+    // fetch only what the chain needs from step q's vectors (C for its columns, F for the next pivot rows), bring
+    // those rows up to date, invert and publish - all at raised priority.  The rest of this wave's step-q update
+    // happens one step later (see phase()).
+    template <int NGI>
+    __device__ static __forceinline__ void chain(float (&m)[RB][CB], int nbl, int q, SweepSmem<NMAX, NT>& sm) {
+        constexpr int N0 = NGI * CB, N1 = NGI * CB + CB;
+        const int q_stamp = q; (void)q_stamp;
+        ADKF_TS(0);
+        if (!(ADKF_ABLATE & 32)) __builtin_amdgcn_s_setprio(3);
+        const int j0 = bc() * CB, slot = q % 3;
+        float fi[B][RB], cj[B][CB];
+#pragma unroll
+        for (int a = 0; a < B; ++a) {
+#pragma unroll
+            for (int r = N0; r < N1; ++r) fi[a][r] = sm.fvec[slot][a][row(r)];
+#pragma unroll
+            for (int c = 0; c < CB; ++c) cj[a][c] = sm.cross[slot][a][j0 + c];
+        }
+        ADKF_TS(1);
+        update_rows<N0, N1>(m, fi, cj);
+        ADKF_TS(2);
+        publish<NGI>(m, nbl, (q + 1) % 3, sm);
+        ADKF_TS(7);
+        __builtin_amdgcn_s_setprio(0);
+    }
+
     // All block steps whose pivot rows are local row group GI.
     template <int GI>
     __device__ static __forceinline__ void phase(float (&m)[RB][CB], int nq, SweepSmem<NMAX, NT>& sm) {
@@ -235,44 +288,32 @@ struct Sweep {
                 const int q = GI * NBR + bl;
                 if (q >= nq) break;
                 __syncthreads();
-                float fi[B][RB], cj[B][CB];
-                if (!(ADKF_ABLATE & 8) && q > 0 && wave == owner_wave(bl)) {
-                    // this wave ran the chain for block q during the previous step and postponed the rest of that
-                    // step's update (everything but its pivot rows GI*CB..): do it now, off the critical path
-                    load_vectors((q + 2) % 3, sm, fi, cj);  // slot of step q - 1
-                    update_rows<0, GI * CB>(m, fi, cj);
-                    update_rows<GI * CB + CB, RB>(m, fi, cj);
-                }
-                if (!(ADKF_ABLATE & 64) || wave == owner_wave(bl + 1)) load_vectors(q % 3, sm, fi, cj);
-                const bool has_next = q + 1 < nq;
-                if (bl + 1 < NBR) {
-                    if (has_next && wave == owner_wave(bl + 1)) {
-                        update_rows<GI * CB, GI * CB + CB>(m, fi, cj);
-                        if (!(ADKF_ABLATE & 32)) __builtin_amdgcn_s_setprio(3);
-                        publish<GI>(m, bl + 1, (q + 1) % 3, sm);
-                        __builtin_amdgcn_s_setprio(0);
-                        if (ADKF_ABLATE & 8) { update_rows<0, GI * CB>(m, fi, cj); update_rows<GI * CB + CB, RB>(m, fi, cj); }
-                    } else {
-                        if (!(ADKF_ABLATE & 64)) update_rows<0, RB>(m, fi, cj);
-                    }
+                const bool last_of_group = bl + 1 == NBR;
+                const bool has_next = q + 1 < nq && (!last_of_group || GI + 1 < G);
+                if (has_next && wave == owner_wave(last_of_group ? 0 : bl + 1)) {
+                    if (!last_of_group) chain<GI>(m, bl + 1, q, sm);
+                    else if constexpr (GI + 1 < G) chain<GI + 1>(m, 0, q, sm);
                 } else {
-                    if constexpr (GI + 1 < G) {
-                        if (has_next && wave == owner_wave(0)) {
-                            update_rows<(GI + 1) * CB, (GI + 1) * CB + CB>(m, fi, cj);
-                            if (!(ADKF_ABLATE & 32)) __builtin_amdgcn_s_setprio(3);
-                            publish<GI + 1>(m, 0, (q + 1) % 3, sm);
-                            __builtin_amdgcn_s_setprio(0);
-                        } else {
-                            update_rows<0, RB>(m, fi, cj);
-                        }
-                    } else {
-                        update_rows<0, RB>(m, fi, cj);
+                    const int q_stamp = q; (void)q_stamp;
+                    ADKF_TS(0);
+#ifdef ADKF_BULK_SLEEP
+                    __builtin_amdgcn_s_sleep(ADKF_BULK_SLEEP);  // let the chain owner's LDS reads and issue slots go first
+#endif
+                    float fi[B][RB], cj[B][CB];
+                    if (q > 0 && wave == owner_wave(bl)) {
+                        // this wave ran the chain for block q during the previous step and postponed the rest of that
+                        // step's update (everything but its pivot rows GI*CB..): do it now, off the critical path
+                        load_vectors((q + 2) % 3, sm, fi, cj);  // slot of step q - 1
+                        update_rows<0, GI * CB>(m, fi, cj);
+                        update_rows<GI * CB + CB, RB>(m, fi, cj);
                     }
+                    ADKF_TS(8);
+                    load_vectors(q % 3, sm, fi, cj);
+                    ADKF_TS(9);
+                    update_rows<0, RB>(m, fi, cj);
+                    ADKF_TS(10);
                 }
             }
-            // the postponed part of the LAST step of this phase, if its chain ran in the previous step of this phase,
-            // is picked up by the first step of the next phase (same code path: q > 0 && owner); after the final
-            // phase nothing is pending because the last block step has no successor to publish.
             phase<GI + 1>(m, nq, sm);
         }
     }

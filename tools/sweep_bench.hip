@@ -31,6 +31,9 @@ __global__ __launch_bounds__(NT) void k_sweep(const float* A, float* out, int n,
         acc += m[0][0];
     }
     if (threadIdx.x == 0) out[blockIdx.x] = acc + m[1][1];
+#if ADKF_STAMP
+    if (blockIdx.x == 3 && threadIdx.x < 128 && VAR == 0) ((unsigned long long*)(out + 1024))[threadIdx.x] = sm.stamp[threadIdx.x];
+#endif
 }
 
 template <int VAR>
@@ -51,8 +54,17 @@ int main(int argc, char** argv) {
     for (int t = 0; t < T; ++t) for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
         float d = (float)(i - j); A[((size_t)t * n + i) * n + j] = 0.7f * expf(-d * d / 50.f) + (i == j ? 0.1f : 0.f);
     }
-    float *dA, *dout; hipMalloc(&dA, A.size() * 4); hipMalloc(&dout, T * 4);
+    float *dA, *dout; hipMalloc(&dA, A.size() * 4); hipMalloc(&dout, (T + 2048) * 4); hipMemset(dout, 0, (T + 2048) * 4);
     hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
+#if ADKF_STAMP
+    {
+        std::vector<unsigned long long> st(128);
+        k_sweep<128, 512, 0><<<T, 512>>>(dA, dout, n, 1); hipDeviceSynchronize();
+        hipMemcpy(st.data(), dout + 1024, 128 * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull; for (int w = 0; w < 8; ++w) if (st[w * 16] && st[w * 16] < t0) t0 = st[w * 16];
+        for (int w = 0; w < 8; ++w) { printf("wave %d:", w); for (int s_ = 0; s_ < 11; ++s_) printf(" %6lld", st[w * 16 + s_] ? (long long)(st[w * 16 + s_] - t0) : -1ll); printf("\n"); }
+    }
+#endif
     printf("T=%d  us per sweep:  full %.1f | update-only %.1f | barriers-only %.1f\n", T,
            run<0>(dA, dout, T, n, reps), run<1>(dA, dout, T, n, reps), run<3>(dA, dout, T, n, reps));
     return 0;
