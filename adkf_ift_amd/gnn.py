@@ -1,0 +1,359 @@
+"""GNN feature extractor, re-authored for PyTorch-ROCm with native index/scatter ops.
+
+Same function as the reference's ``GraphFeatureExtractor`` (fs_mol/modules/graph_feature_extractor.py:43-98):
+``init_node_proj`` -> ``num_layers`` x ``GNNBlock`` (PNA multi-aggregation relational message passing in
+``num_heads`` "towers", ReZero, BOOM MLP; fs_mol/modules/gnn.py:168-265, 389-515) -> ``CombinedGraphReadout``
+(weighted-mean + weighted-sum + max; fs_mol/modules/graph_readout.py:119-296), default sizes of Appendix B of the
+survey.  What is different is the execution plan, chosen for a GPU that wants few, fat kernels:
+
+* the reference runs ``towers x edge_types`` tiny ``Linear(2*32 -> 3*64)`` modules per block and gathers node states
+  once per tower and edge type; here each edge type gathers the full node state ONCE and all towers go through one
+  batched GEMM (``einsum('ehi,hio->eho')`` on a ``[towers, 2*in, 3*msg]`` weight);
+* everything that depends only on the graph (concatenated targets, in-degrees, PNA scalers, bidirectional edge
+  lists) is computed once per forward, not once per tower per layer;
+* the four first-layer MLPs of the two weighted read-outs are one GEMM over the ``[V, 1408]`` node states;
+* ``torch_scatter`` (not installable here) is replaced by ``index_add_`` / ``scatter_reduce_`` whose empty-segment
+  conventions are made to match (``scatter_max`` / ``scatter_mean`` of an empty segment = 0);
+* any number of tasks is concatenated into ONE disconnected graph (``concat_graph_batches``), so a meta-batch costs
+  one forward and one backward of the extractor instead of >= 3 + (h+1) per task.
+
+``mp_norm_layer`` exists in the reference block but is never applied in its forward (gnn.py:477-515); it is kept as
+an (unused) submodule only so that reference checkpoints map one-to-one (``load_reference_state_dict``).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+SMALL_NUMBER = 1e-7
+NUM_NODE_FEATURES = 32   # fs_mol/data/fsmol_dataset.py:21
+NUM_EDGE_TYPES = 3       # fs_mol/data/fsmol_dataset.py:22
+PNA_DELTA = 1.1515       # fs_mol/modules/gnn.py:237
+
+
+@dataclass
+class GNNConfig:
+    """CLI defaults of the reference (fs_mol/modules/gnn.py:31-63), not its dataclass defaults."""
+
+    type: str = "PNA"
+    num_edge_types: int = NUM_EDGE_TYPES
+    hidden_dim: int = 128
+    num_heads: int = 4
+    per_head_dim: int = 64
+    intermediate_dim: int = 1024
+    message_function_depth: int = 1
+    num_layers: int = 10
+    dropout_rate: float = 0.0
+    use_rezero_scaling: bool = True
+    make_edges_bidirectional: bool = True
+
+
+@dataclass
+class GraphReadoutConfig:
+    readout_type: str = "combined"
+    use_all_states: bool = True
+    num_heads: int = 12
+    head_dim: int = 64
+    output_dim: int = 512
+
+
+@dataclass
+class GraphFeatureExtractorConfig:
+    initial_node_feature_dim: int = NUM_NODE_FEATURES
+    gnn_config: GNNConfig = field(default_factory=GNNConfig)
+    readout_config: GraphReadoutConfig = field(default_factory=GraphReadoutConfig)
+    output_norm: str = "off"
+
+
+@dataclass
+class GraphBatch:
+    """The fields of ``FSMolBatch`` (fs_mol/data/fsmol_batcher.py:22-54) the extractor reads, as torch tensors."""
+
+    node_features: torch.Tensor            # [V, F] float
+    adjacency_lists: List[torch.Tensor]    # num_edge_types x [E_t, 2] int64 (src, tgt)
+    node_to_graph: torch.Tensor            # [V] int64
+    num_graphs: int
+
+    def to(self, device):
+        return GraphBatch(self.node_features.to(device), [a.to(device) for a in self.adjacency_lists],
+                          self.node_to_graph.to(device), self.num_graphs)
+
+
+def concat_graph_batches(batches: Sequence[GraphBatch]) -> GraphBatch:
+    """Many disconnected-graph batches -> one (node and graph ids renumbered)."""
+    nodes, n2g, adj = [], [], [[] for _ in batches[0].adjacency_lists]
+    v0 = g0 = 0
+    for b in batches:
+        nodes.append(b.node_features)
+        n2g.append(b.node_to_graph + g0)
+        for t, a in enumerate(b.adjacency_lists):
+            adj[t].append(a + v0)
+        v0 += b.node_features.shape[0]
+        g0 += b.num_graphs
+    return GraphBatch(torch.cat(nodes), [torch.cat(a) for a in adj], torch.cat(n2g), g0)
+
+
+class _GraphPlan:
+    """Per-forward graph constants shared by all layers and towers."""
+
+    def __init__(self, adjacency_lists: List[torch.Tensor], num_nodes: int, bidirectional: bool, pna: bool,
+                 dtype: torch.dtype = torch.float32):
+        if bidirectional:  # fs_mol/modules/gnn.py:540-544
+            adjacency_lists = [torch.cat((a, a.flip(1)), dim=0) for a in adjacency_lists]
+        self.srcs = [a[:, 0] for a in adjacency_lists]
+        self.tgts = [a[:, 1] for a in adjacency_lists]
+        self.all_tgts = torch.cat(self.tgts) if self.tgts else torch.zeros(0, dtype=torch.long)
+        self.num_nodes = num_nodes
+        deg = torch.bincount(self.all_tgts, minlength=num_nodes).to(dtype)
+        self.inv_count = 1.0 / deg.clamp(min=1.0)                      # scatter_mean: empty segment -> 0
+        if pna:
+            log_deg = torch.log(deg + 1.0)
+            self.amplify = (log_deg / PNA_DELTA).unsqueeze(-1)                      # gnn.py:241
+            self.attenuate = (PNA_DELTA / (log_deg + SMALL_NUMBER)).unsqueeze(-1)   # gnn.py:242
+
+
+class TowerMessagePassing(nn.Module):
+    """All ``num_heads`` towers of one block at once: relational message functions per edge type
+    (fs_mol/modules/gnn.py:95-148) and PNA / multi-aggregation / plain aggregation (:150-265)."""
+
+    def __init__(self, config: GNNConfig):
+        super().__init__()
+        self.kind = config.type.lower()
+        if self.kind not in ("pna", "multiaggr", "plain"):
+            raise ValueError(f"Unknown GNN type {config.type}.")  # MultiHeadAttention: other ablation, out of scope
+        H, self.in_dim = config.num_heads, config.hidden_dim // config.num_heads
+        assert config.hidden_dim % config.num_heads == 0, "Number of heads needs to divide GNN hidden dim."
+        self.H, self.msg = H, config.per_head_dim
+        self.out_msg = (3 if self.kind != "plain" else 1) * self.msg
+        dims = [2 * self.in_dim] * config.message_function_depth + [self.out_msg]
+        self.weights = nn.ParameterList()   # [edge_type][layer] -> [H, in, out]
+        self.biases = nn.ParameterList()
+        self.depth = config.message_function_depth
+        for _ in range(config.num_edge_types):
+            for l in range(self.depth):
+                w = torch.empty(H, dims[l], dims[l + 1])
+                b = torch.empty(H, dims[l + 1])
+                for h in range(H):  # nn.Linear's default init, per tower
+                    nn.init.kaiming_uniform_(w[h].t(), a=math.sqrt(5))
+                    bound = 1.0 / math.sqrt(dims[l])
+                    nn.init.uniform_(b[h], -bound, bound)
+                self.weights.append(nn.Parameter(w))
+                self.biases.append(nn.Parameter(b))
+
+    @property
+    def message_size(self) -> int:
+        per_tower = {"plain": self.msg, "multiaggr": 4 * self.msg, "pna": 12 * self.msg}[self.kind]
+        return self.H * per_tower
+
+    def forward(self, x: torch.Tensor, plan: _GraphPlan) -> torch.Tensor:
+        V, H, m = x.shape[0], self.H, self.msg
+        xt = x.view(V, H, self.in_dim)
+        msgs = []
+        for et in range(len(plan.srcs)):
+            h = torch.cat((xt[plan.srcs[et]], xt[plan.tgts[et]]), dim=2)       # [E, H, 2 in]
+            for l in range(self.depth):
+                k = et * self.depth + l
+                h = torch.einsum("ehi,hio->eho", h, self.weights[k]) + self.biases[k]
+                if l + 1 < self.depth:
+                    h = F.relu(h)
+            msgs.append(F.relu(h))                                             # gnn.py:141
+        msgs = torch.cat(msgs, dim=0)                                          # [E_all, H, out_msg]
+        tg = plan.all_tgts
+        if self.kind == "plain":
+            return x.new_zeros(V, H, m).index_add_(0, tg, msgs).reshape(V, -1)
+        s_sum = x.new_zeros(V, H, m).index_add_(0, tg, msgs[..., :m])
+        mean_msgs = msgs[..., m:2 * m]
+        s_mean = x.new_zeros(V, H, m).index_add_(0, tg, mean_msgs) * plan.inv_count.view(V, 1, 1).to(x.dtype)
+        dev = F.relu(mean_msgs.pow(2) - s_mean[tg].pow(2)) + SMALL_NUMBER      # gnn.py:213-216
+        s_std = torch.sqrt(x.new_zeros(V, H, m).index_add_(0, tg, dev))
+        idx = tg.view(-1, 1, 1).expand(-1, H, m)
+        s_max = x.new_zeros(V, H, m).scatter_reduce_(0, idx, msgs[..., 2 * m:3 * m], reduce="amax", include_self=False)
+        agg = torch.cat((s_sum, s_mean, s_std, s_max), dim=2)                  # [V, H, 4m], tower-major like the reference cat
+        if self.kind == "pna":
+            amp, att = plan.amplify.unsqueeze(-1).to(x.dtype), plan.attenuate.unsqueeze(-1).to(x.dtype)
+            agg = torch.cat((agg, amp * agg, att * agg), dim=2)                # gnn.py:244-251
+        return agg.reshape(V, -1)
+
+
+class BOOMLayer(nn.Module):
+    def __init__(self, inout_dim: int, intermediate_dim: int, dropout: float):
+        super().__init__()
+        self.linear1 = nn.Linear(inout_dim, intermediate_dim)
+        self.linear2 = nn.Linear(intermediate_dim, inout_dim)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        return self.linear2(self.dropout(F.leaky_relu(self.linear1(x))))
+
+
+class GNNBlock(nn.Module):
+    """v' = v + alpha * MsgOut(MP(v));  v = v' + alpha * BOOM(LN(v'))   (fs_mol/modules/gnn.py:477-515)."""
+
+    def __init__(self, config: GNNConfig):
+        super().__init__()
+        self.config = config
+        if config.use_rezero_scaling:
+            self.alpha = nn.Parameter(torch.full((1,), SMALL_NUMBER))
+        self.mp = TowerMessagePassing(config)
+        self.msg_out_projection = nn.Linear(self.mp.message_size, config.hidden_dim)
+        self.mp_norm_layer = nn.LayerNorm(config.hidden_dim)  # present, never applied - exactly like the reference
+        if config.intermediate_dim > 0:
+            self.boom_layer: Optional[BOOMLayer] = BOOMLayer(config.hidden_dim, config.intermediate_dim, config.dropout_rate)
+            self.boom_norm_layer: Optional[nn.Module] = nn.LayerNorm(config.hidden_dim)
+        else:
+            self.boom_layer = self.boom_norm_layer = None
+        self.dropout_layer = nn.Dropout(config.dropout_rate)
+
+    def forward(self, x: torch.Tensor, plan: _GraphPlan) -> torch.Tensor:
+        new = self.dropout_layer(self.msg_out_projection(self.mp(x, plan)))
+        if self.config.use_rezero_scaling:
+            new = self.alpha * new
+        x = x + new
+        if self.boom_layer is not None:
+            boomed = self.dropout_layer(self.boom_layer(self.boom_norm_layer(x)))
+            if self.config.use_rezero_scaling:
+                boomed = self.alpha * boomed
+            x = x + boomed
+        return x
+
+
+class GNN(nn.Module):
+    def __init__(self, config: GNNConfig):
+        super().__init__()
+        self.config = config
+        self.gnn_blocks = nn.ModuleList(GNNBlock(config) for _ in range(config.num_layers))
+
+    def forward(self, node_features: torch.Tensor, adj_lists: List[torch.Tensor]) -> List[torch.Tensor]:
+        plan = _GraphPlan(adj_lists, node_features.shape[0], self.config.make_edges_bidirectional,
+                          self.config.type.lower() == "pna", node_features.dtype)
+        cur, states = node_features, [node_features]
+        for blk in self.gnn_blocks:
+            cur = blk(cur, plan)
+            states.append(cur)
+        return states
+
+
+def _segment_softmax(scores: torch.Tensor, index: torch.Tensor, num_segments: int) -> torch.Tensor:
+    """torch_scatter.scatter_softmax(scores, index, dim=0) (graph_readout.py:238)."""
+    idx = index.view(-1, 1).expand_as(scores)
+    mx = scores.new_full((num_segments, scores.shape[1]), float("-inf")).scatter_reduce_(0, idx, scores, reduce="amax", include_self=True)
+    ex = torch.exp(scores - mx[index])
+    den = scores.new_zeros(num_segments, scores.shape[1]).index_add_(0, index, ex)
+    return ex / den[index]
+
+
+class CombinedGraphReadout(nn.Module):
+    """weighted-mean + weighted-sum (multi-head) + max pooling, then Linear(ReLU(cat))  (graph_readout.py:119-296).
+    The two scoring MLPs and two value MLPs share their input, so their first layers run as one GEMM."""
+
+    def __init__(self, node_dim: int, out_dim: int, num_heads: int, head_dim: int):
+        super().__init__()
+        self.nh, self.hd = num_heads, head_dim
+        hid = num_heads * head_dim
+        self.first = nn.Linear(node_dim, 4 * hid)            # [mean.score | mean.value | sum.score | sum.value] hidden layers
+        self.mean_score_out = nn.Linear(hid, num_heads)
+        self.mean_value_out = nn.Linear(hid, hid)
+        self.sum_score_out = nn.Linear(hid, num_heads)
+        self.sum_value_out = nn.Linear(hid, hid)
+        self.mean_combination = nn.Linear(hid, out_dim, bias=False)
+        self.sum_combination = nn.Linear(hid, out_dim, bias=False)
+        self.max_combination = nn.Linear(node_dim, out_dim, bias=False)
+        self.combination_layer = nn.Linear(3 * out_dim, out_dim, bias=False)
+
+    def forward(self, node_embeddings: torch.Tensor, node_to_graph_id: torch.Tensor, num_graphs: int) -> torch.Tensor:
+        V, hid = node_embeddings.shape[0], self.nh * self.hd
+        h = F.relu(self.first(node_embeddings))
+        h_ms, h_mv, h_ss, h_sv = h.split(hid, dim=1)
+        w_mean = _segment_softmax(self.mean_score_out(h_ms), node_to_graph_id, num_graphs)      # [V, heads]
+        w_sum = torch.sigmoid(self.sum_score_out(h_ss))
+        v_mean = self.mean_value_out(h_mv).view(V, self.nh, self.hd)
+        v_sum = self.sum_value_out(h_sv).view(V, self.nh, self.hd)
+        zeros = node_embeddings.new_zeros(num_graphs, hid)
+        g_mean = zeros.index_add(0, node_to_graph_id, (w_mean.unsqueeze(-1) * v_mean).reshape(V, hid))
+        g_sum = zeros.index_add(0, node_to_graph_id, (w_sum.unsqueeze(-1) * v_sum).reshape(V, hid))
+        idx = node_to_graph_id.view(-1, 1).expand_as(node_embeddings)
+        g_max = node_embeddings.new_zeros(num_graphs, node_embeddings.shape[1]).scatter_reduce_(
+            0, idx, node_embeddings, reduce="amax", include_self=False)
+        raw = torch.cat((self.mean_combination(g_mean), self.sum_combination(g_sum), self.max_combination(g_max)), dim=1)
+        return self.combination_layer(F.relu(raw))
+
+
+class GraphFeatureExtractor(nn.Module):
+    def __init__(self, config: GraphFeatureExtractorConfig):
+        super().__init__()
+        self.config = config
+        g, r = config.gnn_config, config.readout_config
+        self.init_node_proj = nn.Linear(config.initial_node_feature_dim, g.hidden_dim, bias=False)
+        self.gnn = GNN(g)
+        node_dim = (g.num_layers + 1) * g.hidden_dim if r.use_all_states else g.hidden_dim
+        if not r.readout_type.startswith("combined"):
+            raise ValueError("only the reference's default 'combined' read-out is built")
+        self.readout = CombinedGraphReadout(node_dim, r.output_dim, r.num_heads, r.head_dim)
+        if config.output_norm == "off":
+            self.final_norm_layer: Optional[nn.Module] = None
+        elif config.output_norm == "layer":
+            self.final_norm_layer = nn.LayerNorm(r.output_dim)
+        elif config.output_norm == "batch":
+            self.final_norm_layer = nn.BatchNorm1d(r.output_dim)
+        else:
+            raise ValueError(config.output_norm)
+
+    def forward(self, batch) -> torch.Tensor:
+        """``batch`` = anything with node_features, adjacency_lists, node_to_graph, num_graphs (FSMolBatch layout)."""
+        states = self.gnn(self.init_node_proj(batch.node_features), list(batch.adjacency_lists))
+        node_repr = torch.cat(states, dim=-1) if self.config.readout_config.use_all_states else states[-1]
+        out = self.readout(node_repr, batch.node_to_graph, batch.num_graphs)
+        if self.final_norm_layer is not None:
+            out = self.final_norm_layer(out)
+        return out
+
+    # ---- checkpoint compatibility ------------------------------------------------------------
+    def load_reference_state_dict(self, ref: Dict[str, torch.Tensor], prefix: str = "graph_feature_extractor.") -> None:
+        """Maps a state dict with the reference's parameter names (per-tower, per-edge-type ``nn.Linear``s; separate
+        read-out MLPs) onto the fused parameters of this module."""
+        g = self.config.gnn_config
+        get = lambda k: ref[prefix + k]
+        own = {"init_node_proj.weight": get("init_node_proj.weight")}
+        for b in range(g.num_layers):
+            p = f"gnn.gnn_blocks.{b}."
+            if g.use_rezero_scaling:
+                own[p + "alpha"] = get(p + "alpha")
+            for et in range(g.num_edge_types):
+                for l in range(g.message_function_depth):
+                    k = et * g.message_function_depth + l
+                    ws = [get(f"{p}mp_layers.{h}.message_fns.{et}._layers.{2 * l}.weight").t() for h in range(g.num_heads)]
+                    bs = [get(f"{p}mp_layers.{h}.message_fns.{et}._layers.{2 * l}.bias") for h in range(g.num_heads)]
+                    own[f"{p}mp.weights.{k}"] = torch.stack(ws)
+                    own[f"{p}mp.biases.{k}"] = torch.stack(bs)
+            for name in ("msg_out_projection.weight", "msg_out_projection.bias", "mp_norm_layer.weight", "mp_norm_layer.bias"):
+                own[p + name] = get(p + name)
+            if g.intermediate_dim > 0:
+                for name in ("boom_layer.linear1.weight", "boom_layer.linear1.bias", "boom_layer.linear2.weight",
+                             "boom_layer.linear2.bias", "boom_norm_layer.weight", "boom_norm_layer.bias"):
+                    own[p + name] = get(p + name)
+        r = "readout."
+        firsts_w, firsts_b = [], []
+        for pool, tag in (("_weighted_mean_pooler", "mean"), ("_weighted_sum_pooler", "sum")):
+            for mlp, kind in (("_scoring_module", "score"), ("_transformation_mlp", "value")):
+                firsts_w.append(get(f"{r}{pool}.{mlp}._layers.0.weight"))
+                firsts_b.append(get(f"{r}{pool}.{mlp}._layers.0.bias"))
+                own[f"{r}{tag}_{kind}_out.weight"] = get(f"{r}{pool}.{mlp}._layers.2.weight")
+                own[f"{r}{tag}_{kind}_out.bias"] = get(f"{r}{pool}.{mlp}._layers.2.bias")
+            own[f"{r}{tag}_combination.weight"] = get(f"{r}{pool}._combination_layer.weight")
+        own[r + "first.weight"] = torch.cat(firsts_w)
+        own[r + "first.bias"] = torch.cat(firsts_b)
+        own[r + "max_combination.weight"] = get(r + "_max_pooler._combination_layer.weight")
+        own[r + "combination_layer.weight"] = get(r + "_combination_layer.weight")
+        for k in ("final_norm_layer.weight", "final_norm_layer.bias"):
+            if prefix + k in ref:
+                own[k] = get(k)
+        missing, unexpected = self.load_state_dict(own, strict=False)
+        unexpected = [k for k in unexpected]
+        missing = [k for k in missing if "num_batches_tracked" not in k and "running_" not in k]
+        if missing or unexpected:
+            raise KeyError(f"reference checkpoint does not match: missing {missing}, unexpected {unexpected}")
