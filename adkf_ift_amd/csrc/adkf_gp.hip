@@ -10,7 +10,7 @@ using namespace adkf;
 
 namespace {
 
-constexpr int MAX_POINTS = 128;  // LDS-resident factorisation: two (N x (N+1)) fp32 buffers
+constexpr int MAX_POINTS = 256;  // register-resident sweep: 64 matrix elements per lane at 1024 lanes
 
 inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
@@ -125,7 +125,8 @@ int launch_inner(InnerArgs a, hipStream_t st) {
     if (a.ld <= 16) launch_inner_k<16, 256>(a, st);
     else if (a.ld <= 32) launch_inner_k<32, 256>(a, st);
     else if (a.ld <= 64) launch_inner_k<64, 256>(a, st);
-    else launch_inner_k<128, 512>(a, st);
+    else if (a.ld <= 128) launch_inner_k<128, 512>(a, st);
+    else launch_inner_k<256, 1024>(a, st);
     LAUNCH_OK();
     return 0;
 }
@@ -134,7 +135,8 @@ int launch_outer_factor(const OuterArgs& a, int nq, hipStream_t st) {
     if (nq <= 16) k_outer_factor<16, 256><<<grid_for(a.T, 1), 256, 0, st>>>(a);
     else if (nq <= 32) k_outer_factor<32, 256><<<grid_for(a.T, 1), 256, 0, st>>>(a);
     else if (nq <= 64) k_outer_factor<64, 256><<<grid_for(a.T, 1), 256, 0, st>>>(a);
-    else k_outer_factor<128, 512><<<grid_for(a.T, 1), 512, 0, st>>>(a);
+    else if (nq <= 128) k_outer_factor<128, 512><<<grid_for(a.T, 1), 512, 0, st>>>(a);
+    else k_outer_factor<256, 1024><<<grid_for(a.T, 1), 1024, 0, st>>>(a);
     LAUNCH_OK();
     return 0;
 }
@@ -232,7 +234,8 @@ int adkf_median_lengthscale(const adkf_batch_t* b, float* l0, void* ws, size_t w
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = stage_dist(b, w, has_query(b), st);
     if (rc) return rc;
-    k_median<<<grid_for(b->T, 1), 512, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T);
+    if (b->ns_max <= 128) k_median<512, 32><<<grid_for(b->T, 1), 512, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T);
+    else k_median<1024, 64><<<grid_for(b->T, 1), 1024, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T);
     LAUNCH_OK();
     return 0;
 }

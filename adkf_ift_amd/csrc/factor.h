@@ -50,6 +50,7 @@ template <int NMAX, int NT> struct SweepCfg;
 #define ADKF_CFG128_CB 4
 #endif
 template <> struct SweepCfg<128, 512> { static constexpr int RB = ADKF_CFG128_RB, CB = ADKF_CFG128_CB; };
+template <> struct SweepCfg<256, 1024> { static constexpr int RB = 16, CB = 4; };  // 64 elements per lane, <= 128 VGPRs
 template <> struct SweepCfg<64, 256> { static constexpr int RB = 4, CB = 4; };
 template <> struct SweepCfg<32, 256> { static constexpr int RB = 2, CB = 2; };
 template <> struct SweepCfg<16, 256> { static constexpr int RB = 1, CB = 1; };
@@ -223,33 +224,38 @@ struct Sweep {
         }
     }
 
-    // rank-B update of local rows [R0, R1) of this thread's block from the vectors of one block step
+    // rank-B update of local rows [R0, R1) of this thread's block from the vectors of block step `slot`; the vectors
+    // are fetched one pivot (a) at a time so that at most RB + CB of them are live (RB = 16 in the 256-point config)
     template <int R0, int R1>
-    __device__ static __forceinline__ void update_rows(float (&m)[RB][CB], const float (&fi)[B][RB], const float (&cj)[B][CB]) {
-#pragma unroll
-        for (int a = 0; a < B; ++a)
-#pragma unroll
-            for (int r = R0; r < R1; ++r)
-#pragma unroll
-                for (int c = 0; c < CB; ++c) m[r][c] = fmaf(-fi[a][r], cj[a][c], m[r][c]);
-    }
-
-    __device__ static __forceinline__ void load_vectors(int slot, SweepSmem<NMAX, NT>& sm, float (&fi)[B][RB], float (&cj)[B][CB]) {
+    __device__ static __forceinline__ void apply_pivot(float (&m)[RB][CB], int slot, int a, SweepSmem<NMAX, NT>& sm) {
         const int j0 = bc() * CB;
+        float fi[R1 - R0], cj[CB];
 #pragma unroll
-        for (int a = 0; a < B; ++a) {
+        for (int r = R0; r < R1; ++r) fi[r - R0] = sm.fvec[slot][a][row(r)];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) fi[a][r] = sm.fvec[slot][a][row(r)];
+        for (int c = 0; c < CB; ++c) cj[c] = sm.cross[slot][a][j0 + c];
 #pragma unroll
-            for (int c = 0; c < CB; ++c) cj[a][c] = sm.cross[slot][a][j0 + c];
+        for (int r = R0; r < R1; ++r)
+#pragma unroll
+            for (int c = 0; c < CB; ++c) m[r][c] = fmaf(-fi[r - R0], cj[c], m[r][c]);
+    }
+    template <int R0, int R1>
+    __device__ static __forceinline__ void apply_step(float (&m)[RB][CB], int slot, SweepSmem<NMAX, NT>& sm) {
+        if constexpr (R0 < R1) {
+            if constexpr (RB * CB > 32) {
+                // 64 matrix elements per lane: keep only one pivot's vectors live at a time (128-VGPR budget)
+#pragma unroll 1
+                for (int a = 0; a < B; ++a) apply_pivot<R0, R1>(m, slot, a, sm);
+            } else {
+#pragma unroll
+                for (int a = 0; a < B; ++a) apply_pivot<R0, R1>(m, slot, a, sm);
+            }
         }
     }
 
     // (for the ablation harness tools/sweep_bench.hip)
     __device__ static __forceinline__ void step(float (&m)[RB][CB], int q, SweepSmem<NMAX, NT>& sm) {
-        float fi[B][RB], cj[B][CB];
-        load_vectors(q % 3, sm, fi, cj);
-        update_rows<0, RB>(m, fi, cj);
+        apply_step<0, RB>(m, q % 3, sm);
     }
 
     // The critical path of one block step, run by the wave that owns the NEXT pivot block qn = NGI * NBR + nbl:
@@ -262,17 +268,8 @@ struct Sweep {
         const int q_stamp = q; (void)q_stamp;
         ADKF_TS(0);
         if (!(ADKF_ABLATE & 32)) __builtin_amdgcn_s_setprio(3);
-        const int j0 = bc() * CB, slot = q % 3;
-        float fi[B][RB], cj[B][CB];
-#pragma unroll
-        for (int a = 0; a < B; ++a) {
-#pragma unroll
-            for (int r = N0; r < N1; ++r) fi[a][r] = sm.fvec[slot][a][row(r)];
-#pragma unroll
-            for (int c = 0; c < CB; ++c) cj[a][c] = sm.cross[slot][a][j0 + c];
-        }
         ADKF_TS(1);
-        update_rows<N0, N1>(m, fi, cj);
+        apply_step<N0, N1>(m, q % 3, sm);
         ADKF_TS(2);
         publish<NGI>(m, nbl, (q + 1) % 3, sm);
         ADKF_TS(7);
@@ -299,18 +296,14 @@ struct Sweep {
 #ifdef ADKF_BULK_SLEEP
                     __builtin_amdgcn_s_sleep(ADKF_BULK_SLEEP);  // let the chain owner's LDS reads and issue slots go first
 #endif
-                    float fi[B][RB], cj[B][CB];
                     if (q > 0 && wave == owner_wave(bl)) {
                         // this wave ran the chain for block q during the previous step and postponed the rest of that
                         // step's update (everything but its pivot rows GI*CB..): do it now, off the critical path
-                        load_vectors((q + 2) % 3, sm, fi, cj);  // slot of step q - 1
-                        update_rows<0, GI * CB>(m, fi, cj);
-                        update_rows<GI * CB + CB, RB>(m, fi, cj);
+                        apply_step<0, GI * CB>(m, (q + 2) % 3, sm);  // slot of step q - 1
+                        apply_step<GI * CB + CB, RB>(m, (q + 2) % 3, sm);
                     }
                     ADKF_TS(8);
-                    load_vectors(q % 3, sm, fi, cj);
-                    ADKF_TS(9);
-                    update_rows<0, RB>(m, fi, cj);
+                    apply_step<0, RB>(m, q % 3, sm);
                     ADKF_TS(10);
                 }
             }

@@ -29,14 +29,46 @@ struct InnerArgs {
     float gtol, ftol;
 };
 
+// The squared distances of this thread's block: register-resident for the whole fit (<= 128 points), or re-read
+// from L2 at every evaluation in the 256-point configuration (64 more live registers per lane would not fit the
+// 128-VGPR budget of a 1024-thread workgroup; the re-read is 64 floats per lane against a ~70 us sweep).
+template <int NMAX, int NT, bool REGS>
+struct D2Block {
+    using SW = Sweep<NMAX, NT>;
+    static constexpr int RB = SW::RB, CB = SW::CB;
+    float reg[REGS ? RB : 1][REGS ? CB : 1];
+    const float* base;
+    int ld, n;
+    __device__ __forceinline__ void init(const float* D2, int ld_, int n_) {
+        base = D2; ld = ld_; n = n_;
+        if constexpr (REGS) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) reg[r][c] = fetch(r, c);
+        }
+    }
+    __device__ __forceinline__ float fetch(int r, int c) const {
+        const int i = SW::row(r), j = SW::col(c);
+        const int hi = i > j ? i : j, lo = i > j ? j : i;  // exactly symmetric input to the sweep
+        return (i < n && j < n) ? base[(size_t)hi * ld + lo] : 0.f;
+    }
+    __device__ __forceinline__ float get(int r, int c) const {
+        if constexpr (REGS) return reg[r][c];
+        else return fetch(r, c);
+    }
+};
+
 template <int NMAX, int NT, int KIND>
 struct InnerEval {
+    static constexpr bool D2_REGS = NMAX <= 128;
+    using D2 = D2Block<NMAX, NT, D2_REGS>;
     using SW = Sweep<NMAX, NT>;
     static constexpr int RB = SW::RB, CB = SW::CB;
 
     // One evaluation at raw parameters x.  d2 = this thread's block of squared distances.  On return m = -(A^-1)
     // (this thread's block), sm.vec_out = alpha.  extra (9 floats) receives the scalars later stages reuse.
-    __device__ static __forceinline__ int run(SweepSmem<NMAX, NT>& sm, const float (&d2)[RB][CB], float (&m)[RB][CB], int n,
+    __device__ static __forceinline__ int run(SweepSmem<NMAX, NT>& sm, const D2& d2, float (&m)[RB][CB], int n,
                                               const float* x, const float* pri, float& f, float* g, float* extra,
                                               bool fast) {
         const int j0 = SW::bc() * CB, tid = threadIdx.x;
@@ -49,7 +81,7 @@ struct InnerEval {
             for (int c = 0; c < CB; ++c) {
                 const int i = SW::row(r), j = j0 + c;
                 if (i < n && j < n) {
-                    const float u = d2[r][c] * il2;
+                    const float u = d2.get(r, c) * il2;
                     m[r][c] = os * (fast ? kappa0_t<KIND, true>(u) : kappa0_t<KIND, false>(u)) + (i == j ? noise : 0.f);
                 }
                 else m[r][c] = (i == j) ? 1.f : 0.f;
@@ -72,7 +104,7 @@ struct InnerEval {
                 // dK/dl regenerated from the distances (cheaper than 32 more live registers per lane);
                 // zero outside n x n because d2 is zero there
                 float k0, k1, k2;
-                const float u = d2[r][c] * il2;
+                const float u = d2.get(r, c) * il2;
                 if (fast) kappa3<KIND, true>(u, k0, k1, k2); else kappa3<KIND, false>(u, k0, k1, k2);
                 const float G = os * k1 * u * gl;
                 acc[0] -= m[r][c] * G;
@@ -253,15 +285,9 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
     const float* D2 = a.D2ss + (size_t)t * a.ld * a.ld;
     const int j0 = SW::bc() * CB;
 
-    float d2[RB][CB], m[RB][CB];
-#pragma unroll
-    for (int r = 0; r < RB; ++r)
-#pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            const int i = SW::row(r), j = j0 + c;
-            const int hi = i > j ? i : j, lo = i > j ? j : i;  // exactly symmetric input to the sweep
-            d2[r][c] = (i < n && j < n) ? D2[(size_t)hi * a.ld + lo] : 0.f;
-        }
+    typename EV::D2 d2;
+    d2.init(D2, a.ld, n);
+    float m[RB][CB];
     if (tid < NMAX) sm.vec_in[tid] = (tid < n) ? a.y_s[(size_t)t * a.ld + tid] : 0.f;
     float pri[4];
 #pragma unroll

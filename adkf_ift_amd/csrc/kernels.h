@@ -84,8 +84,8 @@ struct ProbDist {
 // 31-step radix select on the float bit patterns (positive floats order like their bits). ---------------
 // One workgroup per task; the (at most 128 x 128) candidates are loaded ONCE into registers (32 per lane), every
 // radix step is then 32 compares + a wave/LDS count reduction, no memory traffic.
-__global__ __launch_bounds__(512) void k_median(const float* D2ss, const int32_t* n_s, int ld, float* l0, int T) {
-    constexpr int NT = 512, EPT = 32;  // 512 * 32 = 128 * 128
+template <int NT, int EPT>  // NT * EPT >= ld * ld: <512, 32> up to 128 points, <1024, 64> up to 256
+__global__ __launch_bounds__(NT) void k_median(const float* D2ss, const int32_t* n_s, int ld, float* l0, int T) {
     __shared__ int red[NT / 64];
     int t, tile;
     if (!task_tile(T, 1, t, tile)) return;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_rowsums(RowsumArgs a) {
     const float* Wqq = a.Wqq ? a.Wqq + (size_t)t * a.tv.nq_ld * a.tv.nq_ld : nullptr;
     float* vb = a.vecs + (size_t)t * NVEC * a.tv.vld;
     // column sums of W_qs: every wave sums its share of the rows for all columns (coalesced), partials meet in LDS
-    constexpr int CMAX = 128;  // >= adkf_max_points()
+    constexpr int CMAX = 256;  // >= adkf_max_points()
     __shared__ float cpart[NW][CMAX];
     if (m > 0) {
         for (int j = lane; j < n; j += 64) {

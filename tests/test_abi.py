@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_host_only_entry_points(lib):
     assert b"gfx950" in lib.adkf_version()
-    assert lib.adkf_max_points() >= 128
+    assert lib.adkf_max_points() >= 256
     assert lib.adkf_workspace_bytes(0, 8, 8, 4) == 0
     small = lib.adkf_workspace_bytes(4, 16, 16, 8)
     big = lib.adkf_workspace_bytes(256, 128, 128, 256)
