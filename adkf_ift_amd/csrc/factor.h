@@ -50,7 +50,7 @@ template <int NMAX, int NT> struct SweepCfg;
 #define ADKF_CFG128_CB 4
 #endif
 template <> struct SweepCfg<128, 512> { static constexpr int RB = ADKF_CFG128_RB, CB = ADKF_CFG128_CB; };
-template <> struct SweepCfg<256, 1024> { static constexpr int RB = 16, CB = 4; };  // 64 elements per lane, <= 128 VGPRs
+template <> struct SweepCfg<256, 1024> { static constexpr int RB = 16, CB = 4; };  // 64 elements per lane; functional, not tuned (spills: see DESIGN.md)
 template <> struct SweepCfg<64, 256> { static constexpr int RB = 4, CB = 4; };
 template <> struct SweepCfg<32, 256> { static constexpr int RB = 2, CB = 2; };
 template <> struct SweepCfg<16, 256> { static constexpr int RB = 1, CB = 1; };
@@ -175,22 +175,14 @@ struct Sweep {
         ADKF_TS(3);
         if (br() == bl) {
             const int j0 = bc() * CB;
-            float C[B][CB], F[B][CB], piv[B];
+            const float hold = (bc() == q) ? 1.f : 0.f;  // this thread holds D: C := D - I at the pivot columns
+            float piv[B];
+            // C rows straight from the matrix registers (no private copy: the 256-point config has no registers to
+            // spare); they are final, so their stores fly under the inverse
 #pragma unroll
             for (int a = 0; a < B; ++a)
 #pragma unroll
-                for (int c = 0; c < CB; ++c) C[a][c] = m[RO + a][c];
-            if (bc() == q) {  // this thread holds D: C := D - I at the pivot columns, M_PP := D - 2I
-#pragma unroll
-                for (int a = 0; a < B; ++a) {
-                    C[a][a] -= 1.f;
-                    m[RO + a][a] -= 2.f;
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < B; ++a)
-#pragma unroll
-                for (int c = 0; c < CB; ++c) sm.cross[slot][a][j0 + c] = C[a][c];  // C is final: its stores fly under the inverse
+                for (int c = 0; c < CB; ++c) sm.cross[slot][a][j0 + c] = m[RO + a][c] - (a == c ? hold : 0.f);
 #if ADKF_ABLATE & 1
             for (int a = 0; a < B; ++a) piv[a] = D[a][a];
 #else
@@ -202,25 +194,26 @@ struct Sweep {
                 for (int a = 0; a < B; ++a) sm.pivs[q * B + a] = piv[a];
             }
 #pragma unroll
-            for (int a = 0; a < B; ++a)
+            for (int a = 0; a < B; ++a) {
+                float f[CB];
 #pragma unroll
                 for (int c = 0; c < CB; ++c) {
 #if ADKF_ABLATE & 4
-                    F[a][c] = C[a][c] * D[a][a];
+                    f[c] = m[RO + a][c] * D[a][a];
 #else
                     float s = 0.f;
 #pragma unroll
-                    for (int b = 0; b < B; ++b) s = fmaf(D[a][b], C[b][c], s);
-                    F[a][c] = s;
+                    for (int b = 0; b < B; ++b) s = fmaf(D[a][b], m[RO + b][c] - (b == c ? hold : 0.f), s);
+                    f[c] = s;
 #endif
                 }
 #pragma unroll
-            for (int a = 0; a < B; ++a)
+                for (int c = 0; c < CB; ++c) sm.fvec[slot][a][j0 + c] = f[c];
+            }
+            // M_PP := D - 2I (see header): only now, after C and F have been formed from the unmodified rows
 #pragma unroll
-                for (int c = 0; c < CB; ++c) {
-                    sm.fvec[slot][a][j0 + c] = F[a][c];
+            for (int a = 0; a < B; ++a) m[RO + a][a] -= 2.f * hold;
             ADKF_TS(6);
-                }
         }
     }
 
