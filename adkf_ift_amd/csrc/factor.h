@@ -173,6 +173,59 @@ struct Sweep {
                 D[b][a] = D[a][b];
             }
         ADKF_TS(3);
+        if constexpr (RB * CB <= 32) {
+            // private copies of C and F: fastest when registers are plentiful (<= 128 points)
+        if (br() == bl) {
+            const int j0 = bc() * CB;
+            float C[B][CB], F[B][CB], piv[B];
+#pragma unroll
+            for (int a = 0; a < B; ++a)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) C[a][c] = m[RO + a][c];
+            if (bc() == q) {  // this thread holds D: C := D - I at the pivot columns, M_PP := D - 2I
+#pragma unroll
+                for (int a = 0; a < B; ++a) {
+                    C[a][a] -= 1.f;
+                    m[RO + a][a] -= 2.f;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < B; ++a)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) sm.cross[slot][a][j0 + c] = C[a][c];  // C is final: its stores fly under the inverse
+#if ADKF_ABLATE & 1
+            for (int a = 0; a < B; ++a) piv[a] = D[a][a];
+#else
+            InvSpd<B>::run(D, piv);
+#endif
+            ADKF_TS(4);
+            if (bc() == q) {
+#pragma unroll
+                for (int a = 0; a < B; ++a) sm.pivs[q * B + a] = piv[a];
+            }
+#pragma unroll
+            for (int a = 0; a < B; ++a)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+#if ADKF_ABLATE & 4
+                    F[a][c] = C[a][c] * D[a][a];
+#else
+                    float s = 0.f;
+#pragma unroll
+                    for (int b = 0; b < B; ++b) s = fmaf(D[a][b], C[b][c], s);
+                    F[a][c] = s;
+#endif
+                }
+#pragma unroll
+            for (int a = 0; a < B; ++a)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    sm.fvec[slot][a][j0 + c] = F[a][c];
+            ADKF_TS(6);
+                }
+        }
+        } else {
+            // 64 matrix elements per lane: no registers to spare, form C and F straight from the matrix registers
         if (br() == bl) {
             const int j0 = bc() * CB;
             const float hold = (bc() == q) ? 1.f : 0.f;  // this thread holds D: C := D - I at the pivot columns
@@ -214,6 +267,7 @@ struct Sweep {
 #pragma unroll
             for (int a = 0; a < B; ++a) m[RO + a][a] -= 2.f * hold;
             ADKF_TS(6);
+        }
         }
     }
 
