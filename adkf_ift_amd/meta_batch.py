@@ -1,0 +1,148 @@
+"""Meta-batches of few-shot tasks for the deep-kernel model: the data layout on either side of the hot path.
+
+The reference feeds ONE task at a time (``DKTBatch``, fs_mol/data/dkt.py:32-46: support / query ``MoleculeDKTFeatures``
+= an ``FSMolBatch`` disconnected graph + fingerprints + descriptors, fs_mol/data/fsmol_batcher.py:22-54) and runs the
+feature extractor >= 3 times forward and h+1 times backward per task.  Here all molecules of all tasks of a meta-batch
+form ONE disconnected graph, the extractor runs once, and index maps scatter the molecule features into the padded
+``[T, N_max, d]`` layout the HIP library consumes (ragged sizes through ``n_s`` / ``n_q``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from .gnn import GraphBatch, concat_graph_batches
+
+
+@dataclass
+class MoleculeFeatures:
+    """``MoleculeDKTFeatures`` (fs_mol/data/dkt.py:25-29) as torch tensors."""
+
+    node_features: torch.Tensor
+    adjacency_lists: List[torch.Tensor]
+    node_to_graph: torch.Tensor
+    num_graphs: int
+    fingerprints: torch.Tensor   # [G, 2048]
+    descriptors: torch.Tensor    # [G, 42]
+
+    def graph(self) -> GraphBatch:
+        return GraphBatch(self.node_features, self.adjacency_lists, self.node_to_graph, self.num_graphs)
+
+    def to(self, device):
+        g = self.graph().to(device)
+        return MoleculeFeatures(g.node_features, g.adjacency_lists, g.node_to_graph, g.num_graphs,
+                                self.fingerprints.to(device), self.descriptors.to(device))
+
+
+@dataclass
+class DKTBatch:
+    """Same fields as the reference's ``DKTBatch`` (fs_mol/data/dkt.py:32-46)."""
+
+    support_features: MoleculeFeatures
+    support_labels: torch.Tensor
+    support_numeric_labels: torch.Tensor
+    query_features: MoleculeFeatures
+    query_labels: torch.Tensor
+    query_numeric_labels: torch.Tensor
+
+    @property
+    def num_support_samples(self) -> int:
+        return self.support_features.num_graphs
+
+    @property
+    def num_query_samples(self) -> int:
+        return self.query_features.num_graphs
+
+    def to(self, device):
+        return DKTBatch(self.support_features.to(device), self.support_labels.to(device), self.support_numeric_labels.to(device),
+                        self.query_features.to(device), self.query_labels.to(device), self.query_numeric_labels.to(device))
+
+
+def _concat_molecules(parts: Sequence[MoleculeFeatures]) -> MoleculeFeatures:
+    g = concat_graph_batches([p.graph() for p in parts])
+    return MoleculeFeatures(g.node_features, g.adjacency_lists, g.node_to_graph, g.num_graphs,
+                            torch.cat([p.fingerprints for p in parts]), torch.cat([p.descriptors for p in parts]))
+
+
+@dataclass
+class MetaBatch:
+    molecules: MoleculeFeatures   # every molecule of every task, one disconnected graph
+    s_index: torch.Tensor         # [T, Ns_max] molecule id of each support slot (0 where padded)
+    q_index: torch.Tensor         # [T, Nq_max]
+    s_mask: torch.Tensor          # [T, Ns_max] 1.0 for real slots
+    q_mask: torch.Tensor
+    n_s: torch.Tensor             # [T] int32
+    n_q: torch.Tensor
+    support_labels: torch.Tensor          # [T, Ns_max] bool (False where padded)
+    support_numeric_labels: torch.Tensor  # [T, Ns_max]
+    query_labels: torch.Tensor
+    query_numeric_labels: torch.Tensor
+
+    @property
+    def num_tasks(self) -> int:
+        return self.s_index.shape[0]
+
+    def to(self, device):
+        return MetaBatch(self.molecules.to(device), *(t.to(device) for t in (
+            self.s_index, self.q_index, self.s_mask, self.q_mask, self.n_s, self.n_q, self.support_labels,
+            self.support_numeric_labels, self.query_labels, self.query_numeric_labels)))
+
+    def labels(self, use_numeric_labels: bool):
+        """±1 for bool labels (fs_mol/models/adaptive_dkt.py:207-209) or the (already standardised) numeric ones."""
+        if use_numeric_labels:
+            return self.support_numeric_labels.float(), self.query_numeric_labels.float()
+        cv = lambda l: (l.float() - 0.5) * 2.0
+        return cv(self.support_labels) * self.s_mask, cv(self.query_labels) * self.q_mask
+
+
+def collate_meta_batch(tasks: Sequence[DKTBatch], pad_to: int = 4) -> MetaBatch:
+    """Many single-task batches -> one meta-batch.  Padded sizes are rounded up to a multiple of ``pad_to`` so that
+    the library's 16-byte vector loads stay legal."""
+    T = len(tasks)
+    ns = [t.num_support_samples for t in tasks]
+    nq = [t.num_query_samples for t in tasks]
+    up = lambda x: ((max(x) + pad_to - 1) // pad_to) * pad_to
+    Ns, Nq = up(ns), up(nq)
+    parts, s_index, q_index = [], torch.zeros(T, Ns, dtype=torch.long), torch.zeros(T, Nq, dtype=torch.long)
+    s_mask, q_mask = torch.zeros(T, Ns), torch.zeros(T, Nq)
+    sl, snl = torch.zeros(T, Ns, dtype=torch.bool), torch.zeros(T, Ns)
+    ql, qnl = torch.zeros(T, Nq, dtype=torch.bool), torch.zeros(T, Nq)
+    g0 = 0
+    for t, b in enumerate(tasks):
+        parts += [b.support_features, b.query_features]
+        s_index[t, :ns[t]] = torch.arange(g0, g0 + ns[t]); g0 += ns[t]
+        q_index[t, :nq[t]] = torch.arange(g0, g0 + nq[t]); g0 += nq[t]
+        s_mask[t, :ns[t]] = 1.0
+        q_mask[t, :nq[t]] = 1.0
+        sl[t, :ns[t]] = b.support_labels.bool().cpu()
+        ql[t, :nq[t]] = b.query_labels.bool().cpu()
+        snl[t, :ns[t]] = b.support_numeric_labels.float().cpu()
+        qnl[t, :nq[t]] = b.query_numeric_labels.float().cpu()
+    mols = _concat_molecules([p.to("cpu") for p in parts])
+    return MetaBatch(mols, s_index, q_index, s_mask, q_mask, torch.tensor(ns, dtype=torch.int32),
+                     torch.tensor(nq, dtype=torch.int32), sl, snl, ql, qnl)
+
+
+def meta_features(model, mb: MetaBatch):
+    """ONE forward of the deep-kernel feature extractor for the whole meta-batch ->
+    ``Z_s [T, Ns_max, d]``, ``Z_q [T, Nq_max, d]`` (padded rows are zero and receive zero gradient)."""
+    F = model._features(mb.molecules)  # [G_total, d]
+    Z_s = F[mb.s_index] * mb.s_mask.unsqueeze(-1).to(F.dtype)
+    Z_q = F[mb.q_index] * mb.q_mask.unsqueeze(-1).to(F.dtype)
+    return Z_s, Z_q
+
+
+def model_meta_step(model, optimizer, mb: MetaBatch, cfg=None, distributed: bool = False, check: bool = False):
+    """The batched counterpart of one iteration of ``ADKTModelTrainer.train_loop``
+    (fs_mol/utils/adaptive_dkt_utils.py:352-413) for an ``ADKTModel``: returns per-task per-sample losses."""
+    from .trainer import MetaStepConfig, meta_step
+
+    if cfg is None:
+        c = model.config
+        cfg = MetaStepConfig(gp_kernel=c.gp_kernel, use_numeric_labels=c.use_numeric_labels,
+                             use_lengthscale_prior=c.use_lengthscale_prior, ignore_grad_correction=c.ignore_grad_correction)
+    y_s, y_q = mb.labels(cfg.use_numeric_labels)
+    return meta_step(lambda: meta_features(model, mb), list(model.feature_extractor_params()), optimizer, y_s, y_q, cfg,
+                     n_s=mb.n_s, n_q=mb.n_q, distributed=distributed, check=check)

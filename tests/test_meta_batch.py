@@ -1,0 +1,57 @@
+"""CPU: collating many single-task DKTBatches into one disconnected graph + index maps reproduces the per-task
+features exactly (the GP tail is not involved here)."""
+import torch
+
+from adkf_ift_amd.gnn import GNNConfig, GraphFeatureExtractorConfig, GraphReadoutConfig
+from adkf_ift_amd.meta_batch import DKTBatch, MoleculeFeatures, collate_meta_batch, meta_features
+from adkf_ift_amd.models import ADKTModel, ADKTModelConfig
+
+from test_gnn import random_graphs
+
+
+def random_task(ns, nq, seed):
+    g = torch.Generator().manual_seed(seed)
+    def part(n, s):
+        gb = random_graphs(n, seed=s)
+        return MoleculeFeatures(gb.node_features.float(), gb.adjacency_lists, gb.node_to_graph, gb.num_graphs,
+                                torch.poisson(torch.full((n, 2048), 0.05), generator=g), torch.randn(n, 42, generator=g))
+    return DKTBatch(part(ns, seed * 2), torch.rand(ns, generator=g) > 0.5, torch.randn(ns, generator=g),
+                    part(nq, seed * 2 + 1), torch.rand(nq, generator=g) > 0.5, torch.randn(nq, generator=g))
+
+
+def small_model(numeric=False):
+    gcfg = GraphFeatureExtractorConfig(gnn_config=GNNConfig(hidden_dim=16, num_heads=4, per_head_dim=4, intermediate_dim=16, num_layers=2),
+                                       readout_config=GraphReadoutConfig(num_heads=2, head_dim=4, output_dim=8))
+    return ADKTModelConfig(graph_feature_extractor_config=gcfg, used_features="gnn+ecfp+fc", gp_kernel="matern",
+                           use_numeric_labels=numeric, fc_hidden_dim=16, fc_out_dim=12)
+
+
+def test_collate_matches_per_task_features():
+    torch.manual_seed(0)
+    tasks = [random_task(5, 9, 1), random_task(8, 3, 2), random_task(2, 6, 3)]
+    mb = collate_meta_batch(tasks)
+    assert mb.s_index.shape == (3, 8) and mb.q_index.shape == (3, 12)      # padded to multiples of 4
+    assert mb.n_s.tolist() == [5, 8, 2] and mb.n_q.tolist() == [9, 3, 6]
+    assert mb.molecules.num_graphs == sum(t.num_support_samples + t.num_query_samples for t in tasks)
+
+    class Stub(torch.nn.Module):  # ADKTModel needs the GPU for its GP tail; the feature path is what is tested here
+        def __init__(self, cfg):
+            super().__init__()
+            self.config = cfg
+    from adkf_ift_amd.models import _DeepKernelBase
+    cfg = small_model()
+    m = type("FeatOnly", (_DeepKernelBase,), {})()
+    m.config = cfg
+    m._build_features(cfg)
+    with torch.no_grad():
+        for blk in m.graph_feature_extractor.gnn.gnn_blocks:
+            blk.alpha.fill_(0.5)
+    Z_s, Z_q = meta_features(m, mb)
+    assert Z_s.shape == (3, 8, 12) and Z_q.shape == (3, 12, 12)
+    for t, task in enumerate(tasks):
+        fs, fq = m._features(task.support_features), m._features(task.query_features)
+        assert torch.allclose(Z_s[t, :task.num_support_samples], fs, atol=1e-5)
+        assert torch.allclose(Z_q[t, :task.num_query_samples], fq, atol=1e-5)
+        assert float(Z_s[t, task.num_support_samples:].abs().max() if task.num_support_samples < 8 else 0.0) == 0.0
+    ys, yq = mb.labels(False)
+    assert set(ys.unique().tolist()) <= {-1.0, 0.0, 1.0} and float(ys[2, 2:].abs().max()) == 0.0
