@@ -143,6 +143,15 @@ def main():
         value = total_tasks / dt
         fit_flops = fl["inner_fit"] * T            # algorithmic FLOPs of ONE launch of the dominant kernel
         achieved = fit_flops / (fit_ms * 1e-3) / 1e12
+        # HBM bytes of that launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE in separate runs of this same command; KB -> bytes; the k_inner loads are dword-wide, for
+        # which the guide's x2 FETCH_SIZE correction is uncalibrated, so the raw counters are reported)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_final_k_inner_pmc.json")
+        if os.path.exists(pmc) and (T, N, Nq, d, I) == (256, 128, 128, 256, 20) and args.kernel == "rbf":
+            with open(pmc) as fh:
+                pm = json.load(fh)
+            traffic = (pm["FETCH_SIZE_KB_per_launch"] + pm["WRITE_SIZE_KB_per_launch"]) * 1024.0
         line = {
             "metric": "meta-tasks/sec (N_support=128, d=256)", "value": value, "unit": "tasks/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -155,7 +164,7 @@ def main():
             "whole_path_frac_of_fp32_peak": value * fl["total"] / 1e12 / (roofline.PEAK_FP32_TFLOPS * world),
             "roofline": {"kernel": "k_inner (in-kernel quasi-Newton fit: kernel build + LDL^T + inverse per evaluation)",
                          "bound": "mfma", "achieved": achieved, "peak": roofline.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / roofline.PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / roofline.PEAK_FP32_TFLOPS, "traffic": traffic,
                          "flops_per_launch": fit_flops, "avg_launch_ms": fit_ms},
             "cpu_baseline": cpu_baseline,
             "parity": parity,
