@@ -4,18 +4,23 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/adkf_gp.h"
-#include "kernels.h"
+#include "large.h"
 
 using namespace adkf;
 
 namespace {
 
-constexpr int MAX_POINTS = 256;  // register-resident sweep: 64 matrix elements per lane at 1024 lanes
+constexpr int MAX_POINTS = 4096;  // <= 128: register-resident sweep (inner.h); above: blocked sweep through L2/HBM (large.h)
+constexpr int REG_POINTS = 128;
 
 inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct Workspace {
     float *mean, *nrm_s, *nrm_q, *D2ss, *D2qs, *D2qq, *Ainv, *P, *C, *S, *OC, *Wss, *Wqs, *Wqq, *vecs, *scal, *part_oc, *part_ma, *l0;
+    // blocked path only (max(ns, nq) > REG_POINTS)
+    float *lg_Dinv, *lg_C, *lg_F, *lg_logdet, *lg_part;
+    int32_t* lg_info;
+    FitShared* lg_fit;
     int vld, nt_oc, nt_ma;
     size_t bytes;
 };
@@ -47,6 +52,16 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
     w.part_oc = take(Tz * (w.nt_oc > 0 ? w.nt_oc : 1) * 4);
     w.part_ma = take(Tz * w.nt_ma * 4);
     w.l0 = take(Tz);
+    w.lg_Dinv = w.lg_C = w.lg_F = w.lg_logdet = w.lg_part = nullptr; w.lg_info = nullptr; w.lg_fit = nullptr;
+    if (w.vld > REG_POINTS) {
+        w.lg_Dinv = take(Tz * LB * LB);
+        w.lg_C = take(Tz * LB * w.vld);
+        w.lg_F = take(Tz * LB * w.vld);
+        w.lg_logdet = take(Tz);
+        w.lg_part = take(Tz * w.nt_ma * 4);
+        w.lg_info = reinterpret_cast<int32_t*>(take(Tz));
+        w.lg_fit = reinterpret_cast<FitShared*>(take(Tz * ((sizeof(FitShared) + 3) / 4)));
+    }
     w.bytes = off;
     return w;
 }
@@ -120,23 +135,74 @@ void launch_inner_k(const InnerArgs& a, hipStream_t st) {
     else k_inner<NMAX, NT, 1><<<grid_for(a.T, 1), NT, 0, st>>>(a);
 }
 
-// Stage B (and the fit): dispatch on the padded support size.
-int launch_inner(InnerArgs a, hipStream_t st) {
-    if (a.ld <= 16) launch_inner_k<16, 256>(a, st);
-    else if (a.ld <= 32) launch_inner_k<32, 256>(a, st);
-    else if (a.ld <= 64) launch_inner_k<64, 256>(a, st);
-    else if (a.ld <= 128) launch_inner_k<128, 512>(a, st);
-    else launch_inner_k<256, 1024>(a, st);
+LgMat lg_mat(const Workspace& w, float* M, int ld, const int32_t* n_arr, const FitShared* fit, int T) {
+    LgMat m;
+    m.M = M; m.ld = ld; m.n_arr = n_arr; m.fit = fit;
+    m.Dinv = w.lg_Dinv; m.Cbuf = w.lg_C; m.Fbuf = w.lg_F; m.logdet = w.lg_logdet; m.info = w.lg_info;
+    m.T = T; m.vec = (ld & 3) == 0;
+    return m;
+}
+
+// M -> -(M^-1) in place by 128-pivot block steps (large.h)
+void lg_sweep(const LgMat& m, hipStream_t st) {
+    const int nb = ceil_div(m.ld, LB), tn = ceil_div(m.ld, GT);
+    for (int step = 0; step < nb; ++step) {
+        k_lg_diag<<<grid_for(m.T, 1), 512, 0, st>>>(m, step);
+        ProbLgPanel pp; pp.m = m; pp.step = step;
+        k_bgemm<ProbLgPanel><<<grid_for(m.T, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn);
+        ProbLgUpdate pu; pu.m = m; pu.step = step;
+        k_bgemm<ProbLgUpdate><<<grid_for(m.T, tn * tn), 256, 0, st>>>(pu, m.T, tn, tn);
+    }
+}
+
+int launch_inner_large(const InnerArgs& a, const Workspace& w, hipStream_t st) {
+    LgInner li;
+    li.in = a; li.fit = w.lg_fit; li.part = w.lg_part;
+    li.tiles_1d = ceil_div(a.ld, GT); li.ntiles = li.tiles_1d * li.tiles_1d;
+    li.mat = lg_mat(w, a.Ainv, a.ld, a.n_s, w.lg_fit, a.T);
+    LgMatvecArgs mv{li.mat, a.y_s, (size_t)a.ld, a.vecs + (size_t)V_ALPHA * a.vld, (size_t)NVEC * a.vld, -1.f};
+    k_lg_begin<<<ceil_div(a.T, 64), 64, 0, st>>>(li);
+    const int n_evals = a.max_evals > 0 ? a.max_evals : 1;
+    for (int e = 0; e < n_evals; ++e) {
+        k_lg_build<<<grid_for(a.T, li.ntiles), 256, 0, st>>>(li);
+        lg_sweep(li.mat, st);
+        k_lg_matvec<<<dim3(ceil_div(a.ld, 4), a.T), 256, 0, st>>>(mv);
+        k_lg_traces<<<grid_for(a.T, li.ntiles), 256, 0, st>>>(li);
+        k_lg_advance<<<a.T, 64, 0, st>>>(li);
+    }
     LAUNCH_OK();
     return 0;
 }
 
-int launch_outer_factor(const OuterArgs& a, int nq, hipStream_t st) {
+// Stage B (and the fit): dispatch on the padded support size.
+int launch_inner(InnerArgs a, const Workspace& w, hipStream_t st) {
+    if (a.ld > REG_POINTS) return launch_inner_large(a, w, st);
+    if (a.ld <= 16) launch_inner_k<16, 256>(a, st);
+    else if (a.ld <= 32) launch_inner_k<32, 256>(a, st);
+    else if (a.ld <= 64) launch_inner_k<64, 256>(a, st);
+    else launch_inner_k<128, 512>(a, st);
+    LAUNCH_OK();
+    return 0;
+}
+
+int launch_outer_factor(const OuterArgs& a, const Workspace& w, int nq, hipStream_t st) {
+    if (nq > REG_POINTS) {
+        k_lg_resid<<<dim3(ceil_div(nq, 4), a.T), 256, 0, st>>>(a);
+        LgMat m = lg_mat(w, a.S, a.tv.nq_ld, a.tv.n_q, nullptr, a.T);
+        lg_sweep(m, st);
+        LgMatvecArgs mv{m, a.vecs + (size_t)V_R * a.tv.vld, (size_t)NVEC * a.tv.vld, a.vecs + (size_t)V_E * a.tv.vld, (size_t)NVEC * a.tv.vld, -1.f};
+        k_lg_matvec<<<dim3(ceil_div(nq, 4), a.T), 256, 0, st>>>(mv);
+        const int tn = ceil_div(nq, GT);
+        k_lg_negate<<<grid_for(a.T, tn * tn), 256, 0, st>>>(m, tn);
+        LgOuterFin fin{a, w.lg_logdet, w.lg_info};
+        k_lg_outer_fin<<<grid_for(a.T, 1), 1024, 0, st>>>(fin);
+        LAUNCH_OK();
+        return 0;
+    }
     if (nq <= 16) k_outer_factor<16, 256><<<grid_for(a.T, 1), 256, 0, st>>>(a);
     else if (nq <= 32) k_outer_factor<32, 256><<<grid_for(a.T, 1), 256, 0, st>>>(a);
     else if (nq <= 64) k_outer_factor<64, 256><<<grid_for(a.T, 1), 256, 0, st>>>(a);
-    else if (nq <= 128) k_outer_factor<128, 512><<<grid_for(a.T, 1), 512, 0, st>>>(a);
-    else k_outer_factor<256, 1024><<<grid_for(a.T, 1), 1024, 0, st>>>(a);
+    else k_outer_factor<128, 512><<<grid_for(a.T, 1), 512, 0, st>>>(a);
     LAUNCH_OK();
     return 0;
 }
@@ -161,7 +227,7 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)T, st);
     } else {
         InnerArgs ia = inner_args(b, w, const_cast<float*>(phi), info);
-        rc = launch_inner(ia, st);
+        rc = launch_inner(ia, w, st);
         if (rc) return rc;
     }
     TaskView tv = make_tv(b, w, true);
@@ -179,7 +245,7 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
     ProbS ps; ps.tv = tv; ps.C = w.C; ps.D2qs = w.D2qs; ps.D2qq = w.D2qq; ps.S = w.S;
     k_bgemm<ProbS><<<grid_for(T, tmq * tmq), 256, 0, st>>>(ps, T, tmq, tmq);
     OuterArgs oa{tv, w.C, w.S, b->y_s, b->y_q, w.vecs, w.scal, f_out, info, T};
-    rc = launch_outer_factor(oa, nq, st);
+    rc = launch_outer_factor(oa, w, nq, st);
     if (rc) return rc;
     ProbOC po; po.tv = tv; po.Sinv = w.S; po.C = w.C; po.D2qs = w.D2qs; po.OC = w.OC; po.Wqs = w.Wqs; po.part = w.part_oc; po.ntiles = w.nt_oc; po.dirscale = dirscale;
     k_bgemm<ProbOC><<<grid_for(T, tmq * tms), 256, 0, st>>>(po, T, tmq, tms);
@@ -194,7 +260,8 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         k_bgemm<ProbMixed><<<grid_for(T, tms * tms), 256, 0, st>>>(px, T, tms, tms);
     }
     if (dZ_s || dZ_q) {
-        RowsumArgs ra{tv, w.Wss, w.Wqs, w.Wqq, w.vecs, T};
+        RowsumArgs ra{tv, w.Wss, w.Wqs, w.Wqq, w.vecs, T, ns > 256 ? 1 : 0};
+        if (ra.ext_colsum) k_lg_colsum<<<dim3(ceil_div(ns, 256), T), 256, 0, st>>>(ra);
         k_rowsums<<<grid_for(T, 1), SMALL_NT, 0, st>>>(ra);
         const int tn = ceil_div(d, GT);
         if (dZ_s) {
@@ -235,7 +302,8 @@ int adkf_median_lengthscale(const adkf_batch_t* b, float* l0, void* ws, size_t w
     rc = stage_dist(b, w, has_query(b), st);
     if (rc) return rc;
     if (b->ns_max <= 128) k_median<512, 32><<<grid_for(b->T, 1), 512, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T);
-    else k_median<1024, 64><<<grid_for(b->T, 1), 1024, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T);
+    else if (b->ns_max <= 256) k_median<1024, 64><<<grid_for(b->T, 1), 1024, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T);
+    else k_median_large<<<grid_for(b->T, 1), 1024, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T);
     LAUNCH_OK();
     return 0;
 }
@@ -268,7 +336,7 @@ int adkf_mll_value_grad(const adkf_batch_t* b, const float* phi, float* f_in, fl
     if (rc) return rc;
     InnerArgs ia = inner_args(b, w, const_cast<float*>(phi), info);
     ia.f_out = f_in; ia.g_out = g_phi;
-    rc = launch_inner(ia, st);
+    rc = launch_inner(ia, w, st);
     if (rc) return rc;
     if (dZ_s) {
         TaskView tv = make_tv(b, w, false);
@@ -299,7 +367,7 @@ int adkf_fit(const adkf_batch_t* b, float* phi, const adkf_fit_options_t* opt, f
     ia.f_out = f_final; ia.gnorm_out = gnorm; ia.nevals_out = n_evals;
     ia.max_evals = opt->max_evals; ia.exact_evals = opt->exact_evals; ia.gtol = opt->gtol; ia.ftol = opt->ftol;
     if (opt->ev_start && hipEventRecord(static_cast<hipEvent_t>(opt->ev_start), st) != hipSuccess) return ADKF_E_LAUNCH;
-    rc = launch_inner(ia, st);
+    rc = launch_inner(ia, w, st);
     if (opt->ev_stop && hipEventRecord(static_cast<hipEvent_t>(opt->ev_stop), st) != hipSuccess) return ADKF_E_LAUNCH;
     return rc;
 }
@@ -318,7 +386,7 @@ int adkf_predict(const adkf_batch_t* b, const float* phi, float* mean, float* va
         hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)b->T, st);
     } else {
         InnerArgs ia = inner_args(b, w, const_cast<float*>(phi), info);
-        rc = launch_inner(ia, st);
+        rc = launch_inner(ia, w, st);
         if (rc) return rc;
     }
     TaskView tv = make_tv(b, w, true);

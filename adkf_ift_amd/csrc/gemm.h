@@ -17,7 +17,11 @@
 //   __device__ float a(int i, int k), b(int k, int j)   : operand entries (callers guarantee in-range)
 //   __device__ void  epi(int i, int j, float acc, float* red)
 //   __device__ void  store_red(int tile, const float* red)   (only when NRED > 0; called by thread 0)
+//   __device__ bool  skip(int m0, int n0)        : OPTIONAL - true when the tile at (m0, n0) needs no product (its
+//                                                  epilogue still runs, with acc = 0)
 #pragma once
+#include <type_traits>
+
 #include "device_utils.h"
 
 namespace adkf {
@@ -29,6 +33,9 @@ constexpr int LD_K = GT + 16; // [k][mn] layout, MN-contiguous operands (LD % 32
 constexpr int GPT = GT * GK / 256;  // operand elements staged per thread per chunk
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <class P, class = void> struct has_skip : std::false_type {};
+template <class P> struct has_skip<P, std::void_t<decltype(&P::skip)>> : std::true_type {};
 
 // Each thread stages GPT = 8 operand entries per chunk as two groups of 4 that are consecutive along the operand's
 // contiguous direction: K-contiguous -> (row r, k4..k4+3), MN-contiguous -> (k, mn4..mn4+3).
@@ -79,7 +86,8 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
     int task, tile;
     if (!task_tile(T, tiles_m * tiles_n, task, tile)) return;
     if (!p.setup(task)) return;
-    const int M = p.M(), N = p.N(), K = p.K();
+    const int M = p.M(), N = p.N();
+    int K = p.K();
     const int m0 = (tile / tiles_n) * GT, n0 = (tile % tiles_n) * GT;
     if (m0 >= M || n0 >= N) {  // tile outside this (ragged) task: contributes zero partials
         if (P::NRED > 0 && threadIdx.x == 0) {
@@ -104,6 +112,9 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (has_skip<P>::value) {
+        if (p.skip(m0, n0)) K = 0;
+    }
     float ra[GPT], rb[GPT];
     gemm_fetch<P, true>(p, ra, m0, 0, M, K);
     gemm_fetch<P, false>(p, rb, n0, 0, N, K);

@@ -59,6 +59,39 @@ struct D2Block {
     }
 };
 
+// f_inner = (nll - log priors) / n and its raw-parameter gradient from the five reductions
+// acc = {tr(Ainv G), a^T G a, tr(Ainv), a^T a, y^T a} (oracle/closed_form.py::inner_stage); shared by the register-resident
+// evaluator below and the blocked large-N path (large.h).
+__device__ __forceinline__ void inner_finalize(int n, const float* x, const float* pri, float logdet, const float* acc,
+                                               float& f, float* g, float* extra) {
+    const float noise = softplus_f(x[0]) + NOISE_LB, os = softplus_f(x[1]), ls = softplus_f(x[2]);
+    const float d1n = sigmoid_f(x[0]), d1s = sigmoid_f(x[1]), d1l = sigmoid_f(x[2]);
+    const float trAinvG = acc[0], aGa = acc[1], trAinv = acc[2], aa = acc[3], ya = acc[4];
+    const float fn = (float)n;
+    const float nll = 0.5f * ya + 0.5f * logdet + 0.5f * fn * LOG_2PI;
+    // LogNormal priors on the transformed values (oracle/closed_form.py::lognormal_terms)
+    float lp = 0.f, dpn = 0.f, dpl = 0.f;
+    if (pri[1] > 0.f) {
+        const float lx = logf(noise), sc = pri[1], z = (lx - pri[0]) / (sc * sc);
+        lp += -lx - logf(sc) - 0.5f * LOG_2PI - 0.5f * (lx - pri[0]) * z;
+        dpn = (-1.f - z) / noise;
+    }
+    if (pri[3] > 0.f) {
+        const float lx = logf(ls), sc = pri[3], z = (lx - pri[2]) / (sc * sc);
+        lp += -lx - logf(sc) - 0.5f * LOG_2PI - 0.5f * (lx - pri[2]) * z;
+        dpl = (-1.f - z) / ls;
+    }
+    f = (nll - lp) / fn;
+    const float gt0 = 0.5f * trAinv - 0.5f * aa - dpn;
+    const float gt1 = (0.5f * (fn - noise * trAinv) - 0.5f * (ya - noise * aa)) / os;
+    const float gt2 = 0.5f * trAinvG - 0.5f * aGa - dpl;
+    g[0] = gt0 * d1n / fn;
+    g[1] = gt1 * d1s / fn;
+    g[2] = gt2 * d1l / fn;
+    extra[0] = logdet; extra[1] = trAinv; extra[2] = aa; extra[3] = ya; extra[4] = trAinvG; extra[5] = aGa;
+    extra[6] = gt0; extra[7] = gt1; extra[8] = gt2;
+}
+
 template <int NMAX, int NT, int KIND>
 struct InnerEval {
     static constexpr bool D2_REGS = NMAX <= 128;
@@ -73,7 +106,6 @@ struct InnerEval {
                                               bool fast) {
         const int j0 = SW::bc() * CB, tid = threadIdx.x;
         const float noise = softplus_f(x[0]) + NOISE_LB, os = softplus_f(x[1]), ls = softplus_f(x[2]);
-        const float d1n = sigmoid_f(x[0]), d1s = sigmoid_f(x[1]), d1l = sigmoid_f(x[2]);
         const float il2 = 1.f / (ls * ls), gl = -2.f / ls;
 #pragma unroll
         for (int r = 0; r < RB; ++r)
@@ -117,30 +149,7 @@ struct InnerEval {
             acc[4] = sm.vec_in[tid] * a;
         }
         block_sum<5, NT>(acc, sm.red);
-        const float trAinvG = acc[0], aGa = acc[1], trAinv = acc[2], aa = acc[3], ya = acc[4];
-        const float fn = (float)n;
-        const float nll = 0.5f * ya + 0.5f * logdet + 0.5f * fn * LOG_2PI;
-        // LogNormal priors on the transformed values (oracle/closed_form.py::lognormal_terms)
-        float lp = 0.f, dpn = 0.f, dpl = 0.f;
-        if (pri[1] > 0.f) {
-            const float lx = logf(noise), sc = pri[1], z = (lx - pri[0]) / (sc * sc);
-            lp += -lx - logf(sc) - 0.5f * LOG_2PI - 0.5f * (lx - pri[0]) * z;
-            dpn = (-1.f - z) / noise;
-        }
-        if (pri[3] > 0.f) {
-            const float lx = logf(ls), sc = pri[3], z = (lx - pri[2]) / (sc * sc);
-            lp += -lx - logf(sc) - 0.5f * LOG_2PI - 0.5f * (lx - pri[2]) * z;
-            dpl = (-1.f - z) / ls;
-        }
-        f = (nll - lp) / fn;
-        const float gt0 = 0.5f * trAinv - 0.5f * aa - dpn;
-        const float gt1 = (0.5f * (fn - noise * trAinv) - 0.5f * (ya - noise * aa)) / os;
-        const float gt2 = 0.5f * trAinvG - 0.5f * aGa - dpl;
-        g[0] = gt0 * d1n / fn;
-        g[1] = gt1 * d1s / fn;
-        g[2] = gt2 * d1l / fn;
-        extra[0] = logdet; extra[1] = trAinv; extra[2] = aa; extra[3] = ya; extra[4] = trAinvG; extra[5] = aGa;
-        extra[6] = gt0; extra[7] = gt1; extra[8] = gt2;
+        inner_finalize(n, x, pri, logdet, acc, f, g, extra);
         if (info != 0 || !(f == f)) {
             f = INFINITY;
             return info != 0 ? info : n + 1;
@@ -271,6 +280,18 @@ __device__ __forceinline__ void fit_advance(FitShared& fs, const InnerArgs& a, f
     fs.phase = phase;
 }
 
+// The per-task scalars later stages (Hessian, outer NLL, mixed term) read back from the workspace.
+__device__ __forceinline__ void write_inner_scal(float* sc, const float* xe, float f, const float* g, const float* extra) {
+    sc[S_NOISE] = softplus_f(xe[0]) + NOISE_LB; sc[S_OS] = softplus_f(xe[1]); sc[S_LS] = softplus_f(xe[2]);
+    const float sn = sigmoid_f(xe[0]), ss_ = sigmoid_f(xe[1]), sl = sigmoid_f(xe[2]);
+    sc[S_D1N] = sn; sc[S_D1S] = ss_; sc[S_D1L] = sl;
+    sc[S_D2N] = sn * (1.f - sn); sc[S_D2S] = ss_ * (1.f - ss_); sc[S_D2L] = sl * (1.f - sl);
+    sc[S_FIN] = f; sc[S_GIN0] = g[0]; sc[S_GIN1] = g[1]; sc[S_GIN2] = g[2];
+    sc[S_LOGDET] = extra[0]; sc[S_TRAINV] = extra[1]; sc[S_AA] = extra[2]; sc[S_YA] = extra[3];
+    sc[S_TRAINVG] = extra[4]; sc[S_AGA] = extra[5];
+    sc[S_GT0] = extra[6]; sc[S_GT1] = extra[7]; sc[S_GT2] = extra[8];
+}
+
 template <int NMAX, int NT, int KIND>
 __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
     using EV = InnerEval<NMAX, NT, KIND>;
@@ -322,17 +343,7 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
         if (a.g_out) { a.g_out[t * 3 + 0] = g[0]; a.g_out[t * 3 + 1] = g[1]; a.g_out[t * 3 + 2] = g[2]; }
         if (a.gnorm_out) a.gnorm_out[t] = fmaxf(fabsf(g[0]), fmaxf(fabsf(g[1]), fabsf(g[2])));
         if (a.nevals_out) a.nevals_out[t] = evals;
-        if (a.scal) {
-            float* sc = a.scal + (size_t)t * NSCAL;
-            sc[S_NOISE] = softplus_f(xe[0]) + NOISE_LB; sc[S_OS] = softplus_f(xe[1]); sc[S_LS] = softplus_f(xe[2]);
-            const float sn = sigmoid_f(xe[0]), ss_ = sigmoid_f(xe[1]), sl = sigmoid_f(xe[2]);
-            sc[S_D1N] = sn; sc[S_D1S] = ss_; sc[S_D1L] = sl;
-            sc[S_D2N] = sn * (1.f - sn); sc[S_D2S] = ss_ * (1.f - ss_); sc[S_D2L] = sl * (1.f - sl);
-            sc[S_FIN] = f; sc[S_GIN0] = g[0]; sc[S_GIN1] = g[1]; sc[S_GIN2] = g[2];
-            sc[S_LOGDET] = extra[0]; sc[S_TRAINV] = extra[1]; sc[S_AA] = extra[2]; sc[S_YA] = extra[3];
-            sc[S_TRAINVG] = extra[4]; sc[S_AGA] = extra[5];
-            sc[S_GT0] = extra[6]; sc[S_GT1] = extra[7]; sc[S_GT2] = extra[8];
-        }
+        if (a.scal) write_inner_scal(a.scal + (size_t)t * NSCAL, xe, f, g, extra);
     }
     if (a.vecs && tid < n) a.vecs[((size_t)t * NVEC + V_ALPHA) * a.vld + tid] = sm.vec_out[tid];
     if (a.Ainv) {

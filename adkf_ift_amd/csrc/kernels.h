@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64) void k_solve_v(SolveArgs a) {
 
 // ---- row/column sums of the weight matrices -> the diagonal coefficients of the dZ GEMMs -----------------
 // coef_s[i] = 2 (2 rowsum(W_ss)[i] + colsum(W_qs)[i]);  coef_q[i] = 2 (rowsum(W_qs)[i] + 2 rowsum(W_qq)[i])
-struct RowsumArgs { TaskView tv; const float* Wss; const float* Wqs; const float* Wqq; float* vecs; int T; };
+struct RowsumArgs { TaskView tv; const float* Wss; const float* Wqs; const float* Wqq; float* vecs; int T; int ext_colsum; };  // ext_colsum: V_CS_QS already holds the column sums (large.h)
 
 __global__ __launch_bounds__(SMALL_NT) void k_rowsums(RowsumArgs a) {
     constexpr int NT = SMALL_NT, NW = NT / 64;
@@ -396,9 +396,9 @@ __global__ __launch_bounds__(SMALL_NT) void k_rowsums(RowsumArgs a) {
     const float* Wqq = a.Wqq ? a.Wqq + (size_t)t * a.tv.nq_ld * a.tv.nq_ld : nullptr;
     float* vb = a.vecs + (size_t)t * NVEC * a.tv.vld;
     // column sums of W_qs: every wave sums its share of the rows for all columns (coalesced), partials meet in LDS
-    constexpr int CMAX = 256;  // >= adkf_max_points()
+    constexpr int CMAX = 256;  // larger support sets come with ext_colsum
     __shared__ float cpart[NW][CMAX];
-    if (m > 0) {
+    if (m > 0 && !a.ext_colsum) {
         for (int j = lane; j < n; j += 64) {
             float s = 0.f;
             for (int i = wv; i < m; i += NW) s += Wqs[(size_t)i * a.tv.ns_ld + j];
@@ -412,8 +412,11 @@ __global__ __launch_bounds__(SMALL_NT) void k_rowsums(RowsumArgs a) {
         s = wave_sum(s);
         if (lane == 0) {
             float cs = 0.f;
-            if (m > 0)
-                for (int w = 0; w < NW; ++w) cs += cpart[w][i];
+            if (m > 0) {
+                if (a.ext_colsum) cs = vb[V_CS_QS * a.tv.vld + i];
+                else
+                    for (int w = 0; w < NW; ++w) cs += cpart[w][i];
+            }
             vb[V_RS_SS * a.tv.vld + i] = 4.f * s + 2.f * cs;
         }
     }

@@ -1,0 +1,366 @@
+// Support / query sets beyond the register-resident sweep (more than 128 points): the same symmetric sweep, blocked by
+// LB = 128 pivots over a matrix that lives in HBM / L2, with the O(N^3) part on the fp32 MFMA (k_bgemm):
+//
+//   per block step P = [p0, p0 + 128):
+//     k_lg_diag     one workgroup per task: D = M_PP into registers, factor.h sweep  ->  Dinv, pivots (log-det, info)
+//     ProbLgPanel   F = Dinv * M_P.   (128 x n, K = 128); the epilogue also snapshots C = M_P.
+//     ProbLgUpdate  M_RR -= C_R^T F_R (n x n, K = 128);  pivot-row / pivot-column / pivot-block tiles do no product,
+//                   their epilogue writes F_R, F_R^T and -Dinv
+//   after the last step M = -(A^-1).
+//
+// One MLL evaluation = k_lg_build (kernel matrix from the squared distances) + the block steps + k_lg_matvec (alpha) +
+// k_lg_traces (the three O(N^2) reductions; also flips the sign in place) + k_lg_advance (value, gradient, and one
+// transition of the SAME BFGS/Armijo state machine k_inner runs, fit_advance(), on state kept in the workspace).
+// The host enqueues max_evals evaluations back to back without synchronising; tasks that have finished are skipped by
+// every kernel (phase == PH_DONE).  The outer factorisation of S reuses the block steps.
+#pragma once
+#include "kernels.h"
+
+namespace adkf {
+
+constexpr int LB = 128;
+enum { PH_DONE = 4 };
+
+// The matrix being swept in place (per task) and the side buffers of one block step.
+struct LgMat {
+    float* M; int ld; const int32_t* n_arr;
+    const FitShared* fit;   // null: every task is active
+    float* Dinv;            // [T, LB, LB]
+    float* Cbuf;            // [T, LB, ld]
+    float* Fbuf;            // [T, LB, ld]
+    float* logdet;          // [T] running log-determinant
+    int32_t* info;          // [T] first non-positive pivot (1-based) or 0
+    int T; bool vec;
+    __device__ __forceinline__ bool active(int t) const { return !fit || fit[t].phase != PH_DONE; }
+    __device__ __forceinline__ int n(int t) const { return n_arr ? n_arr[t] : ld; }
+};
+
+__global__ __launch_bounds__(512) void k_lg_diag(LgMat a, int step) {
+    using SW = Sweep<128, 512>;
+    constexpr int RB = SW::RB, CB = SW::CB;
+    __shared__ SweepSmem<128, 512> sm;
+    int t, tile;
+    if (!task_tile(a.T, 1, t, tile)) return;
+    if (!a.active(t)) return;
+    const int n = a.n(t), p0 = step * LB;
+    const int nloc = min(LB, n - p0);
+    if (nloc <= 0) return;
+    const float* Mi = a.M + (size_t)t * a.ld * a.ld;
+    float m[RB][CB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int i = SW::row(r), j = SW::col(c);
+            const int hi = i > j ? i : j, lo = i > j ? j : i;  // exactly symmetric input to the sweep
+            m[r][c] = (i < nloc && j < nloc) ? Mi[(size_t)(p0 + hi) * a.ld + p0 + lo] : (i == j ? 1.f : 0.f);
+        }
+    __syncthreads();
+    SW::run(m, nloc, sm);
+    float logdet;
+    const int info = SW::finish(nloc, sm, logdet);
+    float* Dv = a.Dinv + (size_t)t * LB * LB;
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) Dv[SW::row(r) * LB + SW::col(c)] = -m[r][c];
+    if (threadIdx.x == 0) {
+        a.logdet[t] = (step == 0 ? 0.f : a.logdet[t]) + logdet;
+        const int prev = step == 0 ? 0 : a.info[t];
+        a.info[t] = prev != 0 ? prev : (info != 0 ? p0 + info : 0);
+    }
+}
+
+struct ProbLgPanel {
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = false;
+    static constexpr int NRED = 0;
+    LgMat m; int step;
+    int n, p0, nloc; const float *Dv, *Mi; float *Cb, *Fb; bool vec;
+    __device__ bool setup(int t) {
+        if (!m.active(t)) return false;
+        n = m.n(t); p0 = step * LB; nloc = min(LB, n - p0); vec = m.vec;
+        if (nloc <= 0) return false;
+        Dv = m.Dinv + (size_t)t * LB * LB; Mi = m.M + (size_t)t * m.ld * m.ld;
+        Cb = m.Cbuf + (size_t)t * LB * m.ld; Fb = m.Fbuf + (size_t)t * LB * m.ld;
+        return true;
+    }
+    __device__ int M() const { return nloc; } __device__ int N() const { return n; } __device__ int K() const { return nloc; }
+    __device__ bool skip(int, int n0) const { return n0 >= p0 && n0 < p0 + LB; }  // F_P is never read
+    __device__ float a(int i, int k) const { return Dv[i * LB + k]; }
+    __device__ float b(int k, int j) const { return Mi[(size_t)(p0 + k) * m.ld + j]; }
+    __device__ void a4(int i, int k, float (&v)[4]) const { ld4(Dv + i * LB + k, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(Mi + (size_t)(p0 + k) * m.ld + j, v); }
+    __device__ void epi(int i, int j, float acc, float*) const {
+        Fb[(size_t)i * m.ld + j] = acc;
+        Cb[(size_t)i * m.ld + j] = Mi[(size_t)(p0 + i) * m.ld + j];
+    }
+    __device__ void store_red(int, const float*) const {}
+};
+
+struct ProbLgUpdate {
+    static constexpr bool A_KCONTIG = false, B_KCONTIG = false;
+    static constexpr int NRED = 0;
+    LgMat m; int step;
+    int n, p0, nloc; const float *Dv, *Cb, *Fb; float* Mi; bool vec;
+    __device__ bool setup(int t) {
+        if (!m.active(t)) return false;
+        n = m.n(t); p0 = step * LB; nloc = min(LB, n - p0); vec = m.vec;
+        if (nloc <= 0) return false;
+        Dv = m.Dinv + (size_t)t * LB * LB; Mi = m.M + (size_t)t * m.ld * m.ld;
+        Cb = m.Cbuf + (size_t)t * LB * m.ld; Fb = m.Fbuf + (size_t)t * LB * m.ld;
+        return true;
+    }
+    __device__ int M() const { return n; } __device__ int N() const { return n; } __device__ int K() const { return nloc; }
+    __device__ bool in_p(int i) const { return i >= p0 && i < p0 + LB; }
+    __device__ bool skip(int m0, int n0) const { return in_p(m0) || in_p(n0); }
+    __device__ float a(int i, int k) const { return Cb[(size_t)k * m.ld + i]; }
+    __device__ float b(int k, int j) const { return Fb[(size_t)k * m.ld + j]; }
+    __device__ void a4(int i, int k, float (&v)[4]) const { ld4(Cb + (size_t)k * m.ld + i, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(Fb + (size_t)k * m.ld + j, v); }
+    __device__ void epi(int i, int j, float acc, float*) const {
+        float* dst = Mi + (size_t)i * m.ld + j;
+        const bool pi = in_p(i), pj = in_p(j);
+        if (!pi && !pj) *dst -= acc;
+        else if (pi && pj) *dst = -Dv[(i - p0) * LB + (j - p0)];
+        else if (pi) *dst = Fb[(size_t)(i - p0) * m.ld + j];
+        else *dst = Fb[(size_t)(j - p0) * m.ld + i];
+    }
+    __device__ void store_red(int, const float*) const {}
+};
+
+// out[i] = sign * sum_j M_ij x_j   (wave per row; grid: ceil(ld / 4) x T)
+struct LgMatvecArgs { LgMat m; const float* x; size_t x_stride; float* out; size_t out_stride; float sign; };
+
+__global__ __launch_bounds__(256) void k_lg_matvec(LgMatvecArgs a) {
+    const int t = blockIdx.y;
+    if (!a.m.active(t)) return;
+    const int n = a.m.n(t), i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const float* row = a.m.M + ((size_t)t * a.m.ld + i) * a.m.ld;
+    const float* x = a.x + (size_t)t * a.x_stride;
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s += row[j] * x[j];
+    s = wave_sum(s);
+    if (lane == 0) a.out[(size_t)t * a.out_stride + i] = a.sign * s;
+}
+
+// ---- inner (support) side ------------------------------------------------------------------------------------
+struct LgInner {
+    InnerArgs in;       // the same argument block k_inner takes
+    LgMat mat;          // mat.M = in.Ainv
+    FitShared* fit;     // [T]
+    float* part;        // [T, ntiles, 4] partial reductions of k_lg_traces
+    int ntiles, tiles_1d;
+};
+
+__global__ void k_lg_begin(LgInner a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.in.T) return;
+    FitShared& fs = a.fit[t];
+    for (int q = 0; q < 3; ++q) { fs.st.x[q] = a.in.phi[t * 3 + q]; fs.xe[q] = fs.st.x[q]; }
+    fs.st.reset_H();
+    fs.st.f = INFINITY;
+    fs.phase = (a.in.max_evals > 0) ? PH_INIT : PH_FINAL;
+    fs.evals = 0;
+}
+
+// M = s kappa(D2 / l^2) + noise I at the trial point of the task's state machine (64 x 64 tile per workgroup)
+__global__ __launch_bounds__(256) void k_lg_build(LgInner a) {
+    int t, tile;
+    if (!task_tile(a.in.T, a.ntiles, t, tile)) return;
+    if (!a.mat.active(t)) return;
+    const int n = a.mat.n(t), ld = a.in.ld;
+    const int m0 = (tile / a.tiles_1d) * GT, n0 = (tile % a.tiles_1d) * GT;
+    if (m0 >= n || n0 >= n) return;
+    const FitShared& fs = a.fit[t];
+    const float noise = softplus_f(fs.xe[0]) + NOISE_LB, os = softplus_f(fs.xe[1]), ls = softplus_f(fs.xe[2]);
+    const float il2 = 1.f / (ls * ls);
+    const float* D2 = a.in.D2ss + (size_t)t * ld * ld;
+    float* Mi = a.mat.M + (size_t)t * ld * ld;
+    for (int e = threadIdx.x; e < GT * GT; e += 256) {
+        const int i = m0 + (e >> 6), j = n0 + (e & 63);
+        if (i < n && j < n) Mi[(size_t)i * ld + j] = os * kappa0(a.in.kind, D2[(size_t)i * ld + j] * il2) + (i == j ? noise : 0.f);
+    }
+}
+
+// After the sweep M = -(A^-1): flip the sign in place and reduce tr(Ainv G), alpha^T G alpha, tr(Ainv) per tile.
+__global__ __launch_bounds__(256) void k_lg_traces(LgInner a) {
+    __shared__ float red[3 * 4];
+    int t, tile;
+    if (!task_tile(a.in.T, a.ntiles, t, tile)) return;
+    if (!a.mat.active(t)) return;
+    const int n = a.mat.n(t), ld = a.in.ld;
+    const int m0 = (tile / a.tiles_1d) * GT, n0 = (tile % a.tiles_1d) * GT;
+    float acc[3] = {0.f, 0.f, 0.f};
+    if (m0 < n && n0 < n) {
+        const FitShared& fs = a.fit[t];
+        const float os = softplus_f(fs.xe[1]), ls = softplus_f(fs.xe[2]);
+        const float il2 = 1.f / (ls * ls), gl = -2.f / ls;
+        const float* D2 = a.in.D2ss + (size_t)t * ld * ld;
+        float* Mi = a.mat.M + (size_t)t * ld * ld;
+        const float* al = a.in.vecs + ((size_t)t * NVEC + V_ALPHA) * a.in.vld;
+        for (int e = threadIdx.x; e < GT * GT; e += 256) {
+            const int i = m0 + (e >> 6), j = n0 + (e & 63);
+            if (i < n && j < n) {
+                const float ai = -Mi[(size_t)i * ld + j];
+                Mi[(size_t)i * ld + j] = ai;
+                float k0, k1, k2;
+                const float u = D2[(size_t)i * ld + j] * il2;
+                kappa3(a.in.kind, u, k0, k1, k2);
+                const float G = os * k1 * u * gl;
+                acc[0] += ai * G;
+                acc[1] += al[i] * al[j] * G;
+                if (i == j) acc[2] += ai;
+            }
+        }
+    }
+    block_sum<3, 256>(acc, red);
+    if (threadIdx.x == 0) {
+        float* p = a.part + ((size_t)t * a.ntiles + tile) * 4;
+        p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2];
+    }
+}
+
+// One wave per task: finish the evaluation, then either advance the optimiser or publish the final results.
+__global__ __launch_bounds__(64) void k_lg_advance(LgInner a) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= a.in.T) return;
+    FitShared& fs = a.fit[t];
+    if (fs.phase == PH_DONE) return;
+    const int n = a.mat.n(t);
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int q = lane; q < a.ntiles; q += 64) {
+        const float* p = a.part + ((size_t)t * a.ntiles + q) * 4;
+        acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2];
+    }
+    const float* al = a.in.vecs + ((size_t)t * NVEC + V_ALPHA) * a.in.vld;
+    const float* y = a.in.y_s + (size_t)t * a.in.ld;
+    for (int i = lane; i < n; i += 64) { const float v = al[i]; acc[3] += v * v; acc[4] += y[i] * v; }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) acc[q] = wave_sum(acc[q]);
+    if (lane != 0) return;
+    float xe[3] = {fs.xe[0], fs.xe[1], fs.xe[2]}, pri[4], f, g[3], extra[9];
+    for (int q = 0; q < 4; ++q) pri[q] = a.in.priors[t * 4 + q];
+    inner_finalize(n, xe, pri, a.mat.logdet[t], acc, f, g, extra);
+    int ie = a.mat.info[t];
+    if (ie != 0 || !(f == f)) { f = INFINITY; ie = ie != 0 ? ie : n + 1; }
+    if (fs.phase != PH_FINAL) { fit_advance(fs, a.in, f, g, ie); return; }
+    const InnerArgs& o = a.in;
+    if (o.max_evals > 0) { o.phi[t * 3 + 0] = xe[0]; o.phi[t * 3 + 1] = xe[1]; o.phi[t * 3 + 2] = xe[2]; }
+    o.info[t] = ie;
+    if (o.f_out) o.f_out[t] = f;
+    if (o.g_out) { o.g_out[t * 3 + 0] = g[0]; o.g_out[t * 3 + 1] = g[1]; o.g_out[t * 3 + 2] = g[2]; }
+    if (o.gnorm_out) o.gnorm_out[t] = fmaxf(fabsf(g[0]), fmaxf(fabsf(g[1]), fabsf(g[2])));
+    if (o.nevals_out) o.nevals_out[t] = fs.evals + 1;
+    if (o.scal) write_inner_scal(o.scal + (size_t)t * NSCAL, xe, f, g, extra);
+    fs.phase = PH_DONE;
+}
+
+// ---- outer (query) side --------------------------------------------------------------------------------------
+// mu = C y_s, r = y_q - mu  (wave per row; grid: ceil(nq_ld / 4) x T)
+__global__ __launch_bounds__(256) void k_lg_resid(OuterArgs a) {
+    const int t = blockIdx.y;
+    const int n = a.tv.ns(t), m = a.tv.nq(t), i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= m) return;
+    const float* row = a.C + ((size_t)t * a.tv.nq_ld + i) * a.tv.ns_ld;
+    const float* ys = a.y_s + (size_t)t * a.tv.ns_ld;
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s += row[j] * ys[j];
+    s = wave_sum(s);
+    if (lane == 0) {
+        float* vb = a.vecs + (size_t)t * NVEC * a.tv.vld;
+        vb[V_MU * a.tv.vld + i] = s;
+        vb[V_R * a.tv.vld + i] = a.y_q[(size_t)t * a.tv.nq_ld + i] - s;
+    }
+}
+
+// S := -S in place (64 x 64 tile per workgroup)
+__global__ __launch_bounds__(256) void k_lg_negate(LgMat a, int tiles_1d) {
+    int t, tile;
+    if (!task_tile(a.T, tiles_1d * tiles_1d, t, tile)) return;
+    const int n = a.n(t);
+    const int m0 = (tile / tiles_1d) * GT, n0 = (tile % tiles_1d) * GT;
+    if (m0 >= n || n0 >= n) return;
+    float* Mi = a.M + (size_t)t * a.ld * a.ld;
+    for (int e = threadIdx.x; e < GT * GT; e += 256) {
+        const int i = m0 + (e >> 6), j = n0 + (e & 63);
+        if (i < n && j < n) Mi[(size_t)i * a.ld + j] = -Mi[(size_t)i * a.ld + j];
+    }
+}
+
+// f_out = (r^T e + log|S| + m log 2 pi) / 2,  Cte = C^T e  (one workgroup per task)
+struct LgOuterFin { OuterArgs o; const float* logdet; const int32_t* info_s; };
+
+__global__ __launch_bounds__(1024) void k_lg_outer_fin(LgOuterFin a) {
+    constexpr int NT = 1024;
+    __shared__ float red[NT / 64];
+    int t, tile;
+    if (!task_tile(a.o.T, 1, t, tile)) return;
+    const TaskView& tv = a.o.tv;
+    const int n = tv.ns(t), m = tv.nq(t), tid = threadIdx.x;
+    float* vb = a.o.vecs + (size_t)t * NVEC * tv.vld;
+    const float* ev = vb + V_E * tv.vld;
+    const float* rv = vb + V_R * tv.vld;
+    float q[1] = {0.f};
+    for (int i = tid; i < m; i += NT) q[0] += rv[i] * ev[i];
+    block_sum<1, NT>(q, red);
+    const float* Ci = a.o.C + (size_t)t * tv.nq_ld * tv.ns_ld;
+    for (int j = tid; j < n; j += NT) {
+        float s = 0.f;
+        for (int i = 0; i < m; ++i) s += Ci[(size_t)i * tv.ns_ld + j] * ev[i];
+        vb[V_CTE * tv.vld + j] = s;
+    }
+    if (tid == 0) {
+        const float logdet = a.logdet[t];
+        const int info = a.info_s[t];
+        const float f = 0.5f * q[0] + 0.5f * logdet + 0.5f * (float)m * LOG_2PI;
+        a.o.scal[(size_t)t * NSCAL + S_FOUT] = f;
+        a.o.scal[(size_t)t * NSCAL + S_LOGDETS] = logdet;
+        if (a.o.f_out) a.o.f_out[t] = (info == 0) ? f : NAN;
+        if (info != 0 && a.o.info[t] == 0) a.o.info[t] = 100000 + info;
+    }
+}
+
+// column sums of W_qs for k_rowsums when the query set does not fit its LDS staging (thread per column)
+__global__ __launch_bounds__(256) void k_lg_colsum(RowsumArgs a) {
+    const int t = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    const int n = a.tv.ns(t), m = a.tv.nq(t);
+    if (j >= n) return;
+    const float* Wqs = a.Wqs + (size_t)t * a.tv.nq_ld * a.tv.ns_ld;
+    float s = 0.f;
+    for (int i = 0; i < m; ++i) s += Wqs[(size_t)i * a.tv.ns_ld + j];
+    a.vecs[((size_t)t * NVEC + V_CS_QS) * a.tv.vld + j] = s;
+}
+
+// Median heuristic for more than 256 points: same 31-step radix select as k_median, candidates re-read from L2.
+__global__ __launch_bounds__(1024) void k_median_large(const float* D2ss, const int32_t* n_s, int ld, float* l0, int T) {
+    constexpr int NT = 1024;
+    __shared__ int red[NT / 64];
+    int t, tile;
+    if (!task_tile(T, 1, t, tile)) return;
+    const int n = n_s ? n_s[t] : ld, tid = threadIdx.x;
+    const uint32_t* D = reinterpret_cast<const uint32_t*>(D2ss + (size_t)t * ld * ld);
+    // rows are dealt to waves, columns to lanes: coalesced, and no integer division per element
+    const int lane = tid & 63, wv = tid >> 6;
+    int cnt = 0;
+    for (int i = wv; i < n; i += NT / 64)
+        for (int j = i + 1 + lane; j < n; j += 64) cnt += (D[(size_t)i * ld + j] != 0u);
+    const int total = block_sum_i<NT>(cnt, red);
+    if (total == 0) { if (tid == 0) l0[t] = 0.f; return; }
+    int rank = (total - 1) / 2;
+    uint32_t prefix = 0;
+    for (int bit = 30; bit >= 0; --bit) {
+        const uint32_t hi_mask = ~((1u << bit) - 1u);
+        int c0 = 0;
+        for (int i = wv; i < n; i += NT / 64)
+            for (int j = i + 1 + lane; j < n; j += 64) {
+                const uint32_t v = D[(size_t)i * ld + j];
+                c0 += (v != 0u && (v & hi_mask) == prefix);
+            }
+        c0 = block_sum_i<NT>(c0, red);
+        if (rank >= c0) { rank -= c0; prefix |= (1u << bit); }
+    }
+    if (tid == 0) l0[t] = sqrtf(0.5f * __uint_as_float(prefix));
+}
+
+}  // namespace adkf

@@ -176,15 +176,17 @@ def test_argument_errors(dev):
         gp_ops.GPBatch(torch.zeros(1, 4, 2), torch.zeros(1, 4), torch.zeros(1, 4))  # CPU tensors: no fallback
     with pytest.raises(ValueError):
         gp_ops.kernel_id("cossim")
-    big = gp_ops.GPBatch(torch.zeros(1, 300, 2, device=dev), torch.zeros(1, 300, device=dev), torch.zeros(1, 4, device=dev))
+    big = gp_ops.GPBatch(torch.zeros(1, 4100, 2, device=dev), torch.zeros(1, 4100, device=dev), torch.zeros(1, 4, device=dev))
     with pytest.raises(RuntimeError):
         gp_ops.median_lengthscale(big)
 
 
-@pytest.mark.parametrize("N,Nq,d,kernel", [(200, 256, 64, "rbf"), (256, 160, 48, "matern"), (130, 129, 32, "rbf")])
-def test_up_to_256_points_against_live_oracle(dev, N, Nq, d, kernel):
-    """The 1024-lane / 64-elements-per-lane configuration (129..256 support or query points): no committed fixture,
-    so the float64 oracle is evaluated live (tests may call the oracle) on seeded synthetic tasks, ragged sizes."""
+@pytest.mark.parametrize("N,Nq,d,kernel", [(200, 256, 64, "rbf"), (256, 160, 48, "matern"), (130, 129, 32, "rbf"),
+                                           (16, 256, 64, "matern"), (384, 300, 64, "rbf"), (516, 132, 40, "matern")])
+def test_blocked_path_against_live_oracle(dev, N, Nq, d, kernel):
+    """More than 128 support or query points: the blocked sweep (csrc/large.h).  No committed fixture, so the float64
+    oracle is evaluated live (tests may call the oracle) on seeded synthetic tasks with ragged sizes - including tasks
+    whose real size would fit the register path and sizes that are not multiples of the 128-pivot block."""
     from adkf_ift_amd import gp_ops
     from adkf_ift_amd.synthetic import make_tasks
     from oracle import gp_oracle as O
@@ -192,7 +194,7 @@ def test_up_to_256_points_against_live_oracle(dev, N, Nq, d, kernel):
     T = 3
     tasks = make_tasks(T, N, d, N_q=Nq, first_task=40)
     Zs, Zq = tasks.features()
-    n_s = torch.tensor([N, N - 7, N - 64])
+    n_s = torch.tensor([N, N - 7, max(N - 64, 5)])
     n_q = torch.tensor([Nq, Nq - 1, Nq - 100])
     kind = gp_ops.kernel_id(kernel)
     pri = torch.empty(T, 4, device=dev)
@@ -216,3 +218,33 @@ def test_up_to_256_points_against_live_oracle(dev, N, Nq, d, kernel):
         assert rel(out["dZ_q"][t, :nq].cpu().numpy(), q["dZq_total"]) <= TOL
         assert float(out["dZ_s"][t, ns:].abs().max() if ns < N else 0.0) == 0.0
         assert gn[t].item() <= 5e-4
+
+
+def test_c5_large_support_regime(dev):
+    """BASELINE.json config C5: N_support = 1024, d = 512 (one task against the live float64 oracle)."""
+    from adkf_ift_amd import gp_ops
+    from adkf_ift_amd.synthetic import make_tasks
+    from oracle import gp_oracle as O
+
+    N, Nq, d, T = 1024, 1024, 512, 2
+    tasks = make_tasks(T, N, d, N_q=Nq, first_task=7)
+    Zs, Zq = tasks.features()
+    pri = torch.empty(T, 4, device=dev)
+    b = gp_ops.GPBatch(Zs.to(dev), tasks.y_s.to(dev), pri, "rbf", Z_q=Zq.to(dev), y_q=tasks.y_q.to(dev))
+    phi0, l0 = gp_ops.init_params_batch(b)
+    b.flags = gp_ops.REUSE_DIST
+    phi, f, gn, ne, info = gp_ops.fit(b, phi0, max_evals=40)
+    gp_ops.check_info(info)
+    b.flags = gp_ops.REUSE_DIST | gp_ops.REUSE_INNER
+    out = gp_ops.ift_hypergrad(b, phi)
+    gp_ops.check_info(out["info"])
+    t = 1
+    p = O.Priors(*pri[t].double().cpu().tolist())
+    l0_ref = O.median_lengthscale_init(Zs[t].double()).item()
+    assert abs(l0[t].item() - l0_ref) <= 1e-5 * l0_ref
+    q = O.full_reference_quantities(Zs[t], tasks.y_s[t], Zq[t], tasks.y_q[t], phi[t].double().cpu(), p, 0)
+    assert rel(f[t].item(), q["f_in"]) <= TOL and rel(out["f_out"][t].item(), q["f_out"]) <= TOL
+    assert rel(out["H"][t].cpu().numpy(), q["H"]) <= TOL
+    assert rel(out["v"][t].cpu().numpy(), q["v"]) <= TOL
+    assert rel(out["dZ_s"][t].cpu().numpy(), q["dZs_total"]) <= TOL
+    assert rel(out["dZ_q"][t].cpu().numpy(), q["dZq_total"]) <= TOL
