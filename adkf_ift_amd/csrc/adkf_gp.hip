@@ -19,7 +19,7 @@ struct Workspace {
     float *mean, *nrm_s, *nrm_q, *D2ss, *D2qs, *D2qq, *Ainv, *P, *C, *S, *OC, *Wss, *Wqs, *Wqq, *vecs, *scal, *part_oc, *part_ma, *l0;
     // blocked path only (max(ns, nq) > REG_POINTS)
     float *lg_Dinv, *lg_C, *lg_F, *lg_logdet, *lg_part;
-    int32_t* lg_info;
+    int32_t *lg_info, *lg_med;  // lg_med: prefix[T], rank[T], hist[T, 256]
     FitShared* lg_fit;
     int vld, nt_oc, nt_ma;
     size_t bytes;
@@ -52,14 +52,16 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
     w.part_oc = take(Tz * (w.nt_oc > 0 ? w.nt_oc : 1) * 4);
     w.part_ma = take(Tz * w.nt_ma * 4);
     w.l0 = take(Tz);
-    w.lg_Dinv = w.lg_C = w.lg_F = w.lg_logdet = w.lg_part = nullptr; w.lg_info = nullptr; w.lg_fit = nullptr;
+    w.lg_Dinv = w.lg_C = w.lg_F = w.lg_logdet = w.lg_part = nullptr; w.lg_info = w.lg_med = nullptr; w.lg_fit = nullptr;
     if (w.vld > REG_POINTS) {
         w.lg_Dinv = take(Tz * LB * LB);
         w.lg_C = take(Tz * LB * w.vld);
         w.lg_F = take(Tz * LB * w.vld);
         w.lg_logdet = take(Tz);
-        w.lg_part = take(Tz * w.nt_ma * 4);
+        const size_t tq = (size_t)((nq + GT - 1) / GT) * ((nq + GT - 1) / GT);
+        w.lg_part = take(Tz * ((size_t)w.nt_ma > tq ? (size_t)w.nt_ma : tq) * 8);
         w.lg_info = reinterpret_cast<int32_t*>(take(Tz));
+        w.lg_med = reinterpret_cast<int32_t*>(take(Tz * 258));
         w.lg_fit = reinterpret_cast<FitShared*>(take(Tz * ((sizeof(FitShared) + 3) / 4)));
     }
     w.bytes = off;
@@ -194,8 +196,11 @@ int launch_outer_factor(const OuterArgs& a, const Workspace& w, int nq, hipStrea
         k_lg_matvec<<<dim3(ceil_div(nq, 4), a.T), 256, 0, st>>>(mv);
         const int tn = ceil_div(nq, GT);
         k_lg_negate<<<grid_for(a.T, tn * tn), 256, 0, st>>>(m, tn);
+        LgColsumArgs cs{a.C, a.tv.ns_ld, (size_t)a.tv.nq_ld * a.tv.ns_ld, a.tv.n_q, a.tv.nq_ld, a.tv.n_s, a.tv.ns_ld,
+                        a.vecs + (size_t)V_E * a.tv.vld, (size_t)NVEC * a.tv.vld, a.vecs + (size_t)V_CTE * a.tv.vld, (size_t)NVEC * a.tv.vld};
+        k_lg_colsum<<<dim3(ceil_div(a.tv.ns_ld, 64), a.T), 1024, 0, st>>>(cs);
         LgOuterFin fin{a, w.lg_logdet, w.lg_info};
-        k_lg_outer_fin<<<grid_for(a.T, 1), 1024, 0, st>>>(fin);
+        k_lg_outer_fin<<<a.T, 64, 0, st>>>(fin);
         LAUNCH_OK();
         return 0;
     }
@@ -205,6 +210,18 @@ int launch_outer_factor(const OuterArgs& a, const Workspace& w, int nq, hipStrea
     else k_outer_factor<128, 512><<<grid_for(a.T, 1), 512, 0, st>>>(a);
     LAUNCH_OK();
     return 0;
+}
+
+void launch_rowsums(const RowsumArgs& ra, const Workspace& w, hipStream_t st) {
+    const TaskView& tv = ra.tv;
+    if (w.vld <= REG_POINTS) { k_rowsums<<<grid_for(ra.T, 1), SMALL_NT, 0, st>>>(ra); return; }
+    if (ra.Wqs) {
+        LgColsumArgs cs{ra.Wqs, tv.ns_ld, (size_t)tv.nq_ld * tv.ns_ld, tv.n_q, tv.nq_ld, tv.n_s, tv.ns_ld, nullptr, 0,
+                        ra.vecs + (size_t)V_CS_QS * tv.vld, (size_t)NVEC * tv.vld};
+        k_lg_colsum<<<dim3(ceil_div(tv.ns_ld, 64), ra.T), 1024, 0, st>>>(cs);
+    }
+    const int rows = tv.ns_ld > tv.nq_ld ? tv.ns_ld : tv.nq_ld;
+    k_lg_rowsums<<<dim3(ceil_div(rows, 4), ra.T), 256, 0, st>>>(ra);
 }
 
 InnerArgs inner_args(const adkf_batch_t* b, const Workspace& w, float* phi, int32_t* info) {
@@ -238,7 +255,17 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         ProbP pp; pp.tv = tv; pp.Ainv = w.Ainv; pp.D2ss = w.D2ss; pp.P = w.P;
         k_bgemm<ProbP><<<grid_for(T, tms * tms), 256, 0, st>>>(pp, T, tms, tms);
         HessArgs ha{tv, w.Ainv, w.P, w.D2ss, b->y_s, b->priors, w.scal, w.vecs, T};
-        k_hess<<<grid_for(T, 1), SMALL_NT, 0, st>>>(ha);
+        if (ns > REG_POINTS) {
+            k_lg_hess_mv<<<dim3(ceil_div(ns, 4), T), 256, 0, st>>>(ha);
+            LgMat am = lg_mat(w, w.Ainv, ns, b->n_s, nullptr, T);
+            LgMatvecArgs mv{am, w.vecs + (size_t)V_BETA * w.vld, (size_t)NVEC * w.vld, w.vecs + (size_t)V_DELTA * w.vld, (size_t)NVEC * w.vld, 1.f};
+            k_lg_matvec<<<dim3(ceil_div(ns, 4), T), 256, 0, st>>>(mv);
+            LgHessTr ht{ha, w.lg_part, tms * tms, tms};
+            k_lg_hess_tr<<<grid_for(T, tms * tms), 256, 0, st>>>(ht);
+            k_lg_hess_fin<<<T, 64, 0, st>>>(ht);
+        } else {
+            k_hess<<<grid_for(T, 1), SMALL_NT, 0, st>>>(ha);
+        }
     }
     ProbC pc; pc.tv = tv; pc.Ainv = w.Ainv; pc.D2qs = w.D2qs; pc.C = w.C;
     k_bgemm<ProbC><<<grid_for(T, tmq * tms), 256, 0, st>>>(pc, T, tmq, tms);
@@ -252,7 +279,13 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
     ProbMA pm; pm.tv = tv; pm.C = w.C; pm.OC = w.OC; pm.D2ss = w.D2ss; pm.Wss = w.Wss; pm.part = w.part_ma; pm.ntiles = w.nt_ma; pm.dirscale = dirscale;
     k_bgemm<ProbMA><<<grid_for(T, tms * tms), 256, 0, st>>>(pm, T, tms, tms);
     WqqArgs wq{tv, w.S, w.D2qq, w.Wqq, w.scal, dirscale, T};
-    k_wqq<<<grid_for(T, 1), SMALL_NT, 0, st>>>(wq);
+    if (nq > REG_POINTS) {
+        LgWqq lw{wq, w.lg_part, tmq * tmq, tmq};
+        k_lg_wqq<<<grid_for(T, tmq * tmq), 256, 0, st>>>(lw);
+        k_lg_wqq_fin<<<T, 64, 0, st>>>(lw);
+    } else {
+        k_wqq<<<grid_for(T, 1), SMALL_NT, 0, st>>>(wq);
+    }
     SolveArgs sa{tv, w.scal, w.vecs, w.part_oc, w.part_ma, w.nt_oc, w.nt_ma, flags, g_phi_out, v_out, H_out, T, with_hessian ? 1 : 0};
     k_solve_v<<<T, 64, 0, st>>>(sa);
     if (corrscale != 0.f) {
@@ -260,9 +293,8 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         k_bgemm<ProbMixed><<<grid_for(T, tms * tms), 256, 0, st>>>(px, T, tms, tms);
     }
     if (dZ_s || dZ_q) {
-        RowsumArgs ra{tv, w.Wss, w.Wqs, w.Wqq, w.vecs, T, ns > 256 ? 1 : 0};
-        if (ra.ext_colsum) k_lg_colsum<<<dim3(ceil_div(ns, 256), T), 256, 0, st>>>(ra);
-        k_rowsums<<<grid_for(T, 1), SMALL_NT, 0, st>>>(ra);
+        RowsumArgs ra{tv, w.Wss, w.Wqs, w.Wqq, w.vecs, T};
+        launch_rowsums(ra, w, st);
         const int tn = ceil_div(d, GT);
         if (dZ_s) {
             hipMemsetAsync(dZ_s, 0, (size_t)T * ns * d * sizeof(float), st);
@@ -303,7 +335,15 @@ int adkf_median_lengthscale(const adkf_batch_t* b, float* l0, void* ws, size_t w
     if (rc) return rc;
     if (b->ns_max <= 128) k_median<512, 32><<<grid_for(b->T, 1), 512, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T);
     else if (b->ns_max <= 256) k_median<1024, 64><<<grid_for(b->T, 1), 1024, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T);
-    else k_median_large<<<grid_for(b->T, 1), 1024, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T);
+    else {
+        LgMedian lm{w.D2ss, b->n_s, b->ns_max, l0, b->T, reinterpret_cast<uint32_t*>(w.lg_med), w.lg_med + b->T, w.lg_med + 2 * (size_t)b->T};
+        hipMemsetAsync(lm.hist, 0, sizeof(int) * 256 * (size_t)b->T, st);
+        const int rows_blocks = ceil_div(b->ns_max, 16) < 64 ? ceil_div(b->ns_max, 16) : 64;
+        for (int pass = 0; pass < 4; ++pass) {
+            k_lg_med_hist<<<dim3(rows_blocks, b->T), 256, 0, st>>>(lm, pass);
+            k_lg_med_pick<<<ceil_div(b->T, 64), 64, 0, st>>>(lm, pass);
+        }
+    }
     LAUNCH_OK();
     return 0;
 }
@@ -343,7 +383,7 @@ int adkf_mll_value_grad(const adkf_batch_t* b, const float* phi, float* f_in, fl
         WinArgs wa{tv, w.Ainv, w.D2ss, w.Wss, w.scal, b->T};
         k_win<<<grid_for(b->T, 1), 256, 0, st>>>(wa);
         RowsumArgs ra{tv, w.Wss, nullptr, nullptr, w.vecs, b->T};
-        k_rowsums<<<grid_for(b->T, 1), SMALL_NT, 0, st>>>(ra);
+        launch_rowsums(ra, w, st);
         hipMemsetAsync(dZ_s, 0, (size_t)b->T * b->ns_max * b->d * sizeof(float), st);
         ProbDZ<false> pz; pz.tv = tv; pz.Wss = w.Wss; pz.Wqs = nullptr; pz.Wqq = nullptr; pz.Zs = b->Z_s; pz.Zq = nullptr; pz.dZ = dZ_s; pz.d = b->d;
         const int tms = ceil_div(b->ns_max, GT), tn = ceil_div(b->d, GT);

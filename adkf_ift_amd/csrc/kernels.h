@@ -137,6 +137,30 @@ struct HessArgs { TaskView tv; const float* Ainv; const float* P; const float* D
 
 constexpr int SMALL_NT = 1024;  // the per-task elementwise/mat-vec kernels: 16 waves per task
 
+// The analytic 3x3 Hessian of f_inner in the raw parameters from the nine reductions
+// acc = {tr(Ainv^2), tr(P Ainv), tr(P P), tr(Ainv K_ll), a^T K_ll a, a^T g, b^T g, b^T d, a^T b}
+// (a = alpha, b = beta = G alpha, g = gamma = Ainv alpha, d = delta = Ainv beta) and the scalars of the evaluation.
+__device__ __forceinline__ void hess_assemble(float* sc, const float* pri, int n, const float* acc) {
+    const float noise = sc[S_NOISE], os = sc[S_OS], ls = sc[S_LS];
+    const float trA2 = acc[0], trPA = acc[1], trPP = acc[2], trAinvKll = acc[3], aKlla = acc[4], ag = acc[5], bg = acc[6], bd = acc[7], ab = acc[8];
+    const float trAinv = sc[S_TRAINV], aa = sc[S_AA], ya = sc[S_YA], trAinvG = sc[S_TRAINVG], aGa = sc[S_AGA];
+    const float fn = (float)n;
+    float h00 = ag - 0.5f * trA2;
+    const float h01 = ((aa - noise * ag) - 0.5f * (trAinv - noise * trA2)) / os;
+    const float h02 = bg - 0.5f * trPA;
+    const float h11 = ((ya - 2.f * noise * aa + noise * noise * ag) - 0.5f * (fn - 2.f * noise * trAinv + noise * noise * trA2)) / (os * os);
+    const float h12 = ((ab - noise * bg) - 0.5f * (trAinvG - noise * trPA)) / os - (0.5f * aGa - 0.5f * trAinvG) / os;
+    float h22 = bd - 0.5f * aKlla - 0.5f * trPP + 0.5f * trAinvKll;
+    // prior curvature (oracle/closed_form.py::lognormal_terms d2)
+    if (pri[1] > 0.f) { const float lx = logf(noise), s2 = pri[1] * pri[1]; h00 -= (1.f + (lx - pri[0]) / s2 - 1.f / s2) / (noise * noise); }
+    if (pri[3] > 0.f) { const float lx = logf(ls), s2 = pri[3] * pri[3]; h22 -= (1.f + (lx - pri[2]) / s2 - 1.f / s2) / (ls * ls); }
+    const float d1[3] = {sc[S_D1N], sc[S_D1S], sc[S_D1L]}, d2[3] = {sc[S_D2N], sc[S_D2S], sc[S_D2L]};
+    const float gt[3] = {sc[S_GT0], sc[S_GT1], sc[S_GT2]};
+    const float h[3][3] = {{h00, h01, h02}, {h01, h11, h12}, {h02, h12, h22}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) sc[S_H0 + i * 3 + j] = (h[i][j] * d1[i] * d1[j] + (i == j ? gt[i] * d2[i] : 0.f)) / fn;
+}
+
 __global__ __launch_bounds__(SMALL_NT) void k_hess(HessArgs a) {
     constexpr int NT = SMALL_NT, NW = NT / 64;
     __shared__ float red[9 * NW];
@@ -187,26 +211,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_hess(HessArgs a) {
     if (tid < n) { acc[5] = al[tid] * ga[tid]; acc[6] = be[tid] * ga[tid]; acc[7] = be[tid] * de[tid]; acc[8] = al[tid] * be[tid]; }
     for (int i = tid + NT; i < n; i += NT) { acc[5] += al[i] * ga[i]; acc[6] += be[i] * ga[i]; acc[7] += be[i] * de[i]; acc[8] += al[i] * be[i]; }
     block_sum<9, NT>(acc, red);
-    if (tid == 0) {
-        const float trA2 = acc[0], trPA = acc[1], trPP = acc[2], trAinvKll = acc[3], aKlla = acc[4], ag = acc[5], bg = acc[6], bd = acc[7], ab = acc[8];
-        const float trAinv = sc[S_TRAINV], aa = sc[S_AA], ya = sc[S_YA], trAinvG = sc[S_TRAINVG], aGa = sc[S_AGA];
-        const float fn = (float)n;
-        float h00 = ag - 0.5f * trA2;
-        const float h01 = ((aa - noise * ag) - 0.5f * (trAinv - noise * trA2)) / os;
-        const float h02 = bg - 0.5f * trPA;
-        const float h11 = ((ya - 2.f * noise * aa + noise * noise * ag) - 0.5f * (fn - 2.f * noise * trAinv + noise * noise * trA2)) / (os * os);
-        const float h12 = ((ab - noise * bg) - 0.5f * (trAinvG - noise * trPA)) / os - (0.5f * aGa - 0.5f * trAinvG) / os;
-        float h22 = bd - 0.5f * aKlla - 0.5f * trPP + 0.5f * trAinvKll;
-        // prior curvature (oracle/closed_form.py::lognormal_terms d2)
-        const float* pri = a.priors + t * 4;
-        if (pri[1] > 0.f) { const float lx = logf(noise), s2 = pri[1] * pri[1]; h00 -= (1.f + (lx - pri[0]) / s2 - 1.f / s2) / (noise * noise); }
-        if (pri[3] > 0.f) { const float lx = logf(ls), s2 = pri[3] * pri[3]; h22 -= (1.f + (lx - pri[2]) / s2 - 1.f / s2) / (ls * ls); }
-        const float d1[3] = {sc[S_D1N], sc[S_D1S], sc[S_D1L]}, d2[3] = {sc[S_D2N], sc[S_D2S], sc[S_D2L]};
-        const float gt[3] = {sc[S_GT0], sc[S_GT1], sc[S_GT2]};
-        const float h[3][3] = {{h00, h01, h02}, {h01, h11, h12}, {h02, h12, h22}};
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) sc[S_H0 + i * 3 + j] = (h[i][j] * d1[i] * d1[j] + (i == j ? gt[i] * d2[i] : 0.f)) / fn;
-    }
+    if (tid == 0) hess_assemble(sc, a.priors + t * 4, n, acc);
 }
 
 // ---- Stage D core: mu = C y, r = y_q - mu, factor S, e = S^-1 r, f_out, Cte = C^T e --------------------
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(64) void k_solve_v(SolveArgs a) {
 
 // ---- row/column sums of the weight matrices -> the diagonal coefficients of the dZ GEMMs -----------------
 // coef_s[i] = 2 (2 rowsum(W_ss)[i] + colsum(W_qs)[i]);  coef_q[i] = 2 (rowsum(W_qs)[i] + 2 rowsum(W_qq)[i])
-struct RowsumArgs { TaskView tv; const float* Wss; const float* Wqs; const float* Wqq; float* vecs; int T; int ext_colsum; };  // ext_colsum: V_CS_QS already holds the column sums (large.h)
+struct RowsumArgs { TaskView tv; const float* Wss; const float* Wqs; const float* Wqq; float* vecs; int T; };
 
 __global__ __launch_bounds__(SMALL_NT) void k_rowsums(RowsumArgs a) {
     constexpr int NT = SMALL_NT, NW = NT / 64;
@@ -396,9 +401,9 @@ __global__ __launch_bounds__(SMALL_NT) void k_rowsums(RowsumArgs a) {
     const float* Wqq = a.Wqq ? a.Wqq + (size_t)t * a.tv.nq_ld * a.tv.nq_ld : nullptr;
     float* vb = a.vecs + (size_t)t * NVEC * a.tv.vld;
     // column sums of W_qs: every wave sums its share of the rows for all columns (coalesced), partials meet in LDS
-    constexpr int CMAX = 256;  // larger support sets come with ext_colsum
+    constexpr int CMAX = 128;  // larger sets take k_lg_colsum / k_lg_rowsums (large.h)
     __shared__ float cpart[NW][CMAX];
-    if (m > 0 && !a.ext_colsum) {
+    if (m > 0) {
         for (int j = lane; j < n; j += 64) {
             float s = 0.f;
             for (int i = wv; i < m; i += NW) s += Wqs[(size_t)i * a.tv.ns_ld + j];
@@ -412,11 +417,8 @@ __global__ __launch_bounds__(SMALL_NT) void k_rowsums(RowsumArgs a) {
         s = wave_sum(s);
         if (lane == 0) {
             float cs = 0.f;
-            if (m > 0) {
-                if (a.ext_colsum) cs = vb[V_CS_QS * a.tv.vld + i];
-                else
-                    for (int w = 0; w < NW; ++w) cs += cpart[w][i];
-            }
+            if (m > 0)
+                for (int w = 0; w < NW; ++w) cs += cpart[w][i];
             vb[V_RS_SS * a.tv.vld + i] = 4.f * s + 2.f * cs;
         }
     }

@@ -288,32 +288,46 @@ __global__ __launch_bounds__(256) void k_lg_negate(LgMat a, int tiles_1d) {
     }
 }
 
-// f_out = (r^T e + log|S| + m log 2 pi) / 2,  Cte = C^T e  (one workgroup per task)
+// out[j] = sum_i w_i M_ij (w = null: plain column sums) for an m x n matrix: 64 columns x 16 row groups per workgroup
+// (grid: ceil(n / 64) x T), coalesced 256-byte row segments.
+struct LgColsumArgs { const float* M; int ld; size_t m_stride; const int32_t* m_arr; int m_ld; const int32_t* n_arr; int n_ld;
+                      const float* w; size_t w_stride; float* out; size_t out_stride; };
+
+__global__ __launch_bounds__(1024) void k_lg_colsum(LgColsumArgs a) {
+    __shared__ float part[16][64];
+    const int t = blockIdx.y, cl = threadIdx.x & 63, g = threadIdx.x >> 6, j = blockIdx.x * 64 + cl;
+    const int m = a.m_arr ? a.m_arr[t] : a.m_ld, n = a.n_arr ? a.n_arr[t] : a.n_ld;
+    const float* Mi = a.M + (size_t)t * a.m_stride;
+    const float* w = a.w ? a.w + (size_t)t * a.w_stride : nullptr;
+    float s = 0.f;
+    if (j < n)
+        for (int i = g; i < m; i += 16) s += (w ? w[i] : 1.f) * Mi[(size_t)i * a.ld + j];
+    part[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && j < n) {
+        s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += part[q][cl];
+        a.out[(size_t)t * a.out_stride + j] = s;
+    }
+}
+
+// f_out = (r^T e + log|S| + m log 2 pi) / 2  (one wave per task; Cte = C^T e comes from k_lg_colsum)
 struct LgOuterFin { OuterArgs o; const float* logdet; const int32_t* info_s; };
 
-__global__ __launch_bounds__(1024) void k_lg_outer_fin(LgOuterFin a) {
-    constexpr int NT = 1024;
-    __shared__ float red[NT / 64];
-    int t, tile;
-    if (!task_tile(a.o.T, 1, t, tile)) return;
+__global__ __launch_bounds__(64) void k_lg_outer_fin(LgOuterFin a) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= a.o.T) return;
     const TaskView& tv = a.o.tv;
-    const int n = tv.ns(t), m = tv.nq(t), tid = threadIdx.x;
-    float* vb = a.o.vecs + (size_t)t * NVEC * tv.vld;
-    const float* ev = vb + V_E * tv.vld;
-    const float* rv = vb + V_R * tv.vld;
-    float q[1] = {0.f};
-    for (int i = tid; i < m; i += NT) q[0] += rv[i] * ev[i];
-    block_sum<1, NT>(q, red);
-    const float* Ci = a.o.C + (size_t)t * tv.nq_ld * tv.ns_ld;
-    for (int j = tid; j < n; j += NT) {
-        float s = 0.f;
-        for (int i = 0; i < m; ++i) s += Ci[(size_t)i * tv.ns_ld + j] * ev[i];
-        vb[V_CTE * tv.vld + j] = s;
-    }
-    if (tid == 0) {
+    const int m = tv.nq(t);
+    const float* vb = a.o.vecs + (size_t)t * NVEC * tv.vld;
+    float q = 0.f;
+    for (int i = lane; i < m; i += 64) q += vb[V_R * tv.vld + i] * vb[V_E * tv.vld + i];
+    q = wave_sum(q);
+    if (lane == 0) {
         const float logdet = a.logdet[t];
         const int info = a.info_s[t];
-        const float f = 0.5f * q[0] + 0.5f * logdet + 0.5f * (float)m * LOG_2PI;
+        const float f = 0.5f * q + 0.5f * logdet + 0.5f * (float)m * LOG_2PI;
         a.o.scal[(size_t)t * NSCAL + S_FOUT] = f;
         a.o.scal[(size_t)t * NSCAL + S_LOGDETS] = logdet;
         if (a.o.f_out) a.o.f_out[t] = (info == 0) ? f : NAN;
@@ -321,46 +335,212 @@ __global__ __launch_bounds__(1024) void k_lg_outer_fin(LgOuterFin a) {
     }
 }
 
-// column sums of W_qs for k_rowsums when the query set does not fit its LDS staging (thread per column)
-__global__ __launch_bounds__(256) void k_lg_colsum(RowsumArgs a) {
-    const int t = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-    const int n = a.tv.ns(t), m = a.tv.nq(t);
-    if (j >= n) return;
-    const float* Wqs = a.Wqs + (size_t)t * a.tv.nq_ld * a.tv.ns_ld;
-    float s = 0.f;
-    for (int i = 0; i < m; ++i) s += Wqs[(size_t)i * a.tv.ns_ld + j];
-    a.vecs[((size_t)t * NVEC + V_CS_QS) * a.tv.vld + j] = s;
+// ---- tile-parallel twins of the one-workgroup-per-task kernels of kernels.h (few tasks, many points) ---------------
+// k_hess, part 1: beta = G alpha, gamma = Ainv alpha (wave per row; grid: ceil(ns_ld / 4) x T)
+__global__ __launch_bounds__(256) void k_lg_hess_mv(HessArgs a) {
+    const int t = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = a.tv.ns(t), ld = a.tv.ns_ld;
+    if (i >= n) return;
+    const float* sc = a.scal + (size_t)t * NSCAL;
+    const float os = sc[S_OS], ls = sc[S_LS], il2 = 1.f / (ls * ls);
+    const float* Ai = a.Ainv + ((size_t)t * ld + i) * ld;
+    const float* D2 = a.D2ss + ((size_t)t * ld + i) * ld;
+    float* vb = a.vecs + (size_t)t * NVEC * a.tv.vld;
+    const float* al = vb + V_ALPHA * a.tv.vld;
+    float sb = 0.f, sg = 0.f;
+    for (int j = lane; j < n; j += 64) {
+        float k0, k1, k2; const float u = D2[j] * il2; kappa3(a.tv.kind, u, k0, k1, k2);
+        const float aj = al[j];
+        sb += os * k1 * u * (-2.f / ls) * aj;
+        sg += Ai[j] * aj;
+    }
+    sb = wave_sum(sb); sg = wave_sum(sg);
+    if (lane == 0) { vb[V_BETA * a.tv.vld + i] = sb; vb[V_GAMMA * a.tv.vld + i] = sg; }
 }
 
-// Median heuristic for more than 256 points: same 31-step radix select as k_median, candidates re-read from L2.
-__global__ __launch_bounds__(1024) void k_median_large(const float* D2ss, const int32_t* n_s, int ld, float* l0, int T) {
-    constexpr int NT = 1024;
-    __shared__ int red[NT / 64];
+// k_hess, part 2 (after delta = Ainv beta): the five O(N^2) traces per 64 x 64 tile
+struct LgHessTr { HessArgs h; float* part; int ntiles, tiles_1d; };
+
+__global__ __launch_bounds__(256) void k_lg_hess_tr(LgHessTr a) {
+    __shared__ float red[5 * 4];
     int t, tile;
-    if (!task_tile(T, 1, t, tile)) return;
-    const int n = n_s ? n_s[t] : ld, tid = threadIdx.x;
-    const uint32_t* D = reinterpret_cast<const uint32_t*>(D2ss + (size_t)t * ld * ld);
-    // rows are dealt to waves, columns to lanes: coalesced, and no integer division per element
-    const int lane = tid & 63, wv = tid >> 6;
-    int cnt = 0;
-    for (int i = wv; i < n; i += NT / 64)
-        for (int j = i + 1 + lane; j < n; j += 64) cnt += (D[(size_t)i * ld + j] != 0u);
-    const int total = block_sum_i<NT>(cnt, red);
-    if (total == 0) { if (tid == 0) l0[t] = 0.f; return; }
-    int rank = (total - 1) / 2;
-    uint32_t prefix = 0;
-    for (int bit = 30; bit >= 0; --bit) {
-        const uint32_t hi_mask = ~((1u << bit) - 1u);
-        int c0 = 0;
-        for (int i = wv; i < n; i += NT / 64)
-            for (int j = i + 1 + lane; j < n; j += 64) {
-                const uint32_t v = D[(size_t)i * ld + j];
-                c0 += (v != 0u && (v & hi_mask) == prefix);
+    if (!task_tile(a.h.T, a.ntiles, t, tile)) return;
+    const int n = a.h.tv.ns(t), ld = a.h.tv.ns_ld;
+    const int m0 = (tile / a.tiles_1d) * GT, n0 = (tile % a.tiles_1d) * GT;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (m0 < n && n0 < n) {
+        const float* sc = a.h.scal + (size_t)t * NSCAL;
+        const float os = sc[S_OS], ls = sc[S_LS], il2 = 1.f / (ls * ls);
+        const float* Ai = a.h.Ainv + (size_t)t * ld * ld;
+        const float* Pi = a.h.P + (size_t)t * ld * ld;
+        const float* D2 = a.h.D2ss + (size_t)t * ld * ld;
+        const float* al = a.h.vecs + ((size_t)t * NVEC + V_ALPHA) * a.h.tv.vld;
+        for (int e = threadIdx.x; e < GT * GT; e += 256) {
+            const int i = m0 + (e >> 6), j = n0 + (e & 63);
+            if (i < n && j < n) {
+                const float ai = Ai[(size_t)i * ld + j], pij = Pi[(size_t)i * ld + j], pji = Pi[(size_t)j * ld + i];
+                float k0, k1, k2; const float u = D2[(size_t)i * ld + j] * il2; kappa3(a.h.tv.kind, u, k0, k1, k2);
+                const float Kll = os * (k2 * 4.f * u * u + k1 * 6.f * u) * il2;
+                acc[0] += ai * ai; acc[1] += pij * ai; acc[2] += pij * pji; acc[3] += ai * Kll; acc[4] += al[i] * al[j] * Kll;
             }
-        c0 = block_sum_i<NT>(c0, red);
-        if (rank >= c0) { rank -= c0; prefix |= (1u << bit); }
+        }
     }
-    if (tid == 0) l0[t] = sqrtf(0.5f * __uint_as_float(prefix));
+    block_sum<5, 256>(acc, red);
+    if (threadIdx.x == 0) {
+        float* p = a.part + ((size_t)t * a.ntiles + tile) * 8;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) p[q] = acc[q];
+    }
+}
+
+// k_hess, part 3: sum the partials, the four vector dot products, assemble H (one wave per task)
+__global__ __launch_bounds__(64) void k_lg_hess_fin(LgHessTr a) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= a.h.T) return;
+    const int n = a.h.tv.ns(t), vld = a.h.tv.vld;
+    float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = lane; q < a.ntiles; q += 64) {
+        const float* p = a.part + ((size_t)t * a.ntiles + q) * 8;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[k] += p[k];
+    }
+    const float* vb = a.h.vecs + (size_t)t * NVEC * vld;
+    for (int i = lane; i < n; i += 64) {
+        const float al = vb[V_ALPHA * vld + i], be = vb[V_BETA * vld + i], ga = vb[V_GAMMA * vld + i], de = vb[V_DELTA * vld + i];
+        acc[5] += al * ga; acc[6] += be * ga; acc[7] += be * de; acc[8] += al * be;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0) hess_assemble(a.h.scal + (size_t)t * NSCAL, a.h.priors + t * 4, n, acc);
+}
+
+// k_wqq per tile; k_lg_wqq_fin sums the three reductions into the scalar slots
+struct LgWqq { WqqArgs w; float* part; int ntiles, tiles_1d; };
+
+__global__ __launch_bounds__(256) void k_lg_wqq(LgWqq a) {
+    __shared__ float red[3 * 4];
+    int t, tile;
+    if (!task_tile(a.w.T, a.ntiles, t, tile)) return;
+    const int m = a.w.tv.nq(t), ld = a.w.tv.nq_ld;
+    const int m0 = (tile / a.tiles_1d) * GT, n0 = (tile % a.tiles_1d) * GT;
+    float acc[3] = {0.f, 0.f, 0.f};
+    if (m0 < m && n0 < m) {
+        const float* sc = a.w.scal + (size_t)t * NSCAL;
+        const float os = sc[S_OS], ls = sc[S_LS], il2 = 1.f / (ls * ls);
+        const float* Si = a.w.Sinv + (size_t)t * ld * ld;
+        const float* D2 = a.w.D2qq + (size_t)t * ld * ld;
+        float* Wo = a.w.Wqq + (size_t)t * ld * ld;
+        const float* ev = a.w.tv.vec_ptr(t, V_E);
+        for (int e = threadIdx.x; e < GT * GT; e += 256) {
+            const int i = m0 + (e >> 6), j = n0 + (e & 63);
+            if (i < m && j < m) {
+                const float om = 0.5f * (Si[(size_t)i * ld + j] - ev[i] * ev[j]);
+                float k0, k1, k2; const float u = D2[(size_t)i * ld + j] * il2; kappa3(a.w.tv.kind, u, k0, k1, k2);
+                Wo[(size_t)i * ld + j] = a.w.dirscale * om * os * k1 * il2;
+                if (i == j) acc[0] += om;
+                acc[1] += om * k0;
+                acc[2] += om * os * k1 * u * (-2.f / ls);
+            }
+        }
+    }
+    block_sum<3, 256>(acc, red);
+    if (threadIdx.x == 0) {
+        float* p = a.part + ((size_t)t * a.ntiles + tile) * 4;
+        p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_lg_wqq_fin(LgWqq a) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= a.w.T) return;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int q = lane; q < a.ntiles; q += 64) {
+        const float* p = a.part + ((size_t)t * a.ntiles + q) * 4;
+        acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0) {
+        float* sc = a.w.scal + (size_t)t * NSCAL;
+        sc[S_QQ_TR] = acc[0]; sc[S_QQ_K] = acc[1]; sc[S_QQ_L] = acc[2];
+    }
+}
+
+// k_rowsums per row (wave per row; grid: ceil(max(ns_ld, nq_ld) / 4) x T); V_CS_QS must already hold colsum(W_qs)
+__global__ __launch_bounds__(256) void k_lg_rowsums(RowsumArgs a) {
+    const int t = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = a.tv.ns(t), m = a.Wqs ? a.tv.nq(t) : 0;
+    float* vb = a.vecs + (size_t)t * NVEC * a.tv.vld;
+    if (i < n) {
+        const float* row = a.Wss + ((size_t)t * a.tv.ns_ld + i) * a.tv.ns_ld;
+        float s = 0.f;
+        for (int j = lane; j < n; j += 64) s += row[j];
+        s = wave_sum(s);
+        if (lane == 0) vb[V_RS_SS * a.tv.vld + i] = 4.f * s + (m > 0 ? 2.f * vb[V_CS_QS * a.tv.vld + i] : 0.f);
+    }
+    if (i < m) {
+        const float* r1 = a.Wqs + ((size_t)t * a.tv.nq_ld + i) * a.tv.ns_ld;
+        const float* r2 = a.Wqq + ((size_t)t * a.tv.nq_ld + i) * a.tv.nq_ld;
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = lane; j < n; j += 64) s1 += r1[j];
+        for (int j = lane; j < m; j += 64) s2 += r2[j];
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) vb[V_RS_QS * a.tv.vld + i] = 2.f * s1 + 4.f * s2;
+    }
+}
+
+// ---- median heuristic for many points: 4 passes of an 8-bit radix select over the float bit patterns ------------------
+// k_lg_med_hist: histogram of the current digit over the candidates that match the prefix found so far
+//                (grid: rows are dealt to gridDim.x workgroups; LDS histogram, then integer atomics: deterministic)
+// k_lg_med_pick: one thread per task walks the 256 bins, extends the prefix, clears the bins for the next pass
+struct LgMedian { const float* D2ss; const int32_t* n_s; int ld; float* l0; int T; uint32_t* prefix; int* rank; int* hist; };
+
+__device__ __forceinline__ int lg_med_shift(int pass) { return pass == 0 ? 23 : pass == 1 ? 15 : pass == 2 ? 7 : 0; }
+
+__global__ __launch_bounds__(256) void k_lg_med_hist(LgMedian a, int pass) {
+    __shared__ int h[256];
+    const int t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = a.n_s ? a.n_s[t] : a.ld;
+    h[tid] = 0;
+    __syncthreads();
+    const uint32_t* D = reinterpret_cast<const uint32_t*>(a.D2ss + (size_t)t * a.ld * a.ld);
+    const int shift = lg_med_shift(pass);
+    const uint32_t hi_mask = pass == 0 ? 0u : ~((1u << lg_med_shift(pass - 1)) - 1u);
+    const uint32_t digit_mask = pass == 3 ? 127u : 255u;
+    const uint32_t prefix = pass == 0 ? 0u : a.prefix[t];
+    for (int i = blockIdx.x * 4 + wv; i < n; i += gridDim.x * 4)
+        for (int j = i + 1 + lane; j < n; j += 64) {
+            const uint32_t v = D[(size_t)i * a.ld + j];
+            if (v != 0u && (v & hi_mask) == prefix) atomicAdd(&h[(v >> shift) & digit_mask], 1);
+        }
+    __syncthreads();
+    if (h[tid] != 0) atomicAdd(&a.hist[t * 256 + tid], h[tid]);
+}
+
+__global__ void k_lg_med_pick(LgMedian a, int pass) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.T) return;
+    int* h = a.hist + t * 256;
+    int rank;
+    if (pass == 0) {
+        int total = 0;
+        for (int b = 0; b < 256; ++b) total += h[b];
+        if (total == 0) { a.rank[t] = -1; a.prefix[t] = 0u; a.l0[t] = 0.f; for (int b = 0; b < 256; ++b) h[b] = 0; return; }
+        rank = (total - 1) / 2;  // torch.median: lower median
+    } else {
+        rank = a.rank[t];
+        if (rank < 0) return;
+    }
+    uint32_t prefix = pass == 0 ? 0u : a.prefix[t];
+    int b = 0;
+    for (; b < 255; ++b) {
+        if (rank < h[b]) break;
+        rank -= h[b];
+    }
+    prefix |= (uint32_t)b << lg_med_shift(pass);
+    for (int q = 0; q < 256; ++q) h[q] = 0;
+    a.rank[t] = rank; a.prefix[t] = prefix;
+    if (pass == 3) a.l0[t] = sqrtf(0.5f * __uint_as_float(prefix));
 }
 
 }  // namespace adkf
