@@ -19,6 +19,8 @@
 //   __device__ void  store_red(int tile, const float* red)   (only when NRED > 0; called by thread 0)
 //   __device__ bool  skip(int m0, int n0)        : OPTIONAL - true when the tile at (m0, n0) needs no product (its
 //                                                  epilogue still runs, with acc = 0)
+//   __device__ void  epi4(int i0, int j, const float (&acc)[4], float* red) : OPTIONAL - four consecutive rows of one
+//                                                  column at once (what one lane holds after the MFMA), all in range
 #pragma once
 #include <type_traits>
 
@@ -36,6 +38,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <class P, class = void> struct has_skip : std::false_type {};
 template <class P> struct has_skip<P, std::void_t<decltype(&P::skip)>> : std::true_type {};
+template <class P, class = void> struct has_epi4 : std::false_type {};
+template <class P> struct has_epi4<P, std::void_t<decltype(&P::epi4)>> : std::true_type {};
 
 // Each thread stages GPT = 8 operand entries per chunk as two groups of 4 that are consecutive along the operand's
 // contiguous direction: K-contiguous -> (row r, k4..k4+3), MN-contiguous -> (k, mn4..mn4+3).
@@ -155,13 +159,20 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = m0 + wr * 32 + i * 16 + fk * 4 + r;
-                const int gj = n0 + wc * 32 + j * 16 + fi;
-                if (gi < M && gj < N) p.epi(gi, gj, acc[i][j][r], red);
+        for (int j = 0; j < 2; ++j) {
+            const int gi0 = m0 + wr * 32 + i * 16 + fk * 4;
+            const int gj = n0 + wc * 32 + j * 16 + fi;
+            if constexpr (has_epi4<P>::value) {
+                if (gi0 + 3 < M && gj < N) {
+                    const float v4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    p.epi4(gi0, gj, v4, red);
+                    continue;
+                }
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (gi0 + r < M && gj < N) p.epi(gi0 + r, gj, acc[i][j][r], red);
+        }
     if (P::NRED > 0) {
         block_sum<(P::NRED > 0 ? P::NRED : 1), 256>(red, red_s);
         if (tid == 0) p.store_red(tile, red);

@@ -112,18 +112,46 @@ struct ProbLgUpdate {
     }
     __device__ int M() const { return n; } __device__ int N() const { return n; } __device__ int K() const { return nloc; }
     __device__ bool in_p(int i) const { return i >= p0 && i < p0 + LB; }
-    __device__ bool skip(int m0, int n0) const { return in_p(m0) || in_p(n0); }
+    // M stays symmetric: only tiles on or above the diagonal are computed, their epilogue also writes the mirror image
+    __device__ bool skip(int m0, int n0) const { return in_p(m0) || in_p(n0) || m0 > n0; }
     __device__ float a(int i, int k) const { return Cb[(size_t)k * m.ld + i]; }
     __device__ float b(int k, int j) const { return Fb[(size_t)k * m.ld + j]; }
     __device__ void a4(int i, int k, float (&v)[4]) const { ld4(Cb + (size_t)k * m.ld + i, v); }
     __device__ void b4(int k, int j, float (&v)[4]) const { ld4(Fb + (size_t)k * m.ld + j, v); }
     __device__ void epi(int i, int j, float acc, float*) const {
+        const int ti = i >> 6, tj = j >> 6;
+        if (ti > tj) return;
         float* dst = Mi + (size_t)i * m.ld + j;
         const bool pi = in_p(i), pj = in_p(j);
-        if (!pi && !pj) *dst -= acc;
-        else if (pi && pj) *dst = -Dv[(i - p0) * LB + (j - p0)];
-        else if (pi) *dst = Fb[(size_t)(i - p0) * m.ld + j];
-        else *dst = Fb[(size_t)(j - p0) * m.ld + i];
+        float v;
+        if (!pi && !pj) v = *dst - acc;
+        else if (pi && pj) v = -Dv[(i - p0) * LB + (j - p0)];
+        else if (pi) v = Fb[(size_t)(i - p0) * m.ld + j];
+        else v = Fb[(size_t)(j - p0) * m.ld + i];
+        *dst = v;
+        if (ti < tj) Mi[(size_t)j * m.ld + i] = v;
+    }
+    // four rows of one column: the mirror image is ONE 16-byte store (i0 is a multiple of 4, ld too when vec)
+    __device__ void epi4(int i0, int j, const float (&acc)[4], float* red) const {
+        const int ti = i0 >> 6, tj = j >> 6;
+        if (ti > tj) return;
+        if (!vec || ti == tj) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) epi(i0 + r, j, acc[r], red);
+            return;
+        }
+        const bool pi = in_p(i0), pj = in_p(j);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* dst = Mi + (size_t)(i0 + r) * m.ld + j;
+            if (!pi && !pj) v[r] = *dst - acc[r];
+            else if (pi && pj) v[r] = -Dv[(i0 + r - p0) * LB + (j - p0)];
+            else if (pi) v[r] = Fb[(size_t)(i0 + r - p0) * m.ld + j];
+            else v[r] = Fb[(size_t)(j - p0) * m.ld + i0 + r];
+            *dst = v[r];
+        }
+        *reinterpret_cast<float4*>(Mi + (size_t)j * m.ld + i0) = make_float4(v[0], v[1], v[2], v[3]);
     }
     __device__ void store_red(int, const float*) const {}
 };
