@@ -15,6 +15,26 @@ constexpr int REG_POINTS = 128;
 
 inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
+inline int grid_for(int T, int tiles) { return ((T + 7) / 8) * 8 * tiles; }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Output-tile edge of the batched GEMMs.  The 128 x 128 variant (gemm.h) halves the operand traffic but leaves one
+// wave per SIMD: measured slower at every stage of C2 (ProbDist 33 -> 49 us, ProbP 22 -> 32 us, profiles/ notes in
+// DESIGN.md), so 64 x 64 (four co-resident workgroups per CU) is used throughout.
+inline int tile_edge(int, int) { return GT; }
+inline int tiles_of(int M, int N) { const int e = tile_edge(M, N); return ceil_div(M, e) * ceil_div(N, e); }
+
+template <class P>
+void launch_gemm(const P& p, int T, int M, int N, hipStream_t st) {
+    if (tile_edge(M, N) == GTL) {
+        const int tm = ceil_div(M, GTL), tn = ceil_div(N, GTL);
+        k_bgemm<P, GTL><<<((T + 7) / 8) * 8 * tm * tn, 256, 0, st>>>(p, T, tm, tn);
+    } else {
+        const int tm = ceil_div(M, GT), tn = ceil_div(N, GT);
+        k_bgemm<P, GT><<<((T + 7) / 8) * 8 * tm * tn, 256, 0, st>>>(p, T, tm, tn);
+    }
+}
+
 struct Workspace {
     float *mean, *nrm_s, *nrm_q, *D2ss, *D2qs, *D2qq, *Ainv, *P, *C, *S, *OC, *Wss, *Wqs, *Wqq, *vecs, *scal, *part_oc, *part_ma, *l0;
     // blocked path only (max(ns, nq) > REG_POINTS)
@@ -31,8 +51,8 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
     auto take = [&](size_t nfloat) { float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr; off += align_up(nfloat * sizeof(float)); return p; };
     const size_t Tz = (size_t)T;
     w.vld = ns > nq ? ns : nq;
-    w.nt_oc = ((nq + GT - 1) / GT) * ((ns + GT - 1) / GT);
-    w.nt_ma = ((ns + GT - 1) / GT) * ((ns + GT - 1) / GT);
+    w.nt_oc = nq > 0 ? tiles_of(nq, ns) : 0;   // per-tile partial reductions of ProbOC / ProbMA
+    w.nt_ma = tiles_of(ns, ns);
     w.mean = take(Tz * d);
     w.nrm_s = take(Tz * ns);
     w.nrm_q = take(Tz * (nq > 0 ? nq : 1));
@@ -59,7 +79,8 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
         w.lg_F = take(Tz * LB * w.vld);
         w.lg_logdet = take(Tz);
         const size_t tq = (size_t)((nq + GT - 1) / GT) * ((nq + GT - 1) / GT);
-        w.lg_part = take(Tz * ((size_t)w.nt_ma > tq ? (size_t)w.nt_ma : tq) * 8);
+        const size_t ts = (size_t)((ns + GT - 1) / GT) * ((ns + GT - 1) / GT);
+        w.lg_part = take(Tz * (ts > tq ? ts : tq) * 8);
         w.lg_info = reinterpret_cast<int32_t*>(take(Tz));
         w.lg_med = reinterpret_cast<int32_t*>(take(Tz * 258));
         w.lg_fit = reinterpret_cast<FitShared*>(take(Tz * ((sizeof(FitShared) + 3) / 4)));
@@ -78,9 +99,6 @@ int check_batch(const adkf_batch_t* b, bool need_query) {
     }
     return 0;
 }
-
-inline int grid_for(int T, int tiles) { return ((T + 7) / 8) * 8 * tiles; }
-inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -116,16 +134,13 @@ int stage_dist(const adkf_batch_t* b, const Workspace& w, bool with_query, hipSt
     p.mean = w.mean; p.d = d; p.vec = vec_ok(b, w);
     {
         p.X = b->Z_s; p.Y = b->Z_s; p.nx = w.nrm_s; p.ny = w.nrm_s; p.n_x = b->n_s; p.n_y = b->n_s; p.x_ld = ns; p.y_ld = ns; p.symmetric = true; p.D2 = w.D2ss;
-        const int tm = ceil_div(ns, GT);
-        k_bgemm<ProbDist><<<grid_for(T, tm * tm), 256, 0, st>>>(p, T, tm, tm);
+        launch_gemm(p, T, ns, ns, st);
     }
     if (with_query) {
         p.X = b->Z_q; p.Y = b->Z_s; p.nx = w.nrm_q; p.ny = w.nrm_s; p.n_x = b->n_q; p.n_y = b->n_s; p.x_ld = nq; p.y_ld = ns; p.symmetric = false; p.D2 = w.D2qs;
-        int tm = ceil_div(nq, GT), tn = ceil_div(ns, GT);
-        k_bgemm<ProbDist><<<grid_for(T, tm * tn), 256, 0, st>>>(p, T, tm, tn);
+        launch_gemm(p, T, nq, ns, st);
         p.X = b->Z_q; p.Y = b->Z_q; p.nx = w.nrm_q; p.ny = w.nrm_q; p.n_x = b->n_q; p.n_y = b->n_q; p.x_ld = nq; p.y_ld = nq; p.symmetric = true; p.D2 = w.D2qq;
-        tm = ceil_div(nq, GT);
-        k_bgemm<ProbDist><<<grid_for(T, tm * tm), 256, 0, st>>>(p, T, tm, tm);
+        launch_gemm(p, T, nq, nq, st);
     }
     LAUNCH_OK();
     return 0;
@@ -253,7 +268,7 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
     const float corrscale = (with_hessian && !(flags & ADKF_IGNORE_GRAD_CORRECTION)) ? 1.f : 0.f;
     if (with_hessian) {
         ProbP pp; pp.tv = tv; pp.Ainv = w.Ainv; pp.D2ss = w.D2ss; pp.P = w.P;
-        k_bgemm<ProbP><<<grid_for(T, tms * tms), 256, 0, st>>>(pp, T, tms, tms);
+        launch_gemm(pp, T, ns, ns, st);
         HessArgs ha{tv, w.Ainv, w.P, w.D2ss, b->y_s, b->priors, w.scal, w.vecs, T};
         if (ns > REG_POINTS) {
             k_lg_hess_mv<<<dim3(ceil_div(ns, 4), T), 256, 0, st>>>(ha);
@@ -268,16 +283,16 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         }
     }
     ProbC pc; pc.tv = tv; pc.Ainv = w.Ainv; pc.D2qs = w.D2qs; pc.C = w.C;
-    k_bgemm<ProbC><<<grid_for(T, tmq * tms), 256, 0, st>>>(pc, T, tmq, tms);
+    launch_gemm(pc, T, nq, ns, st);
     ProbS ps; ps.tv = tv; ps.C = w.C; ps.D2qs = w.D2qs; ps.D2qq = w.D2qq; ps.S = w.S;
-    k_bgemm<ProbS><<<grid_for(T, tmq * tmq), 256, 0, st>>>(ps, T, tmq, tmq);
+    launch_gemm(ps, T, nq, nq, st);
     OuterArgs oa{tv, w.C, w.S, b->y_s, b->y_q, w.vecs, w.scal, f_out, info, T};
     rc = launch_outer_factor(oa, w, nq, st);
     if (rc) return rc;
     ProbOC po; po.tv = tv; po.Sinv = w.S; po.C = w.C; po.D2qs = w.D2qs; po.OC = w.OC; po.Wqs = w.Wqs; po.part = w.part_oc; po.ntiles = w.nt_oc; po.dirscale = dirscale;
-    k_bgemm<ProbOC><<<grid_for(T, tmq * tms), 256, 0, st>>>(po, T, tmq, tms);
+    launch_gemm(po, T, nq, ns, st);
     ProbMA pm; pm.tv = tv; pm.C = w.C; pm.OC = w.OC; pm.D2ss = w.D2ss; pm.Wss = w.Wss; pm.part = w.part_ma; pm.ntiles = w.nt_ma; pm.dirscale = dirscale;
-    k_bgemm<ProbMA><<<grid_for(T, tms * tms), 256, 0, st>>>(pm, T, tms, tms);
+    launch_gemm(pm, T, ns, ns, st);
     WqqArgs wq{tv, w.S, w.D2qq, w.Wqq, w.scal, dirscale, T};
     if (nq > REG_POINTS) {
         LgWqq lw{wq, w.lg_part, tmq * tmq, tmq};
@@ -290,21 +305,20 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
     k_solve_v<<<T, 64, 0, st>>>(sa);
     if (corrscale != 0.f) {
         ProbMixed px; px.tv = tv; px.Ainv = w.Ainv; px.P = w.P; px.D2ss = w.D2ss; px.Wss = w.Wss; px.corrscale = corrscale;
-        k_bgemm<ProbMixed><<<grid_for(T, tms * tms), 256, 0, st>>>(px, T, tms, tms);
+        launch_gemm(px, T, ns, ns, st);
     }
     if (dZ_s || dZ_q) {
         RowsumArgs ra{tv, w.Wss, w.Wqs, w.Wqq, w.vecs, T};
         launch_rowsums(ra, w, st);
-        const int tn = ceil_div(d, GT);
         if (dZ_s) {
             hipMemsetAsync(dZ_s, 0, (size_t)T * ns * d * sizeof(float), st);
             ProbDZ<false> pz; pz.tv = tv; pz.Wss = w.Wss; pz.Wqs = w.Wqs; pz.Wqq = w.Wqq; pz.Zs = b->Z_s; pz.Zq = b->Z_q; pz.dZ = dZ_s; pz.d = d;
-            k_bgemm<ProbDZ<false>><<<grid_for(T, tms * tn), 256, 0, st>>>(pz, T, tms, tn);
+            launch_gemm(pz, T, ns, d, st);
         }
         if (dZ_q) {
             hipMemsetAsync(dZ_q, 0, (size_t)T * nq * d * sizeof(float), st);
             ProbDZ<true> pz; pz.tv = tv; pz.Wss = w.Wss; pz.Wqs = w.Wqs; pz.Wqq = w.Wqq; pz.Zs = b->Z_s; pz.Zq = b->Z_q; pz.dZ = dZ_q; pz.d = d;
-            k_bgemm<ProbDZ<true>><<<grid_for(T, tmq * tn), 256, 0, st>>>(pz, T, tmq, tn);
+            launch_gemm(pz, T, nq, d, st);
         }
     }
     LAUNCH_OK();
@@ -386,8 +400,7 @@ int adkf_mll_value_grad(const adkf_batch_t* b, const float* phi, float* f_in, fl
         launch_rowsums(ra, w, st);
         hipMemsetAsync(dZ_s, 0, (size_t)b->T * b->ns_max * b->d * sizeof(float), st);
         ProbDZ<false> pz; pz.tv = tv; pz.Wss = w.Wss; pz.Wqs = nullptr; pz.Wqq = nullptr; pz.Zs = b->Z_s; pz.Zq = nullptr; pz.dZ = dZ_s; pz.d = b->d;
-        const int tms = ceil_div(b->ns_max, GT), tn = ceil_div(b->d, GT);
-        k_bgemm<ProbDZ<false>><<<grid_for(b->T, tms * tn), 256, 0, st>>>(pz, b->T, tms, tn);
+        launch_gemm(pz, b->T, b->ns_max, b->d, st);
         LAUNCH_OK();
     }
     return 0;
@@ -430,15 +443,15 @@ int adkf_predict(const adkf_batch_t* b, const float* phi, float* mean, float* va
         if (rc) return rc;
     }
     TaskView tv = make_tv(b, w, true);
-    const int T = b->T, tms = ceil_div(b->ns_max, GT), tmq = ceil_div(b->nq_max, GT);
+    const int T = b->T;
     ProbC pc; pc.tv = tv; pc.Ainv = w.Ainv; pc.D2qs = w.D2qs; pc.C = w.C;
-    k_bgemm<ProbC><<<grid_for(T, tmq * tms), 256, 0, st>>>(pc, T, tmq, tms);
+    launch_gemm(pc, T, b->nq_max, b->ns_max, st);
     PredArgs pa{tv, w.C, w.D2qs, b->y_s, mean, var, w.scal, T};
     k_predict<<<grid_for(T, 1), 256, 0, st>>>(pa);
     if (cov) {
         hipMemsetAsync(cov, 0, (size_t)T * b->nq_max * b->nq_max * sizeof(float), st);
         ProbS ps; ps.tv = tv; ps.C = w.C; ps.D2qs = w.D2qs; ps.D2qq = w.D2qq; ps.S = cov;
-        k_bgemm<ProbS><<<grid_for(T, tmq * tmq), 256, 0, st>>>(ps, T, tmq, tmq);
+        launch_gemm(ps, T, b->nq_max, b->nq_max, st);
     }
     LAUNCH_OK();
     return 0;

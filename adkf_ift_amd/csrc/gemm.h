@@ -1,12 +1,16 @@
-// Batched small-matrix GEMM on the fp32-input MFMA (v_mfma_f32_16x16x4_f32), one 64x64 output tile per
-// 256-thread workgroup, operands produced ON THE FLY by a problem functor (kernel-matrix entries from
-// squared distances, Omega from S^-1 and e, ...) and a fused epilogue functor (elementwise chain rule +
+// Batched small-matrix GEMM on the fp32-input MFMA (v_mfma_f32_16x16x4_f32), one TM x TM output tile per
+// 256-thread workgroup (TM = 64 or 128), operands produced ON THE FLY by a problem functor (kernel-matrix entries
+// from squared distances, Omega from S^-1 and e, ...) and a fused epilogue functor (elementwise chain rule +
 // reductions), so no intermediate kernel matrix is ever written to HBM.
 //
 // Pipeline: K is consumed in chunks of 32; the global loads (and the functor arithmetic, e.g. exp) of chunk c+1
 // are issued into registers before the MFMAs of chunk c and written to LDS after them, so memory latency and the
 // VALU work of operand generation hide under the matrix pipe.  LDS layouts are conflict-free for the b32
-// fragment reads: [mn][34] for K-contiguous operands (bank = 2 i + k), [k][80] for MN-contiguous ones.
+// fragment reads: [mn][34] for K-contiguous operands (bank = 2 i + k), [k][TM + 16] for MN-contiguous ones.
+//
+// Tile size: the 128 x 128 tile halves the L2 -> CU operand traffic of the 64 x 64 one, but with 256 threads it leaves
+// one wave per SIMD and nothing to cover the stage/barrier phases: measured 1.4-1.8x SLOWER on every C2 stage, so the
+// host (adkf_gp.hip::tile_edge) always picks 64; the variant stays for experiments with more waves per tile.
 //
 // A problem type P provides
 //   static constexpr bool A_KCONTIG / B_KCONTIG : is the operand contiguous in memory along k?  (chooses
@@ -28,11 +32,10 @@
 
 namespace adkf {
 
-constexpr int GT = 64;        // tile edge
+constexpr int GT = 64;        // default tile edge
+constexpr int GTL = 128;      // large tile edge
 constexpr int GK = 32;        // k chunk
 constexpr int LD_MN = GK + 2; // [mn][k] layout, K-contiguous operands
-constexpr int LD_K = GT + 16; // [k][mn] layout, MN-contiguous operands (LD % 32 == 16)
-constexpr int GPT = GT * GK / 256;  // operand elements staged per thread per chunk
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -41,14 +44,23 @@ template <class P> struct has_skip<P, std::void_t<decltype(&P::skip)>> : std::tr
 template <class P, class = void> struct has_epi4 : std::false_type {};
 template <class P> struct has_epi4<P, std::void_t<decltype(&P::epi4)>> : std::true_type {};
 
-// Each thread stages GPT = 8 operand entries per chunk as two groups of 4 that are consecutive along the operand's
+template <int TM> struct GemmCfg {
+    static constexpr int GPT = TM * GK / 256;   // operand elements staged per thread per chunk
+    static constexpr int LD_K = TM + 16;        // [k][mn] layout, MN-contiguous operands (LD % 32 == 16)
+    static constexpr int MNQ = TM / 4;          // float4 groups along mn
+    static constexpr int KSTEP = 256 / MNQ;     // k rows covered per pass of the MN-contiguous map
+    static constexpr int MI = TM / 32;          // 16 x 16 MFMA tiles per wave per dimension (2 x 2 waves)
+};
+
+// Each thread stages GPT operand entries per chunk as GPT / 4 groups of 4 that are consecutive along the operand's
 // contiguous direction: K-contiguous -> (row r, k4..k4+3), MN-contiguous -> (k, mn4..mn4+3).
-template <class P, bool IS_A>
-__device__ __forceinline__ void gemm_fetch(const P& p, float (&reg)[GPT], int base, int k0, int lim, int K) {
+template <class P, bool IS_A, int TM>
+__device__ __forceinline__ void gemm_fetch(const P& p, float (&reg)[GemmCfg<TM>::GPT], int base, int k0, int lim, int K) {
+    using C = GemmCfg<TM>;
     constexpr bool KC = IS_A ? P::A_KCONTIG : P::B_KCONTIG;
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int ps = 0; ps < GPT / 4; ++ps) {
+    for (int ps = 0; ps < C::GPT / 4; ++ps) {
         float v[4];
         if (KC) {
             const int g = base + (tid >> 3) + ps * 32, gk = k0 + (tid & 7) * 4;
@@ -59,7 +71,7 @@ __device__ __forceinline__ void gemm_fetch(const P& p, float (&reg)[GPT], int ba
                 for (int x = 0; x < 4; ++x) v[x] = (g < lim && gk + x < K) ? (IS_A ? p.a(g, gk + x) : p.b(gk + x, g)) : 0.f;
             }
         } else {
-            const int g = base + (tid & 15) * 4, gk = k0 + (tid >> 4) + ps * 16;
+            const int g = base + (tid % C::MNQ) * 4, gk = k0 + (tid / C::MNQ) + ps * C::KSTEP;
             if (p.vec && g + 3 < lim && gk < K) {
                 if (IS_A) p.a4(g, gk, v); else p.b4(gk, g, v);
             } else {
@@ -72,27 +84,30 @@ __device__ __forceinline__ void gemm_fetch(const P& p, float (&reg)[GPT], int ba
     }
 }
 
-template <bool KC>
-__device__ __forceinline__ void gemm_stage(float* S, const float (&reg)[GPT]) {
+template <bool KC, int TM>
+__device__ __forceinline__ void gemm_stage(float* S, const float (&reg)[GemmCfg<TM>::GPT]) {
+    using C = GemmCfg<TM>;
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int ps = 0; ps < GPT / 4; ++ps) {
+    for (int ps = 0; ps < C::GPT / 4; ++ps) {
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             if (KC) S[((tid >> 3) + ps * 32) * LD_MN + (tid & 7) * 4 + x] = reg[ps * 4 + x];
-            else S[((tid >> 4) + ps * 16) * LD_K + (tid & 15) * 4 + x] = reg[ps * 4 + x];
+            else S[((tid / C::MNQ) + ps * C::KSTEP) * C::LD_K + (tid % C::MNQ) * 4 + x] = reg[ps * 4 + x];
         }
     }
 }
 
-template <class P>
+template <class P, int TM = GT>
 __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tiles_n) {
+    using C = GemmCfg<TM>;
+    constexpr int MI = C::MI, LD_K = C::LD_K, GPT = C::GPT, WT = TM / 2;
     int task, tile;
     if (!task_tile(T, tiles_m * tiles_n, task, tile)) return;
     if (!p.setup(task)) return;
     const int M = p.M(), N = p.N();
     int K = p.K();
-    const int m0 = (tile / tiles_n) * GT, n0 = (tile % tiles_n) * GT;
+    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TM;
     if (m0 >= M || n0 >= N) {  // tile outside this (ragged) task: contributes zero partials
         if (P::NRED > 0 && threadIdx.x == 0) {
             float z[(P::NRED > 0 ? P::NRED : 1)];
@@ -102,51 +117,51 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
         return;
     }
 
-    __shared__ float As[(P::A_KCONTIG ? GT * LD_MN : GK * LD_K)];
-    __shared__ float Bs[(P::B_KCONTIG ? GT * LD_MN : GK * LD_K)];
+    __shared__ float As[(P::A_KCONTIG ? TM * LD_MN : GK * LD_K)];
+    __shared__ float Bs[(P::B_KCONTIG ? TM * LD_MN : GK * LD_K)];
     __shared__ float red_s[(P::NRED > 0 ? P::NRED * 4 : 1)];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wr = wv >> 1, wc = wv & 1;  // 2x2 waves, 32x32 each
+    const int wr = wv >> 1, wc = wv & 1;  // 2x2 waves, WT x WT each
     const int fi = lane & 15, fk = lane >> 4;
 
-    f32x4 acc[2][2];
+    f32x4 acc[MI][MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if constexpr (has_skip<P>::value) {
         if (p.skip(m0, n0)) K = 0;
     }
     float ra[GPT], rb[GPT];
-    gemm_fetch<P, true>(p, ra, m0, 0, M, K);
-    gemm_fetch<P, false>(p, rb, n0, 0, N, K);
+    gemm_fetch<P, true, TM>(p, ra, m0, 0, M, K);
+    gemm_fetch<P, false, TM>(p, rb, n0, 0, N, K);
     for (int k0 = 0; k0 < K; k0 += GK) {
-        gemm_stage<P::A_KCONTIG>(As, ra);
-        gemm_stage<P::B_KCONTIG>(Bs, rb);
+        gemm_stage<P::A_KCONTIG, TM>(As, ra);
+        gemm_stage<P::B_KCONTIG, TM>(Bs, rb);
         __syncthreads();
         if (k0 + GK < K) {  // next chunk's loads fly while this chunk is multiplied
-            gemm_fetch<P, true>(p, ra, m0, k0 + GK, M, K);
-            gemm_fetch<P, false>(p, rb, n0, k0 + GK, N, K);
+            gemm_fetch<P, true, TM>(p, ra, m0, k0 + GK, M, K);
+            gemm_fetch<P, false, TM>(p, rb, n0, k0 + GK, N, K);
         }
 #pragma unroll
         for (int s = 0; s < GK / 4; ++s) {
-            float af[2], bf[2];
+            float af[MI], bf[MI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = wr * 32 + i * 16 + fi;
+            for (int i = 0; i < MI; ++i) {
+                const int r = wr * WT + i * 16 + fi;
                 af[i] = P::A_KCONTIG ? As[r * LD_MN + 4 * s + fk] : As[(4 * s + fk) * LD_K + r];
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = wc * 32 + j * 16 + fi;
+            for (int j = 0; j < MI; ++j) {
+                const int c = wc * WT + j * 16 + fi;
                 bf[j] = P::B_KCONTIG ? Bs[c * LD_MN + 4 * s + fk] : Bs[(4 * s + fk) * LD_K + c];
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < MI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
@@ -157,11 +172,11 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
 #pragma unroll
     for (int q = 0; q < (P::NRED > 0 ? P::NRED : 1); ++q) red[q] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int gi0 = m0 + wr * 32 + i * 16 + fk * 4;
-            const int gj = n0 + wc * 32 + j * 16 + fi;
+        for (int j = 0; j < MI; ++j) {
+            const int gi0 = m0 + wr * WT + i * 16 + fk * 4;
+            const int gj = n0 + wc * WT + j * 16 + fi;
             if constexpr (has_epi4<P>::value) {
                 if (gi0 + 3 < M && gj < N) {
                     const float v4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
