@@ -357,3 +357,44 @@ class GraphFeatureExtractor(nn.Module):
         missing = [k for k in missing if "num_batches_tracked" not in k and "running_" not in k]
         if missing or unexpected:
             raise KeyError(f"reference checkpoint does not match: missing {missing}, unexpected {unexpected}")
+
+    def reference_state_dict(self, prefix: str = "graph_feature_extractor.") -> Dict[str, torch.Tensor]:
+        """The inverse of ``load_reference_state_dict``: this module's parameters under the reference's names and
+        shapes (what ``ADKTModelTrainer.save_model`` would have written for the same weights)."""
+        g = self.config.gnn_config
+        own = {k: v.detach() for k, v in self.state_dict().items()}
+        out: Dict[str, torch.Tensor] = {"init_node_proj.weight": own["init_node_proj.weight"]}
+        for b in range(g.num_layers):
+            p = f"gnn.gnn_blocks.{b}."
+            if g.use_rezero_scaling:
+                out[p + "alpha"] = own[p + "alpha"]
+            for et in range(g.num_edge_types):
+                for l in range(g.message_function_depth):
+                    k = et * g.message_function_depth + l
+                    for h in range(g.num_heads):
+                        out[f"{p}mp_layers.{h}.message_fns.{et}._layers.{2 * l}.weight"] = own[f"{p}mp.weights.{k}"][h].t().contiguous()
+                        out[f"{p}mp_layers.{h}.message_fns.{et}._layers.{2 * l}.bias"] = own[f"{p}mp.biases.{k}"][h].clone()
+            names = ["msg_out_projection.weight", "msg_out_projection.bias", "mp_norm_layer.weight", "mp_norm_layer.bias"]
+            if g.intermediate_dim > 0:
+                names += ["boom_layer.linear1.weight", "boom_layer.linear1.bias", "boom_layer.linear2.weight",
+                          "boom_layer.linear2.bias", "boom_norm_layer.weight", "boom_norm_layer.bias"]
+            for name in names:
+                out[p + name] = own[p + name]
+        r = "readout."
+        fw, fb = own[r + "first.weight"], own[r + "first.bias"]
+        hid = fw.shape[0] // 4
+        q = 0
+        for pool, tag in (("_weighted_mean_pooler", "mean"), ("_weighted_sum_pooler", "sum")):
+            for mlp, kind in (("_scoring_module", "score"), ("_transformation_mlp", "value")):
+                out[f"{r}{pool}.{mlp}._layers.0.weight"] = fw[q * hid:(q + 1) * hid].clone()
+                out[f"{r}{pool}.{mlp}._layers.0.bias"] = fb[q * hid:(q + 1) * hid].clone()
+                out[f"{r}{pool}.{mlp}._layers.2.weight"] = own[f"{r}{tag}_{kind}_out.weight"]
+                out[f"{r}{pool}.{mlp}._layers.2.bias"] = own[f"{r}{tag}_{kind}_out.bias"]
+                q += 1
+            out[f"{r}{pool}._combination_layer.weight"] = own[f"{r}{tag}_combination.weight"]
+        out[r + "_max_pooler._combination_layer.weight"] = own[r + "max_combination.weight"]
+        out[r + "_combination_layer.weight"] = own[r + "combination_layer.weight"]
+        for k in ("final_norm_layer.weight", "final_norm_layer.bias"):
+            if k in own:
+                out[k] = own[k]
+        return {prefix + k: v for k, v in out.items()}

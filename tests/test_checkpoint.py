@@ -1,0 +1,90 @@
+"""CPU: checkpoint compatibility.  A file with the reference's layout - pickled ``fs_mol.*`` config dataclasses, state dict
+under the reference's parameter names (per-tower Linear layers, GP copies under ``mll.``, prior buffers) - is written with
+stand-in classes living in throw-away ``fs_mol`` modules, which are REMOVED before loading: the loader must cope without
+the reference package.  The loaded model must reproduce the naive restatement of the reference extractor."""
+import sys
+import types
+from dataclasses import dataclass, field
+
+import torch
+
+from adkf_ift_amd import checkpoint as CK
+from adkf_ift_amd.models import ADKTModel
+from oracle import gnn_oracle as GO
+from test_gnn import random_graphs
+
+
+def _fake_reference_modules():
+    mods = {}
+    for name in ("fs_mol", "fs_mol.modules", "fs_mol.modules.gnn", "fs_mol.modules.graph_readout",
+                 "fs_mol.modules.graph_feature_extractor", "fs_mol.utils", "fs_mol.utils.adaptive_dkt_utils"):
+        mods[name] = types.ModuleType(name)
+
+    def make(module, cls_name, **defaults):
+        ns = {"__annotations__": {k: type(v) for k, v in defaults.items()}, "__module__": module}
+        ns.update(defaults)
+        cls = dataclass(type(cls_name, (), ns))
+        setattr(mods[module], cls_name, cls)
+        return cls
+
+    G = make("fs_mol.modules.gnn", "GNNConfig", type="PNA", num_edge_types=3, hidden_dim=16, num_heads=4, per_head_dim=6,
+             intermediate_dim=24, message_function_depth=1, num_layers=3, dropout_rate=0.0, use_rezero_scaling=True,
+             make_edges_bidirectional=True)
+    R = make("fs_mol.modules.graph_readout", "GraphReadoutConfig", readout_type="combined", use_all_states=True, num_heads=3,
+             head_dim=5, output_dim=10)
+    F = make("fs_mol.modules.graph_feature_extractor", "GraphFeatureExtractorConfig", initial_node_feature_dim=32,
+             gnn_config=None, readout_config=None, output_norm="off")
+    Tcfg = make("fs_mol.utils.adaptive_dkt_utils", "ADKTModelTrainerConfig", graph_feature_extractor_config=None,
+                used_features="gnn+ecfp+fc", batch_size=64, tasks_per_batch=16, support_set_size=16, query_set_size=256,
+                num_train_steps=10000, validate_every_num_steps=50, validation_support_set_sizes=(16, 128),
+                validation_query_set_size=256, validation_num_samples=5, learning_rate=1e-4, clip_value=1.0,
+                use_ard=False, gp_kernel="matern", use_lengthscale_prior=True, use_numeric_labels=False,
+                ignore_grad_correction=False)
+    sys.modules.update(mods)
+    return mods, Tcfg(graph_feature_extractor_config=F(gnn_config=G(), readout_config=R()))
+
+
+def test_reference_checkpoint_round_trip(tmp_path):
+    mods, ref_cfg = _fake_reference_modules()
+    try:
+        ours_cfg = CK.convert_config(ref_cfg)
+        gen = torch.Generator().manual_seed(3)
+        sd = GO.random_reference_state_dict(ours_cfg.graph_feature_extractor_config, seed=5, dtype=torch.float32)
+        fc_in = 10 + 2048
+        sd.update({"fc.0.weight": torch.randn(2048, fc_in, generator=gen) * 0.02, "fc.0.bias": torch.randn(2048, generator=gen),
+                   "fc.2.weight": torch.randn(2048, 2048, generator=gen) * 0.02, "fc.2.bias": torch.randn(2048, generator=gen),
+                   "gp_likelihood.noise_covar.raw_noise": torch.tensor([-2.0]),
+                   "gp_likelihood.noise_covar.noise_prior.loc": torch.tensor(-2.24),
+                   "gp_likelihood.noise_covar.raw_noise_constraint.lower_bound": torch.tensor(1e-4),
+                   "gp_model.likelihood.noise_covar.raw_noise": torch.tensor([-2.0]),
+                   "gp_model.covar_module.raw_outputscale": torch.tensor(0.3),
+                   "gp_model.covar_module.base_kernel.raw_lengthscale": torch.tensor([[1.5]]),
+                   "mll.likelihood.noise_covar.raw_noise": torch.tensor([-2.0]),
+                   "mll.model.covar_module.raw_outputscale": torch.tensor(0.3)})
+        path = str(tmp_path / "best_validation.pt")
+        torch.save({"model_config": ref_cfg, "model_state_dict": sd, "epoch": 7}, path)
+    finally:
+        for k in mods:
+            sys.modules.pop(k, None)
+    assert "fs_mol" not in sys.modules
+    model, ckpt = CK.load_reference_checkpoint(path)
+    assert isinstance(model, ADKTModel) and ckpt["epoch"] == 7
+    assert model.config.gp_kernel == "matern" and model.config.graph_feature_extractor_config.gnn_config.num_layers == 3
+    batch = random_graphs(5, seed=9)
+    batch.node_features = batch.node_features.float()
+    want = GO.graph_feature_extractor(batch, sd, model.config.graph_feature_extractor_config)
+    got = model.graph_feature_extractor(batch)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5)
+    assert torch.equal(model.fc[0].weight, sd["fc.0.weight"]) and torch.equal(model.fc[2].bias, sd["fc.2.bias"])
+    assert abs(model.gp_model.covar_module.raw_outputscale.item() - 0.3) < 1e-6
+    # and back: the reference's names and shapes, bit-identical values
+    back = CK.reference_state_dict(model)
+    for k, v in sd.items():
+        if k.startswith(("graph_feature_extractor.", "fc.")) or k in CK.GP_PARAM_NAMES:
+            assert k in back and back[k].shape == v.shape and torch.equal(back[k], v), k
+    assert set(back) <= set(sd)            # nothing the reference's load_model_weights would not find in its own model
+    path2 = str(tmp_path / "ours.pt")
+    CK.save_model(model, path2, optimizer=torch.optim.Adam(model.feature_extractor_params(), 1e-4), epoch=8)
+    model2, ck2 = CK.load_reference_checkpoint(path2)
+    assert ck2["epoch"] == 8 and "optimizer_state_dict" in ck2
+    assert torch.equal(model2.graph_feature_extractor(batch), got)
