@@ -349,9 +349,15 @@ class ADKTModel(_DeepKernelBase):
 
     def forward(self, input_batch, train_loss: Optional[bool], predictive_val_loss: bool = False,
                 is_functional_call: bool = False):
-        Z_s = self._features(input_batch.support_features)
-        Z_q = self._features(input_batch.query_features)
-        y_s, y_q = self._labels(input_batch)
+        return self._tail(*self._task_tensors(input_batch), train_loss, predictive_val_loss, is_functional_call)
+
+    def _task_tensors(self, batch):
+        """(Z_s, y_s, Z_q, y_q) of one task."""
+        y_s, y_q = self._labels(batch)
+        return self._features(batch.support_features), y_s, self._features(batch.query_features), y_q
+
+    def _tail(self, Z_s, y_s, Z_q, y_q, train_loss: Optional[bool], predictive_val_loss: bool, is_functional_call: bool):
+        """The four modes of ``ADKTModel.forward`` (adaptive_dkt.py:166-205) on given features."""
         if self.training:
             assert train_loss is not None
             if train_loss:
@@ -402,11 +408,7 @@ class _FusedTask:
         m = self.model
         fe = {n: p for n, p in zip(self.fe_names, params_outer)}
 
-        def feats(batch):
-            return m._features(batch.support_features), m._features(batch.query_features)
-
-        Z_s, Z_q = functional_call(_Features(m), {"m." + n: p for n, p in fe.items()}, (self.batch,))
-        y_s, y_q = m._labels(self.batch)
+        Z_s, y_s, Z_q, y_q = functional_call(_Features(m), {"m." + n: p for n, p in fe.items()}, (self.batch,))
         phi = torch.cat([p.detach().reshape(-1) for p in params_inner])[None]
         b = gp_ops.GPBatch(Z_s.detach()[None], y_s[None], m.mll.priors_row(Z_s.device), m.gp_model.kernel_id,
                            Z_q=Z_q.detach()[None], y_q=y_q[None])
@@ -432,8 +434,11 @@ class _Features(nn.Module):
         super().__init__()
         self.m = m
 
-    def forward(self, batch):
-        return self.m._features(batch.support_features), self.m._features(batch.query_features)
+    def forward(self, batch, outer: Optional[bool] = None):
+        t = self.m._task_tensors(batch)
+        if outer is None:
+            return t
+        return self.m._tail(*t, train_loss=not outer, predictive_val_loss=outer, is_functional_call=True)
 
 
 class GPTaskLoss:
@@ -444,9 +449,8 @@ class GPTaskLoss:
         self.task, self.outer = task, outer
 
     def __call__(self, params_outer, params_inner):
-        kwargs = ({"train_loss": False, "predictive_val_loss": True, "is_functional_call": True} if self.outer
-                  else {"train_loss": True, "is_functional_call": True})
-        return functional_call(self.task.model, self.task.param_dict(params_outer, params_inner), (self.task.batch,), kwargs)
+        params = {"m." + n: p for n, p in self.task.param_dict(params_outer, params_inner).items()}
+        return functional_call(_Features(self.task.model), params, (self.task.batch, self.outer))
 
 
 @dataclass(frozen=True)
@@ -487,3 +491,101 @@ class DKLModel(_DeepKernelBase):
     def compute_loss(self, logits: GPTrainHandle) -> torch.Tensor:
         assert self.training
         return -self.mll(logits, self.gp_model.train_targets)
+
+
+@dataclass(frozen=True)
+class DKTModelConfig(DKLModelConfig):
+    pass
+
+
+class DKTModel(DKLModel):
+    """fs_mol/models/dkt.py: Deep Kernel Transfer - GP hyper-parameters SHARED across tasks and trained with the
+    features on the joint marginal likelihood of support and query points (dkt.py:146-151); at test time the GP is
+    conditioned on the support set, optionally after re-fitting the hyper-parameters from their saved meta-learned
+    values (``test_time_adaptation``, dkt.py:152-168)."""
+
+    def __init__(self, config: DKTModelConfig):
+        super().__init__(config)
+        self.test_time_adaptation = False
+        self.gp_model_params = None
+        self.gp_likelihood_params = None
+
+    def save_gp_params(self):
+        from copy import deepcopy
+        self.gp_model_params = deepcopy(self.gp_model.state_dict())
+        self.gp_likelihood_params = deepcopy(self.gp_likelihood.state_dict())
+
+    def load_gp_params(self):
+        self.gp_model.load_state_dict(self.gp_model_params)
+        self.gp_likelihood.load_state_dict(self.gp_likelihood_params)
+
+    def forward(self, input_batch):
+        Z_s = self._features(input_batch.support_features)
+        Z_q = self._features(input_batch.query_features)
+        y_s, y_q = self._labels(input_batch)
+        if self.training:
+            Z = torch.cat([Z_s, Z_q], dim=0)
+            self.gp_model.set_train_data(inputs=Z, targets=torch.cat([y_s, y_q]), strict=False)
+            return GPTrainHandle(Z)
+        if self.test_time_adaptation:
+            self.load_gp_params()
+        self.gp_model.set_train_data(inputs=Z_s.detach(), targets=y_s, strict=False)
+        if self.test_time_adaptation:
+            fit_gpytorch_scipy(self.mll)
+        with torch.no_grad():
+            return self._posterior(Z_s, y_s, Z_q)
+
+
+class ADKFModel(ADKTModel):
+    """MoleculeNet variant (MoleculeNet/chem_lib/models/adkf_model.py:14-159): the same adaptive GP tail behind a
+    pluggable molecule encoder ``mol_encoder(x, edge_index, edge_attr, batch) -> (features, _)`` (the reference plugs in a
+    pre-trained GIN from torch_geometric; any module with that signature works).  Classification labels only,
+    lengthscale prior always on, no ARD (adkf_model.py:55,72)."""
+
+    def __init__(self, mol_encoder: nn.Module, emb_dim: int, gp_kernel: str = "matern"):
+        nn.Module.__init__(self)
+        self.mol_encoder = mol_encoder
+        self.emb_dim = self.fc_out_dim = emb_dim
+        self.gp_kernel = gp_kernel
+        self.config = ADKTModelConfig(used_features="encoder", gp_kernel=gp_kernel, use_lengthscale_prior=True,
+                                      use_numeric_labels=False, fc_out_dim=emb_dim)
+        self._ADKTModel__create_tail_GP(kernel_type=gp_kernel)
+
+    @staticmethod
+    def _convert_bool_labels(labels):
+        return (labels.float() - 0.5) * 2.0
+
+    def _encode(self, data):
+        return self.mol_encoder(data.x, data.edge_index, data.edge_attr, data.batch)[0]
+
+    def _task_tensors(self, batch):
+        """batch = (s_data, q_data, s_label), the arguments of ``forward`` (adkfift_trainer.py:177-199)."""
+        s_data, q_data, s_label = batch
+        return self._encode(s_data), self._convert_bool_labels(s_label), self._encode(q_data), self._convert_bool_labels(q_data.y)
+
+    def forward(self, s_data, q_data, train_loss: Optional[bool], s_label=None, q_pred_adj=False,
+                predictive_val_loss: bool = False, is_functional_call: bool = False):
+        assert self.training and train_loss is not None      # adkf_model.py:104-105
+        Z_s = self._encode(s_data)
+        y_s = self._convert_bool_labels(s_label)
+        Z_q = y_q = None
+        if q_data is not None:
+            Z_q, y_q = self._encode(q_data), self._convert_bool_labels(q_data.y)
+        if not train_loss and not predictive_val_loss:
+            raise NotImplementedError                          # adkf_model.py:127-131
+        return self._tail(Z_s, y_s, Z_q, y_q, train_loss, predictive_val_loss, is_functional_call)
+
+    def forward_query_loader(self, s_data, q_loader, train_loss=None, s_label=None, q_pred_adj=False,
+                             predictive_val_loss: bool = False, is_functional_call: bool = False):
+        """Evaluation: sigmoid of the posterior mean for every query batch (adkf_model.py:136-160)."""
+        assert not self.training and train_loss is None
+        with torch.no_grad():
+            Z_s = self._encode(s_data)
+            y_s = self._convert_bool_labels(s_label)
+            self.gp_model.set_train_data(inputs=Z_s, targets=y_s, strict=False)
+            means, labels = [], []
+            for q_data in q_loader:
+                q_data = q_data.to(Z_s.device)
+                labels.append(q_data.y)
+                means.append(self._posterior(Z_s, y_s, self._encode(q_data)).mean)
+        return torch.sigmoid(torch.cat(means, 0)), torch.cat(labels, 0)

@@ -220,3 +220,129 @@ def test_batched_meta_step_equals_per_task_reference_loop(dev):
         g = p.grad if p.grad is not None else torch.zeros_like(p)
         assert (g - a).abs().max().item() <= 2e-3 * scale, ((g - a).abs().max().item(), scale)
     assert np.abs(got_losses.cpu().numpy() - np.array(losses)).max() <= 1e-3 * np.abs(losses).max()
+
+
+def test_dkt_model_joint_mll_and_test_time_adaptation(dev):
+    """fs_mol/models/dkt.py: training loss = -MLL of support U query under shared GP parameters; evaluation conditions
+    on the support set, optionally after re-fitting from the saved meta-learned parameters."""
+    from adkf_ift_amd.models import DKTModel, DKTModelConfig
+    from oracle import gp_oracle as O
+
+    torch.manual_seed(2)
+    model = DKTModel(DKTModelConfig(used_features="ecfp+fc", gp_kernel="matern", fc_hidden_dim=16, fc_out_dim=8)).to(dev)
+    batch = make_batch(dev, ns=16, nq=24, seed=5)
+    model.train()
+    loss = model.compute_loss(model(batch))
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    Zs = model._features(batch.support_features).detach().double().cpu()
+    Zq = model._features(batch.query_features).detach().double().cpu()
+    ys, yq = (batch.support_labels.double().cpu() - 0.5) * 2, (batch.query_labels.double().cpu() - 0.5) * 2
+    phi = torch.cat([p.detach().reshape(-1) for p in model.mll.raw_params()]).double().cpu()
+    noise, os_, ls = O.transform_phi(phi)
+    Z, y = torch.cat([Zs, Zq]), torch.cat([ys, yq])
+    A = O.kernel_matrix(Z, Z, os_, ls, 1) + noise * torch.eye(40, dtype=torch.float64)
+    ref = -O.mvn_log_prob(y, torch.zeros_like(y), A) / 40
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    model.save_gp_params()
+    model.eval()
+    post = model(batch)
+    mean, cov = O.predict(Zs, ys, Zq, phi, 1)
+    assert (post.mean.double().cpu() - mean).abs().max().item() <= 1e-4 * max(1.0, mean.abs().max().item())
+    model.test_time_adaptation = True
+    post2 = model(batch)
+    phi2 = torch.cat([p.detach().reshape(-1) for p in model.mll.raw_params()]).double().cpu()
+    def nll(p):   # no priors in DKT (fs_mol/models/dkt.py:85)
+        n_, o_, l_ = O.transform_phi(p)
+        return -O.mvn_log_prob(ys, torch.zeros_like(ys), O.kernel_matrix(Zs, Zs, o_, l_, 1) + n_ * torch.eye(16, dtype=torch.float64)) / 16
+    assert nll(phi2).item() < nll(phi).item()
+    mean2, _ = O.predict(Zs, ys, Zq, phi2, 1)
+    assert (post2.mean.double().cpu() - mean2).abs().max().item() <= 1e-4 * max(1.0, mean2.abs().max().item())
+
+
+def test_moleculenet_adkf_model_fused_hypergradient(dev):
+    """MoleculeNet/chem_lib/models/adkf_model.py + adkfift_trainer.py:173-201 with a stand-in encoder: reinit + fit +
+    cauchy_hypergradient through the pluggable-encoder model equals the dense reference algorithm on the oracle."""
+    from types import SimpleNamespace
+    from adkf_ift_amd.hypergradient import cauchy_hypergradient
+    from adkf_ift_amd.models import ADKFModel, fit_gpytorch_scipy
+    from oracle import gp_oracle as O
+    from oracle.hypergrad_oracle import dense_ift_hypergradient
+
+    class Enc(torch.nn.Module):   # signature of the reference's GNN_Encoder: (x, edge_index, edge_attr, batch) -> (emb, node_emb)
+        def __init__(self):
+            super().__init__()
+            self.l1, self.l2 = torch.nn.Linear(10, 16), torch.nn.Linear(16, 6)
+        def forward(self, x, edge_index, edge_attr, batch):
+            return self.l2(torch.tanh(self.l1(x))), None
+
+    torch.manual_seed(4)
+    g = torch.Generator().manual_seed(4)
+    data = lambda n: SimpleNamespace(x=torch.randn(n, 10, generator=g).to(dev), edge_index=None, edge_attr=None, batch=None,
+                                     y=(torch.rand(n, generator=g) > 0.5).to(dev), to=lambda d: None)
+    s_data, q_data = data(20), data(32)
+    q_data.to = lambda d: q_data
+    model = ADKFModel(Enc(), 6, "matern").to(dev)
+    model.train()
+    assert model(s_data, q_data, train_loss=True, s_label=s_data.y) is None      # re-initialises the GP tail
+    fit_gpytorch_scipy(model.mll)
+    f_outer, f_inner = model.task_losses((s_data, q_data, s_data.y))
+    po, pi = tuple(model.feature_extractor_params()), tuple(model.gp_params())
+    val = cauchy_hypergradient(f_outer, f_inner, po, pi, dev)
+    # oracle: same encoder in float64 on the CPU
+    enc64 = Enc().double()
+    enc64.load_state_dict({k: v.double().cpu() for k, v in model.mol_encoder.state_dict().items()})
+    names = [n for n, _ in enc64.named_parameters()]
+    Xs, Xq = s_data.x.double().cpu(), q_data.x.double().cpu()
+    ys, yq = (s_data.y.double().cpu() - 0.5) * 2, (q_data.y.double().cpu() - 0.5) * 2
+    pri = O.Priors(*model.mll.priors_row(torch.device("cpu"))[0].double().tolist())
+    from torch.func import functional_call as fc
+    feats = lambda p, X: fc(enc64, dict(zip(names, p)), (X, None, None, None))[0]
+    fin = lambda p, q: O.f_inner(feats(p, Xs), ys, torch.cat([t.reshape(-1) for t in q]), pri, 1)
+    fout = lambda p, q: O.f_outer(feats(p, Xs), ys, feats(p, Xq), yq, torch.cat([t.reshape(-1) for t in q]), 1)
+    p64 = tuple(p.detach().double().cpu().requires_grad_() for p in enc64.parameters())
+    q64 = tuple(p.detach().double().cpu().requires_grad_() for p in pi)
+    ref_val = dense_ift_hypergradient(fout, fin, p64, q64)
+    assert abs(val.item() - ref_val.item()) <= 1e-4 * abs(ref_val.item())
+    scale = max(q.grad.abs().max().item() for q in p64)
+    for p, q in zip(po, p64):
+        assert (p.grad.double().cpu() - q.grad).abs().max().item() <= 1e-3 * scale
+    model.eval()
+    probs, labels = model.forward_query_loader(s_data, [q_data], s_label=s_data.y)
+    assert probs.shape == (32,) and labels.shape == (32,) and ((probs > 0) & (probs < 1)).all()
+
+
+def test_bayes_opt_gp_ei_loop(dev):
+    """bayes_opt/bo_utils.py create_gp + EI: the fitted GP's latent posterior and EI values against the oracle, and
+    a short BO run on a toy objective whose minimiser must be found."""
+    from adkf_ift_amd import bayes_opt as BO
+    from adkf_ift_amd.models import fit_gpytorch_scipy
+    from oracle import gp_oracle as O
+
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(60, 5, generator=g)
+    y = ((X - 0.3) ** 2).sum(1)
+    order = torch.argsort(y)
+    X, y = X[order].to(dev), y[order].to(dev)           # ascending y: index 0 is the optimum
+    idx = [40, 45, 50, 55, 59, 30]
+    ys = (y - y.mean()) / y.std()
+    lik, model, mll = BO.create_gp(X[idx], ys[idx], "matern", dev, noise_init=0.01, noise_prior=True)
+    fit_gpytorch_scipy(mll)
+    mean, var = BO.latent_posterior(model, mll, X)
+    phi = torch.cat([p.detach().reshape(-1) for p in mll.raw_params()]).double().cpu()
+    m_ref, cov = O.predict(X[idx].double().cpu(), ys[idx].double().cpu(), X.double().cpu(), phi, 1)
+    noise = O.transform_phi(phi)[0]
+    v_ref = cov.diagonal() - noise
+    assert (mean.double().cpu() - m_ref).abs().max().item() <= 1e-4 * max(1.0, m_ref.abs().max().item())
+    free = [i for i in range(60) if i not in idx]
+    assert (var.double().cpu()[free] - v_ref[free]).abs().max().item() <= 2e-4 * v_ref.abs().max().item()
+    ei = BO.expected_improvement(mean, var, ys[idx].min().item())
+    s = v_ref.clamp_min(1e-12).sqrt()
+    u = (ys[idx].min().item() - m_ref) / s
+    nrm = torch.distributions.Normal(0.0, 1.0)
+    ei_ref = s * (u * nrm.cdf(u) + torch.exp(nrm.log_prob(u)))
+    assert (ei.double().cpu()[free] - ei_ref[free]).abs().max().item() <= 1e-3 * ei_ref[free].abs().max().item()
+    rec = BO.run_gp_ei_bo(X, y, num_init_points=6, query_batch_size=2, num_bo_iters=8, kernel_type="matern", device=dev,
+                          init_from=20, noise_init=0.01, noise_prior=True, rng=np.random.default_rng(0))
+    assert len(rec) == 1 + 8 * 2 and len(set(rec[1:])) == 16
+    assert min(rec) <= 2          # reaches (one of) the best three points out of 60 within 16 queries
