@@ -63,6 +63,31 @@ def gp_case(N, Nq, d, kind, regression, seed, fitted):
     return out
 
 
+def ard_case(N, Nq, d, kind, regression, seed, fitted):
+    """ARD kernel (``use_ard``: one lengthscale per feature dimension, h = 2 + d): same quantities as gp_case, from the
+    autograd oracle.  H is kept (h x h) because the HIP path's Hessian-vector products are checked against its columns."""
+    tasks = make_tasks(1, N, d, N_q=Nq, regression=regression, first_task=seed)
+    Zs, Zq = tasks.features()
+    Zs, Zq, ys, yq = Zs[0], Zq[0], tasks.y_s[0], tasks.y_q[0]
+    phi0, pri = O.init_phi(Zs.double(), use_numeric_labels=regression, use_lengthscale_prior=True, ard=True)
+    if fitted:
+        phi, res = O.fit_phi(Zs, ys, phi0, pri, kind)
+        nit = res.nit
+    else:
+        g = torch.Generator().manual_seed(199 + seed)
+        phi = phi0 + 0.3 * torch.randn(2 + d, generator=g, dtype=torch.float64)
+        nit = 0
+    q = O.full_reference_quantities(Zs, ys, Zq, yq, phi, pri, kind)
+    out = dict(Z_s=Zs.numpy(), Z_q=Zq.numpy(), y_s=ys.numpy(), y_q=yq.numpy(), phi=phi.numpy(), phi0=phi0.numpy(),
+               priors=pri.as_array(), kind=np.int64(kind), regression=np.int64(regression), fitted=np.int64(fitted),
+               fit_nit=np.int64(nit), ard=np.int64(1))
+    for k, v in q.items():
+        if k in ("pred_cov", "dZs_direct", "dZq_direct"):
+            continue
+        out[k] = np.asarray(v)
+    return out
+
+
 def linear_map_case(N, Nq, d, kind, seed):
     """theta = W [d,d]; Z = X W / sqrt(d).  theta.grad from BOTH reference variants."""
     ch = _load("cauchy_hypergradient").cauchy_hypergradient
@@ -150,7 +175,13 @@ def main():
     for kind in (0, 1):
         cases.append((f"linmap_N16_Nq24_d12_k{kind}", lambda k=kind: linear_map_case(16, 24, 12, k, 7)))
     cases.append(("harness_T4_N16_d8_k0", lambda: harness_case(4, 16, 8, 0)))
+    for a in [(8, 8, 4, 0, 0, 0, 1), (16, 24, 12, 1, 0, 1, 0), (32, 32, 16, 0, 1, 0, 1), (48, 40, 24, 1, 0, 2, 1),
+              (128, 128, 64, 1, 0, 0, 0)]:
+        cases.append(("ard_N%d_Nq%d_d%d_k%d_r%d_s%d" % a[:6], lambda a=a: ard_case(*a)))
+    only = sys.argv[1] if len(sys.argv) > 1 else ""     # python make_golden.py [name-prefix]
     for name, fn in cases:
+        if not name.startswith(only):
+            continue
         out = fn()
         np.savez(os.path.join(HERE, name + ".npz"), **out)
         print(name, "ok", flush=True)

@@ -86,3 +86,31 @@ def test_mll_is_divided_by_n_after_priors():
     mvn = torch.distributions.MultivariateNormal(torch.zeros(6, dtype=torch.float64), A).log_prob(y)
     expect = -(mvn + O.lognormal_log_prob(noise, -2.2, 0.25) + O.lognormal_log_prob(ls, 0.4, 0.25)) / 6
     assert abs(O.f_inner(Z, y, phi, pri, 0).item() - expect.item()) < 1e-12
+
+
+def test_ard_closed_forms_match_autograd_fixtures(golden_dir):
+    """The scaled-feature / homogeneity formulation of the ARD kernel (oracle/closed_form_ard.py: gradient, Hessian-vector
+    product, mixed term, CG solve) against the autograd fixtures."""
+    import glob
+    from oracle.closed_form_ard import ArdTask, cg_solve, full_pipeline_ard
+
+    files = sorted(glob.glob(os.path.join(golden_dir, "ard_*.npz")))
+    assert len(files) >= 5
+    for f in files:
+        z = np.load(f)
+        dense = z["Z_s"].shape[0] <= 48
+        r = full_pipeline_ard(z["Z_s"], z["y_s"], z["Z_q"], z["y_q"], z["phi"], z["priors"], int(z["kind"]), dense_solve=dense)
+        keys = ["f_in", "g_in", "f_out", "g_out", "v", "dfin_dZs", "mixed_Zs", "dZs_total", "dZq_total", "pred_mean", "pred_var"]
+        if dense:
+            keys.append("H")
+        for k in keys:
+            want = np.asarray(z[k], dtype=np.float64)
+            err = np.abs(np.asarray(r[k]) - want).max() / max(np.abs(want).max(), 1e-300)
+            assert err <= (1e-9 if dense else 1e-6), (os.path.basename(f), k, err)
+    # Hessian-vector product against a column combination of the stored H; CG recovers v
+    z = np.load(files[0])
+    t = ArdTask(z["Z_s"], z["y_s"], z["phi"], z["priors"], int(z["kind"]))
+    u = np.linspace(-1, 1, z["phi"].size)
+    assert np.abs(t.hvp(u) - z["H"] @ u).max() <= 1e-10 * np.abs(z["H"] @ u).max()
+    v, its = cg_solve(t.hvp, z["g_out"])
+    assert np.abs(v - z["v"]).max() <= 1e-8 * np.abs(z["v"]).max() and its <= 3 * z["phi"].size
