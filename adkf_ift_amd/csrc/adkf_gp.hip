@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/adkf_gp.h"
-#include "large.h"
+#include "ard.h"
 
 using namespace adkf;
 
@@ -124,15 +124,19 @@ inline bool has_query(const adkf_batch_t* b) { return b->nq_max > 0 && b->Z_q !=
 
 // Stage A: centring, row norms, squared distances.  Skipped when the caller promises (ADKF_BATCH_REUSE_DIST) that
 // this workspace already holds them for exactly this batch.
-int stage_dist(const adkf_batch_t* b, const Workspace& w, bool with_query, hipStream_t st) {
+// parts: 1 = the support block (mean, norms, D2ss), 2 = the query blocks (needs the support mean / norms in place).
+int stage_dist(const adkf_batch_t* b, const Workspace& w, bool with_query, hipStream_t st, int parts = 3) {
     if (b->flags & ADKF_BATCH_REUSE_DIST) return 0;
     const int T = b->T, ns = b->ns_max, nq = with_query ? b->nq_max : 0, d = b->d;
-    k_colmean<<<dim3(ceil_div(d, 64), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, T);
-    k_rownorm<<<dim3(ceil_div(ns, 4), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, w.nrm_s, T);
+    if (!(parts & 2)) with_query = false;
+    if (parts & 1) {
+        k_colmean<<<dim3(ceil_div(d, 64), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, T);
+        k_rownorm<<<dim3(ceil_div(ns, 4), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, w.nrm_s, T);
+    }
     if (with_query) k_rownorm<<<dim3(ceil_div(nq, 4), T), 256, 0, st>>>(b->Z_q, b->n_q, nq, d, w.mean, w.nrm_q, T);
     ProbDist p;
     p.mean = w.mean; p.d = d; p.vec = vec_ok(b, w);
-    {
+    if (parts & 1) {
         p.X = b->Z_s; p.Y = b->Z_s; p.nx = w.nrm_s; p.ny = w.nrm_s; p.n_x = b->n_s; p.n_y = b->n_s; p.x_ld = ns; p.y_ld = ns; p.symmetric = true; p.D2 = w.D2ss;
         launch_gemm(p, T, ns, ns, st);
     }
@@ -325,6 +329,252 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
     return 0;
 }
 
+
+// ======================================================================================================================
+// ARD (ADKF_BATCH_ARD): host side.  See ard.h for the formulation.
+// ======================================================================================================================
+struct ArdWs {
+    float *mu, *ell, *Zt_s, *Zt_q, *G, *Gd_s, *Gd_q, *Gdot, *phi3, *pri3, *f3, *g3, *g3o, *S1, *gt, *coldot;
+    float *c, *ut2, *wn, *Ddot, *Wdot, *adot, *S2;
+    ArdFitState* fst; float *x, *g, *p, *xe, *ge, *S, *Y, *fe; int32_t* info3;
+    ArdCgState* cst; float *cx, *cr, *cp, *cHp, *gout;
+    size_t bytes;
+};
+
+ArdWs carve_ard(void* base, size_t off0, int T, int ns, int nq, int d) {
+    ArdWs a;
+    size_t off = off0;
+    auto take = [&](size_t nfloat) { float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr; off += align_up((nfloat ? nfloat : 1) * sizeof(float)); return p; };
+    const size_t Tz = (size_t)T, h = 2 + (size_t)d;
+    a.mu = take(Tz * d); a.ell = take(Tz * d);
+    a.Zt_s = take(Tz * ns * d); a.Zt_q = take(Tz * nq * d);
+    a.G = take(Tz * ns * d); a.Gd_s = take(Tz * ns * d); a.Gd_q = take(Tz * nq * d); a.Gdot = take(Tz * ns * d);
+    a.phi3 = take(Tz * 3); a.pri3 = take(Tz * 4); a.f3 = take(Tz); a.g3 = take(Tz * 3); a.g3o = take(Tz * 3);
+    a.S1 = take(Tz * d); a.gt = take(Tz * h); a.coldot = take(Tz * d);
+    a.c = take(Tz * d); a.ut2 = take(Tz * 2); a.wn = take(Tz * ns);
+    a.Ddot = take(Tz * ns * ns); a.Wdot = take(Tz * ns * ns); a.adot = take(Tz * ns); a.S2 = take(Tz * d);
+    a.fst = reinterpret_cast<ArdFitState*>(take(Tz * ((sizeof(ArdFitState) + 3) / 4)));
+    a.x = take(Tz * h); a.g = take(Tz * h); a.p = take(Tz * h); a.xe = take(Tz * h); a.ge = take(Tz * h);
+    a.S = take(Tz * ARD_M * h); a.Y = take(Tz * ARD_M * h); a.fe = take(Tz);
+    a.info3 = reinterpret_cast<int32_t*>(take(Tz));
+    a.cst = reinterpret_cast<ArdCgState*>(take(Tz * ((sizeof(ArdCgState) + 3) / 4)));
+    a.cx = take(Tz * h); a.cr = take(Tz * h); a.cp = take(Tz * h); a.cHp = take(Tz * h); a.gout = take(Tz * h);
+    a.bytes = off;
+    return a;
+}
+
+struct ArdCtx {
+    const adkf_batch_t* b;
+    adkf_batch_t bt;   // the scaled batch the non-ARD pipeline runs on
+    Workspace w; ArdWs a; ArdView v;
+    int T, ns, nq, d, h;
+    hipStream_t st;
+};
+
+int ard_setup(const adkf_batch_t* b, void* ws, size_t ws_bytes, hipStream_t st, ArdCtx& c) {
+    c.b = b; c.T = b->T; c.ns = b->ns_max; c.nq = b->nq_max; c.d = b->d; c.h = 2 + b->d; c.st = st;
+    c.w = carve(ws, c.T, c.ns, c.nq, c.d);
+    c.a = carve_ard(ws, c.w.bytes, c.T, c.ns, c.nq, c.d);
+    if (ws_bytes < c.a.bytes) return ADKF_E_WORKSPACE;
+    ArdView& v = c.v;
+    v.T = c.T; v.d = c.d; v.h = c.h; v.ns_ld = c.ns; v.nq_ld = c.nq; v.n_s = b->n_s; v.n_q = b->n_q;
+    v.Z_s = b->Z_s; v.Z_q = b->Z_q; v.Zt_s = c.a.Zt_s; v.Zt_q = c.a.Zt_q; v.mu = c.a.mu; v.ell = c.a.ell;
+    v.phi3 = c.a.phi3; v.pri3 = c.a.pri3; v.priors = b->priors; v.f3 = c.a.f3; v.g3 = c.a.g3; v.S1 = c.a.S1; v.gt = c.a.gt;
+    c.bt = *b;
+    c.bt.Z_s = c.a.Zt_s; c.bt.Z_q = has_query(b) ? c.a.Zt_q : nullptr; c.bt.priors = c.a.pri3; c.bt.flags = 0;
+    if (!(b->flags & ADKF_BATCH_REUSE_INNER))
+        k_colmean<<<dim3(ceil_div(c.d, 64), c.T), 256, 0, st>>>(b->Z_s, b->n_s, c.ns, c.d, c.a.mu, c.T);
+    return 0;
+}
+
+// d f / d Z~_s for the weights in w.Wss (symmetric) -> out
+void ard_dz_support(ArdCtx& c, const float* W, float* out) {
+    TaskView tv = make_tv(&c.bt, c.w, false);
+    RowsumArgs ra{tv, W, nullptr, nullptr, c.w.vecs, c.T};
+    launch_rowsums(ra, c.w, c.st);
+    ProbDZ<false> pz; pz.tv = tv; pz.Wss = W; pz.Wqs = nullptr; pz.Wqq = nullptr; pz.Zs = c.a.Zt_s; pz.Zq = nullptr; pz.dZ = out; pz.d = c.d;
+    launch_gemm(pz, c.T, c.ns, c.d, c.st);
+}
+
+// One evaluation of f_in and its gradient in the h raw parameters at x [T, h]; leaves Zt_s, D2ss, Ainv, alpha, the
+// scalars, G = d f_in / d Z~, S1 and gt for x in the workspace.
+int ard_eval(ArdCtx& c, const float* x, float* f, float* g, int32_t* info3) {
+    hipStream_t st = c.st;
+    k_ard_params<<<dim3(ceil_div(c.d, 256), c.T), 256, 0, st>>>(c.v, x);
+    k_ard_scale<<<dim3(ceil_div(c.d, 256), c.ns, c.T), 256, 0, st>>>(c.v, c.b->Z_s, c.a.Zt_s, c.b->n_s, c.ns);
+    int rc = stage_dist(&c.bt, c.w, false, st, 1);
+    if (rc) return rc;
+    InnerArgs ia = inner_args(&c.bt, c.w, c.a.phi3, info3);
+    ia.f_out = c.a.f3; ia.g_out = c.a.g3;
+    rc = launch_inner(ia, c.w, st);
+    if (rc) return rc;
+    TaskView tv = make_tv(&c.bt, c.w, false);
+    WinArgs wa{tv, c.w.Ainv, c.w.D2ss, c.w.Wss, c.w.scal, c.T};
+    k_win<<<grid_for(c.T, 1), 256, 0, st>>>(wa);
+    ard_dz_support(c, c.w.Wss, c.a.G);
+    ArdColdot cd{c.a.Zt_s, c.a.G, c.b->n_s, c.ns, nullptr, nullptr, nullptr, 0, c.a.S1, c.d};
+    k_ard_coldot<<<dim3(ceil_div(c.d, 64), c.T), 256, 0, st>>>(cd);
+    ArdEvalFin ef{c.v, x, f, g, info3};
+    k_ard_eval_fin<<<c.T, 256, 0, st>>>(ef);
+    LAUNCH_OK();
+    return 0;
+}
+
+ArdHvp ard_hvp_args(ArdCtx& c, const float* x, const float* u, float* Hu, const ArdCgState* cg) {
+    ArdHvp hv;
+    hv.v = c.v; hv.tv = make_tv(&c.bt, c.w, false); hv.x = x; hv.u = u; hv.Hu = Hu;
+    hv.c = c.a.c; hv.ut2 = c.a.ut2; hv.wn = c.a.wn; hv.D2 = c.w.D2ss; hv.Ainv = c.w.Ainv;
+    hv.Ddot = c.a.Ddot; hv.X = c.w.P; hv.Wdot = c.a.Wdot; hv.adot = c.a.adot;
+    hv.part = c.w.part_ma; hv.ntiles = c.w.nt_ma; hv.G = c.a.G; hv.Gdot = c.a.Gdot; hv.S2 = c.a.S2; hv.cg = cg;
+    return hv;
+}
+
+// Everything of one Hessian-vector product up to Gdot' = 4 (rowsum(Wdot) . Z~ - Wdot Z~) (needed alone by the mixed term)
+void ard_hvp_core(ArdCtx& c, const ArdHvp& hv) {
+    hipStream_t st = c.st;
+    k_ard_dir<<<dim3(ceil_div(c.d, 256), c.T), 256, 0, st>>>(hv);
+    k_ard_wnorm<<<dim3(ceil_div(c.ns, 4), c.T), 256, 0, st>>>(hv);
+    ProbArdDdot pd; pd.h = hv; launch_gemm(pd, c.T, c.ns, c.ns, st);
+    ProbArdX px; px.h = hv; launch_gemm(px, c.T, c.ns, c.ns, st);
+    k_ard_adot<<<dim3(ceil_div(c.ns, 4), c.T), 256, 0, st>>>(hv);
+    ProbArdY py; py.h = hv; launch_gemm(py, c.T, c.ns, c.ns, st);
+    ard_dz_support(c, c.a.Wdot, c.a.Gdot);
+}
+
+void ard_hvp(ArdCtx& c, const float* x, const float* u, float* Hu, const ArdCgState* cg) {
+    ArdHvp hv = ard_hvp_args(c, x, u, Hu, cg);
+    ard_hvp_core(c, hv);
+    ArdColdot cd{c.a.Zt_s, c.a.Gdot, c.b->n_s, c.ns, nullptr, nullptr, nullptr, 0, c.a.S2, c.d};
+    k_ard_coldot<<<dim3(ceil_div(c.d, 64), c.T), 256, 0, c.st>>>(cd);
+    k_ard_hvp_fin<<<c.T, 256, 0, c.st>>>(hv);
+}
+
+__global__ void k_ard_expand_phi(const float* phi3, float* phi, int T, int h) {
+    const int t = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k < h) phi[(size_t)t * h + k] = phi3[t * 3 + (k < 2 ? k : 2)];
+}
+
+__global__ void k_ard_cg_info(const ArdCgState* cg, int32_t* info, int32_t* iters, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    if (iters) iters[t] = cg[t].iters;
+    if (cg[t].breakdown && info[t] == 0) info[t] = 200000 + cg[t].iters + 1;   // H not positive definite along a CG direction
+}
+
+int ard_fit(const adkf_batch_t* b, float* phi, const adkf_fit_options_t* opt, float* f_final, float* gnorm, int32_t* n_evals,
+            int32_t* info, void* ws, size_t ws_bytes, hipStream_t st) {
+    ArdCtx c;
+    adkf_batch_t b0 = *b; b0.flags &= ~ADKF_BATCH_REUSE_INNER;
+    int rc = ard_setup(&b0, ws, ws_bytes, st, c);
+    if (rc) return rc;
+    ArdFitArgs fa;
+    fa.T = c.T; fa.h = c.h; fa.max_evals = opt->max_evals; fa.exact_evals = opt->exact_evals; fa.gtol = opt->gtol; fa.ftol = opt->ftol;
+    fa.st = c.a.fst; fa.x = c.a.x; fa.g = c.a.g; fa.p = c.a.p; fa.xe = c.a.xe; fa.ge = c.a.ge; fa.S = c.a.S; fa.Y = c.a.Y;
+    fa.fe = c.a.fe; fa.info_eval = c.a.info3; fa.phi = phi; fa.f_final = f_final; fa.gnorm = gnorm; fa.nevals = n_evals; fa.info = info;
+    k_ard_fit_begin<<<dim3(ceil_div(c.h, 256), c.T), 256, 0, st>>>(fa);
+    if (opt->ev_start && hipEventRecord(static_cast<hipEvent_t>(opt->ev_start), st) != hipSuccess) return ADKF_E_LAUNCH;
+    for (int e = 0; e < opt->max_evals; ++e) {
+        rc = ard_eval(c, c.a.xe, c.a.fe, c.a.ge, c.a.info3);
+        if (rc) return rc;
+        k_ard_advance<<<c.T, 256, 0, st>>>(fa);
+    }
+    if (opt->ev_stop && hipEventRecord(static_cast<hipEvent_t>(opt->ev_stop), st) != hipSuccess) return ADKF_E_LAUNCH;
+    LAUNCH_OK();
+    return 0;
+}
+
+// C = K_qs A^-1, predictive mean / variance (/ covariance) from the distances, A^-1 and scalars in the workspace
+int predict_core(const adkf_batch_t* b, const Workspace& w, float* mean, float* var, float* cov, hipStream_t st) {
+    TaskView tv = make_tv(b, w, true);
+    const int T = b->T;
+    ProbC pc; pc.tv = tv; pc.Ainv = w.Ainv; pc.D2qs = w.D2qs; pc.C = w.C;
+    launch_gemm(pc, T, b->nq_max, b->ns_max, st);
+    PredArgs pa{tv, w.C, w.D2qs, b->y_s, mean, var, w.scal, T};
+    k_predict<<<grid_for(T, 1), 256, 0, st>>>(pa);
+    if (cov) {
+        hipMemsetAsync(cov, 0, (size_t)T * b->nq_max * b->nq_max * sizeof(float), st);
+        ProbS ps; ps.tv = tv; ps.C = w.C; ps.D2qs = w.D2qs; ps.D2qq = w.D2qq; ps.S = cov;
+        launch_gemm(ps, T, b->nq_max, b->nq_max, st);
+    }
+    LAUNCH_OK();
+    return 0;
+}
+
+// The outer stages on the scaled batch: query scaling + distances, f_out, direct feature gradients, g_out (h entries).
+int ard_outer(ArdCtx& c, const float* phi, int flags, float* f_out, int32_t* info, bool want_grads) {
+    hipStream_t st = c.st;
+    int rc;
+    if (!(c.b->flags & ADKF_BATCH_REUSE_INNER)) {
+        rc = ard_eval(c, phi, c.a.fe, c.a.ge, c.a.info3);
+        if (rc) return rc;
+        hipMemcpyAsync(info, c.a.info3, sizeof(int32_t) * (size_t)c.T, hipMemcpyDeviceToDevice, st);
+    } else {
+        hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)c.T, st);
+    }
+    k_ard_scale<<<dim3(ceil_div(c.d, 256), c.nq, c.T), 256, 0, st>>>(c.v, c.b->Z_q, c.a.Zt_q, c.b->n_q, c.nq);
+    rc = stage_dist(&c.bt, c.w, true, st, 2);
+    if (rc) return rc;
+    if (!want_grads) return 0;
+    adkf_batch_t bq = c.bt;
+    bq.flags = ADKF_BATCH_REUSE_DIST | ADKF_BATCH_REUSE_INNER;
+    int32_t* info_o = c.a.info3;   // outer factorisation status, merged below
+    rc = outer_pipeline(&bq, c.w, c.a.phi3, flags & ADKF_IGNORE_DIRECT_GRAD, false, f_out, c.a.Gd_s, c.a.Gd_q, c.a.g3o, nullptr, nullptr, info_o, st);
+    if (rc) return rc;
+    ArdColdot cd{c.a.Zt_s, c.a.Gd_s, c.b->n_s, c.ns, c.a.Zt_q, c.a.Gd_q, c.b->n_q, c.nq, c.a.coldot, c.d};
+    k_ard_coldot<<<dim3(ceil_div(c.d, 64), c.T), 256, 0, st>>>(cd);
+    ArdGout go{c.v, phi, c.a.coldot, c.a.g3o, c.a.gout};
+    k_ard_gout<<<dim3(ceil_div(c.d, 256), c.T), 256, 0, st>>>(go);
+    LAUNCH_OK();
+    return 0;
+}
+
+__global__ void k_merge_info(const int32_t* extra, int32_t* info, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T && info[t] == 0 && extra[t] != 0) info[t] = extra[t];
+}
+
+int ard_ift(const adkf_batch_t* b, const float* phi, int flags, bool with_hessian, int cg_maxiter, float cg_tol, float* f_out,
+            float* dZ_s, float* dZ_q, float* g_phi_out, float* v_out, int32_t* cg_iters, int32_t* info, void* ws, size_t ws_bytes,
+            hipStream_t st) {
+    ArdCtx c;
+    int rc = ard_setup(b, ws, ws_bytes, st, c);
+    if (rc) return rc;
+    if (b->flags & ADKF_BATCH_REUSE_INNER) k_ard_params<<<dim3(ceil_div(c.d, 256), c.T), 256, 0, st>>>(c.v, phi);
+    rc = ard_outer(c, phi, flags, f_out, info, true);
+    if (rc) return rc;
+    k_merge_info<<<ceil_div(c.T, 64), 64, 0, st>>>(c.a.info3, info, c.T);
+    const size_t hb = sizeof(float) * (size_t)c.T * c.h;
+    if (g_phi_out) hipMemcpyAsync(g_phi_out, c.a.gout, hb, hipMemcpyDeviceToDevice, st);
+    const bool correct = with_hessian && !(flags & ADKF_IGNORE_GRAD_CORRECTION);
+    if (correct) {
+        ArdCg cg{c.T, c.h, cg_tol, c.a.cst, c.a.gout, c.a.cx, c.a.cr, c.a.cp, c.a.cHp};
+        k_ard_cg_begin<<<c.T, 256, 0, st>>>(cg);
+        for (int it = 0; it < cg_maxiter; ++it) {
+            ard_hvp(c, phi, c.a.cp, c.a.cHp, c.a.cst);
+            k_ard_cg_step<<<c.T, 256, 0, st>>>(cg);
+        }
+        k_ard_cg_info<<<ceil_div(c.T, 64), 64, 0, st>>>(c.a.cst, info, cg_iters, c.T);
+        if (v_out) hipMemcpyAsync(v_out, c.a.cx, hb, hipMemcpyDeviceToDevice, st);
+        ArdHvp hv = ard_hvp_args(c, phi, c.a.cx, c.a.cHp, nullptr);
+        ard_hvp_core(c, hv);   // Gdot'(v), c(v)
+    } else {
+        if (v_out) hipMemsetAsync(v_out, 0, hb, st);
+        if (cg_iters) hipMemsetAsync(cg_iters, 0, sizeof(int32_t) * (size_t)c.T, st);
+    }
+    if (dZ_s) {
+        ArdDzFin fs{c.v, c.a.Gd_s, correct ? c.a.Gdot : nullptr, c.a.G, c.a.c, correct ? 1.f : 0.f, dZ_s, b->n_s, c.ns};
+        k_ard_dz_fin<<<dim3(ceil_div(c.d, 256), c.ns, c.T), 256, 0, st>>>(fs);
+    }
+    if (dZ_q) {
+        ArdDzFin fq{c.v, c.a.Gd_q, nullptr, nullptr, nullptr, 0.f, dZ_q, b->n_q, c.nq};
+        k_ard_dz_fin<<<dim3(ceil_div(c.d, 256), c.nq, c.T), 256, 0, st>>>(fq);
+    }
+    LAUNCH_OK();
+    return 0;
+}
+
+inline bool is_ard(const adkf_batch_t* b) { return (b->flags & ADKF_BATCH_ARD) != 0; }
+
 }  // namespace
 
 extern "C" {
@@ -373,6 +623,14 @@ int adkf_init_params(const adkf_batch_t* b, int32_t use_numeric_labels, int32_t 
     rc = adkf_median_lengthscale(b, l0p, ws, ws_bytes, stream);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (is_ard(b)) {  // every lengthscale starts at the median heuristic (adaptive_dkt.py:101)
+        ArdWs a = carve_ard(ws, w.bytes, b->T, b->ns_max, b->nq_max, b->d);
+        if (ws_bytes < a.bytes) return ADKF_E_WORKSPACE;
+        k_init_params<<<ceil_div(b->T, 64), 64, 0, st>>>(l0p, b->T, use_numeric_labels, use_lengthscale_prior, a.phi3, priors);
+        k_ard_expand_phi<<<dim3(ceil_div(2 + b->d, 256), b->T), 256, 0, st>>>(a.phi3, phi, b->T, 2 + b->d);
+        LAUNCH_OK();
+        return 0;
+    }
     k_init_params<<<ceil_div(b->T, 64), 64, 0, st>>>(l0p, b->T, use_numeric_labels, use_lengthscale_prior, phi, priors);
     LAUNCH_OK();
     return 0;
@@ -383,6 +641,20 @@ int adkf_mll_value_grad(const adkf_batch_t* b, const float* phi, float* f_in, fl
     int rc = check_batch(b, false);
     if (rc) return rc;
     if (!phi || !f_in || !info || !ws || !b->y_s || !b->priors) return ADKF_E_BADARG;
+    if (is_ard(b)) {
+        ArdCtx c;
+        adkf_batch_t b0 = *b; b0.flags &= ~ADKF_BATCH_REUSE_INNER;
+        rc = ard_setup(&b0, ws, ws_bytes, static_cast<hipStream_t>(stream), c);
+        if (rc) return rc;
+        rc = ard_eval(c, phi, f_in, g_phi ? g_phi : c.a.ge, info);
+        if (rc) return rc;
+        if (dZ_s) {
+            ArdDzFin fs{c.v, c.a.G, nullptr, nullptr, nullptr, 0.f, dZ_s, b->n_s, c.ns};
+            k_ard_dz_fin<<<dim3(ceil_div(c.d, 256), c.ns, c.T), 256, 0, c.st>>>(fs);
+            LAUNCH_OK();
+        }
+        return 0;
+    }
     Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -411,6 +683,7 @@ int adkf_fit(const adkf_batch_t* b, float* phi, const adkf_fit_options_t* opt, f
     int rc = check_batch(b, false);
     if (rc) return rc;
     if (!phi || !opt || !info || !ws || !b->y_s || !b->priors || opt->max_evals < 2) return ADKF_E_BADARG;
+    if (is_ard(b)) return ard_fit(b, phi, opt, f_final, gnorm, n_evals, info, ws, ws_bytes, static_cast<hipStream_t>(stream));
     Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -430,6 +703,16 @@ int adkf_predict(const adkf_batch_t* b, const float* phi, float* mean, float* va
     int rc = check_batch(b, true);
     if (rc) return rc;
     if (!phi || !mean || !info || !ws || !b->y_s || !b->priors) return ADKF_E_BADARG;
+    if (is_ard(b)) {
+        ArdCtx c;
+        rc = ard_setup(b, ws, ws_bytes, static_cast<hipStream_t>(stream), c);
+        if (rc) return rc;
+        if (b->flags & ADKF_BATCH_REUSE_INNER) k_ard_params<<<dim3(ceil_div(c.d, 256), c.T), 256, 0, c.st>>>(c.v, phi);
+        rc = ard_outer(c, phi, 0, nullptr, info, false);
+        if (rc) return rc;
+        adkf_batch_t bq = c.bt;
+        return predict_core(&bq, c.w, mean, var, cov, c.st);
+    }
     Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -442,19 +725,7 @@ int adkf_predict(const adkf_batch_t* b, const float* phi, float* mean, float* va
         rc = launch_inner(ia, w, st);
         if (rc) return rc;
     }
-    TaskView tv = make_tv(b, w, true);
-    const int T = b->T;
-    ProbC pc; pc.tv = tv; pc.Ainv = w.Ainv; pc.D2qs = w.D2qs; pc.C = w.C;
-    launch_gemm(pc, T, b->nq_max, b->ns_max, st);
-    PredArgs pa{tv, w.C, w.D2qs, b->y_s, mean, var, w.scal, T};
-    k_predict<<<grid_for(T, 1), 256, 0, st>>>(pa);
-    if (cov) {
-        hipMemsetAsync(cov, 0, (size_t)T * b->nq_max * b->nq_max * sizeof(float), st);
-        ProbS ps; ps.tv = tv; ps.C = w.C; ps.D2qs = w.D2qs; ps.D2qq = w.D2qq; ps.S = cov;
-        launch_gemm(ps, T, b->nq_max, b->nq_max, st);
-    }
-    LAUNCH_OK();
-    return 0;
+    return predict_core(b, w, mean, var, cov, st);
 }
 
 int adkf_outer_nll_value_grad(const adkf_batch_t* b, const float* phi, float* f_out, float* g_phi, float* dZ_s,
@@ -462,6 +733,8 @@ int adkf_outer_nll_value_grad(const adkf_batch_t* b, const float* phi, float* f_
     int rc = check_batch(b, true);
     if (rc) return rc;
     if (!phi || !f_out || !info || !ws || !b->y_s || !b->y_q || !b->priors) return ADKF_E_BADARG;
+    if (is_ard(b))
+        return ard_ift(b, phi, 0, false, 0, 0.f, f_out, dZ_s, dZ_q, g_phi, nullptr, nullptr, info, ws, ws_bytes, static_cast<hipStream_t>(stream));
     Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     return outer_pipeline(b, w, phi, 0, false, f_out, dZ_s, dZ_q, g_phi, nullptr, nullptr, info, static_cast<hipStream_t>(stream));
@@ -472,9 +745,30 @@ int adkf_ift_hypergrad(const adkf_batch_t* b, const float* phi, int32_t flags, f
     int rc = check_batch(b, true);
     if (rc) return rc;
     if (!phi || !f_out || !dZ_s || !dZ_q || !info || !ws || !b->y_s || !b->y_q || !b->priors) return ADKF_E_BADARG;
+    if (is_ard(b)) {
+        if (H) return ADKF_E_BADARG;   // the h x h Hessian is never formed: the system is solved by conjugate gradients
+        return ard_ift(b, phi, flags, true, ADKF_CG_DEFAULT_MAXITER, ADKF_CG_DEFAULT_TOL, f_out, dZ_s, dZ_q, g_phi_out, v, nullptr, info,
+                       ws, ws_bytes, static_cast<hipStream_t>(stream));
+    }
     Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     return outer_pipeline(b, w, phi, flags, true, f_out, dZ_s, dZ_q, g_phi_out, v, H, info, static_cast<hipStream_t>(stream));
+}
+
+size_t adkf_workspace_bytes_ard(int32_t T, int32_t ns_max, int32_t nq_max, int32_t d) {
+    if (T <= 0 || ns_max <= 0 || nq_max < 0 || d <= 0) return 0;
+    return carve_ard(nullptr, carve(nullptr, T, ns_max, nq_max, d).bytes, T, ns_max, nq_max, d).bytes;
+}
+
+int adkf_ift_hypergrad_cg(const adkf_batch_t* b, const float* phi, int32_t flags, int32_t cg_maxiter, float cg_tol, float* f_out,
+                          float* dZ_s, float* dZ_q, float* g_phi_out, float* v, int32_t* cg_iters, int32_t* info, void* ws,
+                          size_t ws_bytes, void* stream) {
+    int rc = check_batch(b, true);
+    if (rc) return rc;
+    if (!is_ard(b) || cg_maxiter < 1 || !(cg_tol > 0.f)) return ADKF_E_BADARG;
+    if (!phi || !f_out || !dZ_s || !dZ_q || !info || !ws || !b->y_s || !b->y_q || !b->priors) return ADKF_E_BADARG;
+    return ard_ift(b, phi, flags, true, cg_maxiter, cg_tol, f_out, dZ_s, dZ_q, g_phi_out, v, cg_iters, info, ws, ws_bytes,
+                   static_cast<hipStream_t>(stream));
 }
 
 int adkf_check_info(const int32_t* info, int32_t T, void* stream) {

@@ -1,8 +1,8 @@
 """Batched GP operators on the HIP library: thin torch-tensor front end of include/adkf_gp.h.
 
 All tensors live on one ROCm device, float32, contiguous.  Shapes: ``Z_s [T,N,d]``, ``y_s [T,N]``,
-``Z_q [T,Nq,d]``, ``y_q [T,Nq]``, ``phi [T,3]``, ``priors [T,4]``, optional ragged sizes ``n_s [T]``,
-``n_q [T]`` (int32).  PyTorch is used for device memory and streams only; every number comes from the
+``Z_q [T,Nq,d]``, ``y_q [T,Nq]``, ``phi [T,h]`` (h = 3, or 2 + d for ``ard=True`` batches), ``priors [T,4]``,
+optional ragged sizes ``n_s [T]``, ``n_q [T]`` (int32).  PyTorch is used for device memory and streams only; every number comes from the
 hand-written kernels in ``csrc/``.
 """
 from __future__ import annotations
@@ -19,6 +19,7 @@ from ._lib import KERNEL_MATERN52, KERNEL_RBF, Batch, FitOptions
 KERNELS = {"rbf": KERNEL_RBF, "RBF": KERNEL_RBF, "matern": KERNEL_MATERN52}
 REUSE_DIST = 1
 REUSE_INNER = 2
+ARD = 4
 
 _workspaces = {}
 
@@ -59,6 +60,7 @@ class GPBatch:
     n_s: Optional[torch.Tensor] = None
     n_q: Optional[torch.Tensor] = None
     flags: int = 0  # REUSE_DIST / REUSE_INNER promises for consecutive calls on this batch (include/adkf_gp.h)
+    ard: bool = False  # one lengthscale per feature dimension: phi has 2 + d entries per task (ADKF_BATCH_ARD)
 
     def __post_init__(self):
         self.kernel = kernel_id(self.kernel)
@@ -94,16 +96,21 @@ class GPBatch:
     def device(self):
         return self.Z_s.device
 
+    @property
+    def h(self):
+        return 2 + self.d if self.ard else 3
+
     def c_struct(self) -> Batch:
         b = Batch()
-        b.T, b.ns_max, b.nq_max, b.d, b.kernel, b.flags = self.T, self.ns, self.nq, self.d, self.kernel, int(self.flags)
+        flags = int(self.flags) | (ARD if self.ard else 0)
+        b.T, b.ns_max, b.nq_max, b.d, b.kernel, b.flags = self.T, self.ns, self.nq, self.d, self.kernel, flags
         b.n_s, b.n_q = _ptr(self.n_s), _ptr(self.n_q)
         b.Z_s, b.y_s, b.Z_q, b.y_q, b.priors = _ptr(self.Z_s), _ptr(self.y_s), _ptr(self.Z_q), _ptr(self.y_q), _ptr(self.priors)
         return b
 
     def workspace(self) -> Tuple[torch.Tensor, int]:
         lib = _lib.load()
-        need = lib.adkf_workspace_bytes(self.T, self.ns, self.nq, self.d)
+        need = (lib.adkf_workspace_bytes_ard if self.ard else lib.adkf_workspace_bytes)(self.T, self.ns, self.nq, self.d)
         key = (self.device.index, torch.cuda.current_stream(self.device).cuda_stream)
         ws = _workspaces.get(key)
         if ws is None or ws.numel() < need:
@@ -161,7 +168,7 @@ def init_params_batch(b: GPBatch, use_numeric_labels: bool = False, use_lengthsc
     squared distances it computes stay in the workspace, so the caller may set ``b.flags |= REUSE_DIST`` for the
     following ``fit`` / ``ift_hypergrad`` calls on the same batch."""
     lib = _lib.load()
-    phi, l0 = _new(b, b.T, 3), _new(b, b.T)
+    phi, l0 = _new(b, b.T, b.h), _new(b, b.T)
     ws, nb = b.workspace()
     cb = b.c_struct()
     _lib.check(lib.adkf_init_params(C.byref(cb), int(use_numeric_labels), int(use_lengthscale_prior), _ptr(phi),
@@ -173,7 +180,7 @@ def mll_value_grad(b: GPBatch, phi: torch.Tensor, want_grad_phi=True, want_dZ=Fa
     lib = _lib.load()
     phi = _f32(phi, "phi")
     f = _new(b, b.T)
-    g = _new(b, b.T, 3) if want_grad_phi else None
+    g = _new(b, b.T, b.h) if want_grad_phi else None
     dZ = _new(b, b.T, b.ns, b.d) if want_dZ else None
     info = _new(b, b.T, dtype=torch.int32)
     ws, nb = b.workspace()
@@ -218,7 +225,7 @@ def outer_nll_value_grad(b: GPBatch, phi: torch.Tensor, want_grads=True):
     lib = _lib.load()
     phi = _f32(phi, "phi")
     f = _new(b, b.T)
-    g = _new(b, b.T, 3) if want_grads else None
+    g = _new(b, b.T, b.h) if want_grads else None
     dZs = _new(b, b.T, b.ns, b.d) if want_grads else None
     dZq = _new(b, b.T, b.nq, b.d) if want_grads else None
     info = _new(b, b.T, dtype=torch.int32)
@@ -229,9 +236,11 @@ def outer_nll_value_grad(b: GPBatch, phi: torch.Tensor, want_grads=True):
     return f, g, dZs, dZq, info
 
 
-def ift_hypergrad(b: GPBatch, phi: torch.Tensor, ignore_grad_correction=False, ignore_direct_grad=False, out_dZ=None):
+def ift_hypergrad(b: GPBatch, phi: torch.Tensor, ignore_grad_correction=False, ignore_direct_grad=False, out_dZ=None,
+                  cg_maxiter: Optional[int] = None, cg_tol: float = 1e-6):
     """Returns dict(f_out, dZ_s, dZ_q, g_phi, v, H, info): the IFT hypergradient at the feature level.
-    ``out_dZ = (dZ_s, dZ_q)``: optional preallocated contiguous float32 outputs (e.g. two halves of one buffer)."""
+    ``out_dZ = (dZ_s, dZ_q)``: optional preallocated contiguous float32 outputs (e.g. two halves of one buffer).
+    ARD batches: H is None (never formed), ``cg_iters`` reports the conjugate-gradient iterations per task."""
     lib = _lib.load()
     phi = _f32(phi, "phi")
     flags = (_lib.IGNORE_GRAD_CORRECTION if ignore_grad_correction else 0) | (_lib.IGNORE_DIRECT_GRAD if ignore_direct_grad else 0)
@@ -241,10 +250,17 @@ def ift_hypergrad(b: GPBatch, phi: torch.Tensor, ignore_grad_correction=False, i
         assert dZ_s.shape == b.Z_s.shape and dZ_q.shape == b.Z_q.shape
     else:
         dZ_s, dZ_q = _new(b, b.T, b.ns, b.d), _new(b, b.T, b.nq, b.d)
-    out = dict(f_out=_new(b, b.T), dZ_s=dZ_s, dZ_q=dZ_q, g_phi=_new(b, b.T, 3),
-               v=_new(b, b.T, 3), H=_new(b, b.T, 9), info=_new(b, b.T, dtype=torch.int32))
     ws, nb = b.workspace()
     cb = b.c_struct()
+    if b.ard:
+        out = dict(f_out=_new(b, b.T), dZ_s=dZ_s, dZ_q=dZ_q, g_phi=_new(b, b.T, b.h), v=_new(b, b.T, b.h), H=None,
+                   info=_new(b, b.T, dtype=torch.int32), cg_iters=_new(b, b.T, dtype=torch.int32))
+        _lib.check(lib.adkf_ift_hypergrad_cg(C.byref(cb), _ptr(phi), flags, int(cg_maxiter or 48), float(cg_tol), _ptr(out["f_out"]),
+                                             _ptr(dZ_s), _ptr(dZ_q), _ptr(out["g_phi"]), _ptr(out["v"]), _ptr(out["cg_iters"]),
+                                             _ptr(out["info"]), _ptr(ws), nb, _stream(b.device)), "adkf_ift_hypergrad_cg")
+        return out
+    out = dict(f_out=_new(b, b.T), dZ_s=dZ_s, dZ_q=dZ_q, g_phi=_new(b, b.T, 3),
+               v=_new(b, b.T, 3), H=_new(b, b.T, 9), info=_new(b, b.T, dtype=torch.int32))
     _lib.check(lib.adkf_ift_hypergrad(C.byref(cb), _ptr(phi), flags, _ptr(out["f_out"]), _ptr(out["dZ_s"]), _ptr(out["dZ_q"]),
                                       _ptr(out["g_phi"]), _ptr(out["v"]), _ptr(out["H"]), _ptr(out["info"]), _ptr(ws), nb,
                                       _stream(b.device)), "adkf_ift_hypergrad")

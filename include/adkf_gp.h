@@ -56,6 +56,17 @@ extern "C" {
 #define ADKF_BATCH_REUSE_INNER 2 /* A^-1, alpha and the scalars of exactly this phi are in the workspace (adkf_fit
                                     leaves them for its result; adkf_mll_value_grad for its argument) */
 
+/* ARD kernel (``use_ard``: fs_mol/models/adaptive_dkt.py:107-108 -> gpytorch ``ard_num_dims``): one lengthscale per
+ * feature dimension.  With this flag EVERY phi / g_phi / v argument has h = 2 + d entries per task, laid out
+ * (raw_noise, raw_outputscale, raw_lengthscale[0..d)); priors stay [T,4] (the lengthscale prior applies to each
+ * dimension and is summed, as gpytorch does); the workspace must have adkf_workspace_bytes_ard() bytes; the h x h
+ * Hessian is never formed (pass H = NULL): adkf_ift_hypergrad solves H v = grad f_out by conjugate gradients on
+ * closed-form Hessian-vector products.  REUSE_DIST is ignored (distances depend on the lengthscales). */
+#define ADKF_BATCH_ARD 4
+#define ADKF_CG_DEFAULT_MAXITER 48
+#define ADKF_CG_DEFAULT_TOL 1e-6f
+#define ADKF_INFO_CG_BASE 200000 /* info = 200000 + k: CG met non-positive curvature at iteration k (H not PD) */
+
 /* flags of adkf_ift_hypergrad: fs_mol/utils/cauchy_hypergradient.py:11-13 */
 #define ADKF_IGNORE_GRAD_CORRECTION 1
 #define ADKF_IGNORE_DIRECT_GRAD 2
@@ -135,6 +146,16 @@ int adkf_outer_nll_value_grad(const adkf_batch_t* b, const float* phi, float* f_
 int adkf_ift_hypergrad(const adkf_batch_t* b, const float* phi, int32_t flags, float* f_out, float* dZ_s,
                        float* dZ_q, float* g_phi_out, float* v, float* H, int32_t* info, void* ws,
                        size_t ws_bytes, void* stream);
+
+/* Workspace size for batches that carry ADKF_BATCH_ARD (a superset of adkf_workspace_bytes). */
+size_t adkf_workspace_bytes_ard(int32_t T, int32_t ns_max, int32_t nq_max, int32_t d);
+
+/* adkf_ift_hypergrad for ARD batches with explicit conjugate-gradient controls (the north-star's "HVP + CG"):
+ * at most cg_maxiter iterations, stop at |r| <= cg_tol |grad f_out|; cg_iters [T] (nullable) receives the iterations
+ * each task used.  Exactly cg_maxiter rounds of kernels are enqueued (no host synchronisation); converged tasks idle. */
+int adkf_ift_hypergrad_cg(const adkf_batch_t* b, const float* phi, int32_t flags, int32_t cg_maxiter, float cg_tol,
+                          float* f_out, float* dZ_s, float* dZ_q, float* g_phi_out, float* v, int32_t* cg_iters,
+                          int32_t* info, void* ws, size_t ws_bytes, void* stream);
 
 /* Synchronises `stream`, then returns 0 or (index+1) of the first task with info != 0. */
 int adkf_check_info(const int32_t* info, int32_t T, void* stream);
