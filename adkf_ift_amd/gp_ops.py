@@ -133,6 +133,9 @@ def check_info(info: torch.Tensor, what: str = "GP factorisation"):
     rc = lib.adkf_check_info(_ptr(info), info.numel(), _stream(info.device))
     if rc > 0:
         code = int(info[rc - 1].item())
+        if code >= 200000:   # ADKF_INFO_CG_BASE
+            raise RuntimeError(f"{what}: conjugate gradients met non-positive curvature for task {rc - 1} at iteration "
+                               f"{code - 200000}: the inner Hessian is not positive definite (is the inner fit converged?)")
         where = "predictive covariance" if code >= _lib.INFO_OUTER_BASE else "K + noise*I"
         raise RuntimeError(f"{what}: matrix not positive definite for task {rc - 1} ({where}, pivot {code % _lib.INFO_OUTER_BASE})")
     if rc < 0:

@@ -141,7 +141,7 @@ def model_meta_step(model, optimizer, mb: MetaBatch, cfg=None, distributed: bool
 
     if cfg is None:
         c = model.config
-        cfg = MetaStepConfig(gp_kernel=c.gp_kernel, use_numeric_labels=c.use_numeric_labels,
+        cfg = MetaStepConfig(gp_kernel=c.gp_kernel, use_numeric_labels=c.use_numeric_labels, use_ard=c.use_ard,
                              use_lengthscale_prior=c.use_lengthscale_prior, ignore_grad_correction=c.ignore_grad_correction)
     y_s, y_q = mb.labels(cfg.use_numeric_labels)
     return meta_step(lambda: meta_features(model, mb), list(model.feature_extractor_params()), optimizer, y_s, y_q, cfg,

@@ -73,9 +73,8 @@ class GaussianLikelihood(nn.Module):
 class _BaseKernel(nn.Module):
     def __init__(self, ard_num_dims=None):
         super().__init__()
-        if ard_num_dims is not None:
-            raise NotImplementedError("use_ard: the HIP GP path handles the 3-parameter (non-ARD) kernel only")
-        self.raw_lengthscale = nn.Parameter(torch.zeros(1, 1))
+        self.ard_num_dims = ard_num_dims   # gpytorch: lengthscale [1, d] instead of [1, 1]
+        self.raw_lengthscale = nn.Parameter(torch.zeros(1, ard_num_dims or 1))
         self.lengthscale_prior: Optional[Tuple[float, float]] = None
 
     @property
@@ -86,7 +85,7 @@ class _BaseKernel(nn.Module):
     def lengthscale(self, value):
         with torch.no_grad():
             v = torch.as_tensor(value, dtype=self.raw_lengthscale.dtype, device=self.raw_lengthscale.device)
-            self.raw_lengthscale.copy_(_inv_softplus(v).reshape(1, 1))
+            self.raw_lengthscale.copy_(_inv_softplus(v).reshape(1, -1).expand_as(self.raw_lengthscale))
 
     def register_prior(self, name, prior: Tuple[float, float], *unused):
         self.lengthscale_prior = prior
@@ -110,6 +109,7 @@ class ExactGPLayer(nn.Module):
                  use_numeric_labels: bool = False):
         super().__init__()
         self.kernel_id = gp_ops.kernel_id(kernel)
+        self.ard = ard_num_dims is not None
         likelihood.noise_covar.raw_noise.requires_grad = True
         likelihood.noise = 0.01 if use_numeric_labels else 0.1      # fs_mol/utils/gp_utils.py:17
         self.likelihood = likelihood
@@ -144,7 +144,7 @@ class ExactMarginalLogLikelihood(nn.Module):
     def forward(self, function_dist: "GPTrainHandle", target: torch.Tensor) -> torch.Tensor:
         phi = torch.cat([p.reshape(-1) for p in self.raw_params()])
         return _MLLFunction.apply(function_dist.Z, target, phi, self.priors_row(function_dist.Z.device),
-                                  self.model.kernel_id)
+                                  self.model.kernel_id, self.model.ard)
 
 
 @dataclass
@@ -180,8 +180,8 @@ class _MLLFunction(torch.autograd.Function):
     """+MLL (so that callers negate it like the reference does) of one task; differentiable in Z and phi."""
 
     @staticmethod
-    def forward(ctx, Z, y, phi, priors, kernel):
-        b = gp_ops.GPBatch(Z.detach()[None], y.detach()[None].float(), priors, kernel)
+    def forward(ctx, Z, y, phi, priors, kernel, ard=False):
+        b = gp_ops.GPBatch(Z.detach()[None], y.detach()[None].float(), priors, kernel, ard=ard)
         f, g, dZ, info = gp_ops.mll_value_grad(b, phi.detach()[None], want_dZ=True)
         gp_ops.check_info(info, "marginal log likelihood")
         ctx.save_for_backward(g[0], dZ[0])
@@ -190,16 +190,16 @@ class _MLLFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         g, dZ = ctx.saved_tensors
-        return -grad_out * dZ, None, -grad_out * g, None, None
+        return -grad_out * dZ, None, -grad_out * g, None, None, None
 
 
 class _OuterNLLFunction(torch.autograd.Function):
     """f_outer = -log N(y_q; mu_q, Sigma_q + noise I) of one task; differentiable in Z_s, Z_q and phi."""
 
     @staticmethod
-    def forward(ctx, Z_s, y_s, Z_q, y_q, phi, priors, kernel):
+    def forward(ctx, Z_s, y_s, Z_q, y_q, phi, priors, kernel, ard=False):
         b = gp_ops.GPBatch(Z_s.detach()[None], y_s.detach()[None].float(), priors, kernel, Z_q=Z_q.detach()[None],
-                           y_q=y_q.detach()[None].float())
+                           y_q=y_q.detach()[None].float(), ard=ard)
         f, g, dZs, dZq, info = gp_ops.outer_nll_value_grad(b, phi.detach()[None])
         gp_ops.check_info(info, "predictive log likelihood")
         ctx.save_for_backward(g[0], dZs[0], dZq[0])
@@ -208,23 +208,25 @@ class _OuterNLLFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         g, dZs, dZq = ctx.saved_tensors
-        return grad_out * dZs, None, grad_out * dZq, None, grad_out * g, None, None
+        return grad_out * dZs, None, grad_out * dZq, None, grad_out * g, None, None, None
 
 
 def fit_gpytorch_scipy(mll: ExactMarginalLogLikelihood, max_evals: int = 200, gtol: float = 1e-5, ftol: float = 1e-7):
-    """Drop-in for ``botorch.optim.fit.fit_gpytorch_scipy(model.mll)``: minimises -mll over the three raw GP
-    parameters on the GPU (in-kernel quasi-Newton) and writes the optimum back into the module.  Returns
-    ``(mll, info_dict)`` like BoTorch."""
+    """Drop-in for ``botorch.optim.fit.fit_gpytorch_scipy(model.mll)``: minimises -mll over the raw GP parameters on the
+    GPU (in-kernel BFGS for the three-parameter kernel, device L-BFGS for ARD) and writes the optimum back into the
+    module.  Returns ``(mll, info_dict)`` like BoTorch."""
     model = mll.model
     Z = model.train_inputs[0].detach()
     y = model.train_targets.detach().float()
-    b = gp_ops.GPBatch(Z[None], y[None], mll.priors_row(Z.device), model.kernel_id)
+    b = gp_ops.GPBatch(Z[None], y[None], mll.priors_row(Z.device), model.kernel_id, ard=model.ard)
     phi0 = torch.cat([p.detach().reshape(-1) for p in mll.raw_params()])[None]
     phi, f, gnorm, nev, info = gp_ops.fit(b, phi0, max_evals, gtol, ftol)
     gp_ops.check_info(info, "fit_gpytorch_scipy")
     with torch.no_grad():
-        for p, v in zip(mll.raw_params(), phi[0]):
-            p.copy_(v.reshape(p.shape))
+        off = 0
+        for p in mll.raw_params():
+            p.copy_(phi[0, off:off + p.numel()].reshape(p.shape))
+            off += p.numel()
     return mll, {"fopt": f[0].item(), "max_abs_grad": gnorm[0].item(), "nfev": int(nev[0].item())}
 
 
@@ -300,7 +302,7 @@ class _DeepKernelBase(nn.Module):
 
     def _posterior(self, Z_s, y_s, Z_q) -> GPPosterior:
         b = gp_ops.GPBatch(Z_s.detach()[None], y_s[None], self.mll.priors_row(Z_s.device), self.gp_model.kernel_id,
-                           Z_q=Z_q.detach()[None])
+                           Z_q=Z_q.detach()[None], ard=self.gp_model.ard)
         phi = torch.cat([p.detach().reshape(-1) for p in self.mll.raw_params()])[None]
         mean, var, cov, info = gp_ops.predict(b, phi, want_cov=True)
         gp_ops.check_info(info, "GP prediction")
@@ -374,7 +376,7 @@ class ADKTModel(_DeepKernelBase):
                     self.gp_model.set_train_data(inputs=Z_s, targets=y_s, strict=False)
                     phi = torch.cat([p.reshape(-1) for p in self.mll.raw_params()])
                     logits = _OuterNLLFunction.apply(Z_s, y_s, Z_q, y_q, phi, self.mll.priors_row(Z_s.device),
-                                                     self.gp_model.kernel_id)
+                                                     self.gp_model.kernel_id, self.gp_model.ard)
                 else:
                     self.gp_model.set_train_data(inputs=Z_q, targets=y_q, strict=False)
                     logits = -self.mll(GPTrainHandle(Z_q), self.gp_model.train_targets)
@@ -411,10 +413,10 @@ class _FusedTask:
         Z_s, y_s, Z_q, y_q = functional_call(_Features(m), {"m." + n: p for n, p in fe.items()}, (self.batch,))
         phi = torch.cat([p.detach().reshape(-1) for p in params_inner])[None]
         b = gp_ops.GPBatch(Z_s.detach()[None], y_s[None], m.mll.priors_row(Z_s.device), m.gp_model.kernel_id,
-                           Z_q=Z_q.detach()[None], y_q=y_q[None])
+                           Z_q=Z_q.detach()[None], y_q=y_q[None], ard=m.gp_model.ard)
         out = gp_ops.ift_hypergrad(b, phi, ignore_grad_correction, ignore_direct_grad)
-        gp_ops.check_info(out["info"], "cauchy_hypergradient")
-        if sanity_checks and not ignore_grad_correction:
+        gp_ops.check_info(out["info"], "cauchy_hypergradient")   # ARD: also raises when CG met non-positive curvature
+        if sanity_checks and not ignore_grad_correction and out["H"] is not None:
             logabsdet = torch.linalg.slogdet(out["H"][0].double()).logabsdet
             assert logabsdet.item() > -10.0
         outer = [p for p in params_outer]

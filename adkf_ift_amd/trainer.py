@@ -23,6 +23,7 @@ class MetaStepConfig:
     gp_kernel: str = "matern"              # fs_mol/utils/adaptive_dkt_utils.py:64
     use_numeric_labels: bool = False
     use_lengthscale_prior: bool = True
+    use_ard: bool = False                  # one lengthscale per feature dimension: IFT system solved by HVP + CG
     ignore_grad_correction: bool = False
     clip_value: Optional[float] = 1.0      # fs_mol/adaptive_dkt_train.py --clip_value default
     inner_max_evals: int = 200
@@ -41,7 +42,7 @@ class HipGPBackend:
         hypergradient reuses the A^-1, alpha the fit left behind."""
         from . import gp_ops
         priors = torch.empty(Z_s.shape[0], 4, dtype=torch.float32, device=Z_s.device)
-        b = gp_ops.GPBatch(Z_s, y_s, priors, cfg.gp_kernel, Z_q=Z_q, y_q=y_q, n_s=n_s, n_q=n_q)
+        b = gp_ops.GPBatch(Z_s, y_s, priors, cfg.gp_kernel, Z_q=Z_q, y_q=y_q, n_s=n_s, n_q=n_q, ard=cfg.use_ard)
         phi0, _ = gp_ops.init_params_batch(b, cfg.use_numeric_labels, cfg.use_lengthscale_prior)
         b.flags = gp_ops.REUSE_DIST
         phi, f_in, gnorm, nev, info_fit = gp_ops.fit(b, phi0, cfg.inner_max_evals, cfg.inner_gtol, cfg.inner_ftol,

@@ -130,3 +130,61 @@ def test_ard_fit_reaches_oracle_optimum(golden_dir, dev):
         q = O.full_reference_quantities(Zs, ys, torch.tensor(z["Z_q"]).double(), torch.tensor(z["y_q"]).double(), phi[0].double().cpu(), pri, int(z["kind"]))
         assert rel(o_fresh["dZ_s"][0].cpu().numpy(), q["dZs_total"]) <= TOL
         assert rel(o_fresh["dZ_q"][0].cpu().numpy(), q["dZq_total"]) <= TOL
+
+
+def test_ard_model_surface_and_batched_meta_step(dev):
+    """``use_ard=True`` through the reference-shaped surface: reinit (every lengthscale at the median heuristic, [1, d]
+    parameter), fit, fused cauchy_hypergradient == the dense reference algorithm on the float64 oracle; and the batched
+    meta-step equals the per-task loop."""
+    from adkf_ift_amd.hypergradient import cauchy_hypergradient
+    from adkf_ift_amd.models import ADKTModel, ADKTModelConfig, fit_gpytorch_scipy
+    from adkf_ift_amd.trainer import MetaStepConfig, meta_step
+    from oracle import gp_oracle as O
+    from oracle.hypergrad_oracle import dense_ift_hypergradient
+    from test_gpu_surface import make_batch
+
+    torch.manual_seed(3)
+    cfg = ADKTModelConfig(used_features="ecfp+fc", gp_kernel="matern", use_ard=True, fc_hidden_dim=16, fc_out_dim=8)
+    model = ADKTModel(cfg).to(dev)
+    batches = [make_batch(dev, ns=16, nq=24, seed=s) for s in (11, 12)]
+    model.train()
+    acc = [torch.zeros_like(p) for p in model.feature_extractor_params()]
+    vals = []
+    for bi, batch in enumerate(batches):
+        assert model(batch, train_loss=True) is None
+        assert model.gp_model.covar_module.base_kernel.raw_lengthscale.shape == (1, 8)
+        fit_gpytorch_scipy(model.mll)
+        f_outer, f_inner = model.task_losses(batch)
+        po, pi = tuple(model.feature_extractor_params()), tuple(model.gp_params())
+        val = cauchy_hypergradient(f_outer, f_inner, po, pi, dev)
+        vals.append(val.item() / 24)
+        for a, p in zip(acc, po):
+            a += p.grad / len(batches)
+        if bi == 0:   # against the dense algorithm (h = 10: Hessian and mixed Jacobian by autograd) in float64
+            Xs, Xq = batch.support_features.fingerprints.double().cpu(), batch.query_features.fingerprints.double().cpu()
+            ys, yq = (batch.support_labels.double().cpu() - 0.5) * 2, (batch.query_labels.double().cpu() - 0.5) * 2
+            pri = O.Priors(*model.mll.priors_row(torch.device("cpu"))[0].double().tolist())
+            feats = lambda p, X: torch.relu(X @ p[0].T + p[1]) @ p[2].T + p[3]
+            fin = lambda p, q: O.f_inner(feats(p, Xs), ys, torch.cat([t.reshape(-1) for t in q]), pri, 1)
+            fout = lambda p, q: O.f_outer(feats(p, Xs), ys, feats(p, Xq), yq, torch.cat([t.reshape(-1) for t in q]), 1)
+            p64 = tuple(p.detach().double().cpu().requires_grad_() for p in po)
+            q64 = tuple(p.detach().double().cpu().requires_grad_() for p in pi)
+            ref_val = dense_ift_hypergradient(fout, fin, p64, q64)
+            assert abs(val.item() - ref_val.item()) <= 1e-4 * abs(ref_val.item())
+            scale = max(q.grad.abs().max().item() for q in p64)
+            for p, q in zip(po, p64):
+                assert (p.grad.double().cpu() - q.grad).abs().max().item() <= 1e-3 * scale
+    # batched: both tasks in one library call, one backward
+    for p in model.parameters():
+        p.grad = None
+    X_s = torch.stack([b.support_features.fingerprints for b in batches])
+    X_q = torch.stack([b.query_features.fingerprints for b in batches])
+    y_s = torch.stack([(b.support_labels.float() - 0.5) * 2 for b in batches])
+    y_q = torch.stack([(b.query_labels.float() - 0.5) * 2 for b in batches])
+    params = list(model.feature_extractor_params())
+    mcfg = MetaStepConfig(gp_kernel="matern", use_ard=True, clip_value=None)
+    losses, _ = meta_step(lambda: (model.fc(X_s), model.fc(X_q)), params, None, y_s, y_q, mcfg, check=True)
+    scale = max(a.abs().max().item() for a in acc)
+    for a, p in zip(acc, params):
+        assert (p.grad - a).abs().max().item() <= 2e-3 * scale
+    assert np.abs(losses.cpu().numpy() - np.array(vals)).max() <= 1e-3 * np.abs(vals).max()
