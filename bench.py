@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--inner-evals", type=int, default=20)
     ap.add_argument("--kernel", default="rbf", choices=["rbf", "matern"])
     ap.add_argument("--converge", action="store_true", help="run the inner fit to convergence instead of a fixed I")
+    ap.add_argument("--ard", action="store_true", help="ARD kernel (h = 2 + d inner parameters): device L-BFGS + HVP/CG; not the headline config")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -74,7 +75,7 @@ def main():
     W = tasks.W.to(dev).clone().requires_grad_(True)
     opt = torch.optim.Adam([W], lr=1e-4, fused=True)  # fs_mol/adaptive_dkt_train.py --lr default; fused: one kernel instead of nine
     cfg = MetaStepConfig(gp_kernel=args.kernel, inner_max_evals=(200 if args.converge else I),
-                         inner_exact_evals=not args.converge, clip_value=1.0)
+                         inner_exact_evals=not args.converge, clip_value=1.0, use_ard=args.ard)
     inv_sqrt_d = 1.0 / math.sqrt(d)
 
     features = LinearFeatureMap(X_s, X_q, W)  # one GEMM for support+query rows; chunked-bmm backward
@@ -153,7 +154,9 @@ def main():
                 pm = json.load(fh)
             traffic = (pm["FETCH_SIZE_KB_per_launch"] + pm["WRITE_SIZE_KB_per_launch"]) * 1024.0
         cfg_name = {(256, 128, 256): "C2", (64, 32, 64): "C1", (8, 1024, 512): "C5"}.get((T, N, d), "custom")
-        fit_kernel = ("k_inner (in-kernel quasi-Newton fit: kernel build + register-resident sweep per evaluation)" if N <= 128 else
+        if args.ard:
+            cfg_name += " with the ARD kernel (roofline FLOP model below is the non-ARD one: indicative only)"
+        fit_kernel = ("ARD inner fit (all launches between the two events)" if args.ard else "k_inner (in-kernel quasi-Newton fit: kernel build + register-resident sweep per evaluation)" if N <= 128 else
                       "blocked inner fit (all launches between the two events: k_lg_build, k_lg_diag, panel/update MFMA GEMMs, "
                       "k_lg_traces, k_lg_advance per evaluation)")
         line = {
