@@ -35,6 +35,7 @@ _lib = None
 # name -> (restype, argtypes); kept in one table so tests can check every declared symbol is exported
 SIGNATURES = {
     "adkf_version": (C.c_char_p, []),
+    "adkf_last_hip_error": (C.c_char_p, []),
     "adkf_max_points": (C.c_int, []),
     "adkf_workspace_bytes": (C.c_size_t, [C.c_int32] * 4),
     "adkf_median_lengthscale": (C.c_int, [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -67,6 +68,10 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
             "The GP path has no CPU or PyTorch fallback.")
+    # torch first: its bundled HIP runtime must be the one in the process before this library binds to libamdhip64
+    # (loaded the other way round, the library sees "no ROCm-capable device" for streams created by torch)
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = the library does not export what the header declares
@@ -78,4 +83,5 @@ def load():
 
 def check(rc: int, what: str):
     if rc != 0:
-        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}")
+        detail = f" ({_lib.adkf_last_hip_error().decode()})" if rc == -4 and _lib is not None else ""
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}{detail}")

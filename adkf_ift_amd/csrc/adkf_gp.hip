@@ -90,6 +90,7 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
 }
 
 int check_batch(const adkf_batch_t* b, bool need_query) {
+    (void)hipGetLastError();  // a stale error left by another library on this thread must not be blamed on our launches
     if (!b || b->T <= 0 || b->ns_max <= 0 || b->d <= 0 || !b->Z_s) return ADKF_E_BADARG;
     if (b->kernel != ADKF_KERNEL_RBF && b->kernel != ADKF_KERNEL_MATERN52) return ADKF_E_BADARG;
     if (b->ns_max > MAX_POINTS) return ADKF_E_SIZE;
@@ -118,7 +119,8 @@ TaskView make_tv(const adkf_batch_t* b, const Workspace& w, bool with_query) {
     return tv;
 }
 
-#define LAUNCH_OK() do { if (hipGetLastError() != hipSuccess) return ADKF_E_LAUNCH; } while (0)
+thread_local hipError_t g_last_hip_error = hipSuccess;  // diagnostics only: what ADKF_E_LAUNCH was about (adkf_last_hip_error)
+#define LAUNCH_OK() do { const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { g_last_hip_error = e_; return ADKF_E_LAUNCH; } } while (0)
 
 inline bool has_query(const adkf_batch_t* b) { return b->nq_max > 0 && b->Z_q != nullptr; }
 
@@ -578,6 +580,8 @@ inline bool is_ard(const adkf_batch_t* b) { return (b->flags & ADKF_BATCH_ARD) !
 }  // namespace
 
 extern "C" {
+
+const char* adkf_last_hip_error(void) { return hipGetErrorString(g_last_hip_error); }
 
 const char* adkf_version(void) { return "adkf_gp 0.1 (gfx950)"; }
 

@@ -98,6 +98,9 @@ typedef struct adkf_fit_options {
 
 const char* adkf_version(void);
 
+/* Diagnostics: the HIP runtime's description of the error behind the calling thread's last ADKF_E_LAUNCH. */
+const char* adkf_last_hip_error(void);
+
 /* Largest support/query set this build handles in its LDS-resident factorisation. */
 int adkf_max_points(void);
 
