@@ -8,6 +8,11 @@
 
 using namespace adkf;
 
+#if ADKF_EVAL_STAMP
+extern "C" __device__ unsigned long long adkf_eval_stamps[16] = {};
+extern "C" int adkf_read_eval_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(adkf_eval_stamps), sizeof(unsigned long long) * 16); }
+#endif
+
 namespace {
 
 constexpr int MAX_POINTS = 4096;  // <= 128: register-resident sweep (inner.h); above: blocked sweep through L2/HBM (large.h)
@@ -154,8 +159,15 @@ int stage_dist(const adkf_batch_t* b, const Workspace& w, bool with_query, hipSt
 
 template <int NMAX, int NT>
 void launch_inner_k(const InnerArgs& a, hipStream_t st) {
-    if (a.kind == ADKF_KERNEL_RBF) k_inner<NMAX, NT, 0><<<grid_for(a.T, 1), NT, 0, st>>>(a);
-    else k_inner<NMAX, NT, 1><<<grid_for(a.T, 1), NT, 0, st>>>(a);
+    constexpr size_t cache_bytes = sizeof(float) * NMAX * NMAX;   // the kappa' u cache of inner.h (one float per matrix element)
+    static const bool attr_set = [] {   // 64 KB of dynamic LDS on top of the static part needs the opt-in
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner<NMAX, NT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cache_bytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner<NMAX, NT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cache_bytes);
+        return true;
+    }();
+    (void)attr_set;
+    if (a.kind == ADKF_KERNEL_RBF) k_inner<NMAX, NT, 0><<<grid_for(a.T, 1), NT, cache_bytes, st>>>(a);
+    else k_inner<NMAX, NT, 1><<<grid_for(a.T, 1), NT, cache_bytes, st>>>(a);
 }
 
 LgMat lg_mat(const Workspace& w, float* M, int ld, const int32_t* n_arr, const FitShared* fit, int T) {

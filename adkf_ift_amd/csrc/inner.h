@@ -7,6 +7,16 @@
 #pragma once
 #include "factor.h"
 
+#ifndef ADKF_EVAL_STAMP
+#define ADKF_EVAL_STAMP 0   // diagnostic build only (tools/eval_phases.py): s_memtime at the phase boundaries of one evaluation
+#endif
+#if ADKF_EVAL_STAMP
+extern "C" __device__ unsigned long long adkf_eval_stamps[16];
+#define ADKF_ES(slot) do { if (blockIdx.x == 8 && threadIdx.x == ADKF_EVAL_STAMP - 1 && adkf_stamp_on) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); adkf_eval_stamps[slot] = t_; } } while (0)
+#else
+#define ADKF_ES(slot) do {} while (0)
+#endif
+
 namespace adkf {
 
 struct InnerArgs {
@@ -101,28 +111,51 @@ struct InnerEval {
 
     // One evaluation at raw parameters x.  d2 = this thread's block of squared distances.  On return m = -(A^-1)
     // (this thread's block), sm.vec_out = alpha.  extra (9 floats) receives the scalars later stages reuse.
+    // cache: NT * RB * CB floats of LDS; carries kappa'(u) u from the kernel build to the trace pass (no second exp).
     __device__ static __forceinline__ int run(SweepSmem<NMAX, NT>& sm, const D2& d2, float (&m)[RB][CB], int n,
                                               const float* x, const float* pri, float& f, float* g, float* extra,
-                                              bool fast) {
+                                              bool fast, float* cache) {
         const int j0 = SW::bc() * CB, tid = threadIdx.x;
+#if ADKF_EVAL_STAMP
+        const bool adkf_stamp_on = fast;   // the search evaluations (the final one uses libm expf)
+#endif
+        ADKF_ES(0);
         const float noise = softplus_f(x[0]) + NOISE_LB, os = softplus_f(x[1]), ls = softplus_f(x[2]);
         const float il2 = 1.f / (ls * ls), gl = -2.f / ls;
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
+        for (int r = 0; r < RB; ++r) {
+            __builtin_amdgcn_sched_barrier(0);   // one row of exponentials in flight at a time: keeps the pressure of this loop out of the sweep's allocation
 #pragma unroll
             for (int c = 0; c < CB; ++c) {
                 const int i = SW::row(r), j = j0 + c;
+                float k1u = 0.f;
                 if (i < n && j < n) {
                     const float u = d2.get(r, c) * il2;
-                    m[r][c] = os * (fast ? kappa0_t<KIND, true>(u) : kappa0_t<KIND, false>(u)) + (i == j ? noise : 0.f);
+                    float k0, k1, k2;
+                    if (fast) kappa3<KIND, true>(u, k0, k1, k2); else kappa3<KIND, false>(u, k0, k1, k2);
+                    m[r][c] = os * k0 + (i == j ? noise : 0.f);
+                    k1u = k1 * u;
                 }
                 else m[r][c] = (i == j) ? 1.f : 0.f;
+                cache[(r * CB + c) * NT + tid] = k1u;   // lane-private slots, conflict-free
             }
+        }
+        ADKF_ES(1);
         __syncthreads();  // previous readers of sm (cross/vec_out) are done
+        ADKF_ES(10);
         SW::run(m, n, sm);
+        // Opaque re-definition of the block: without it the pairing (SLP) choices of the consumers below leak back into
+        // the sweep's register assignment and cost ~190 extra v_mov per two block steps (+34 % sweep time, measured).
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < CB; ++c) asm volatile("" : "+v"(m[r][c]));
+        ADKF_ES(2);
         SW::solve(m, sm.vec_in, sm.vec_out);  // alpha = A^-1 y
+        ADKF_ES(3);
         float logdet;
         const int info = SW::finish(n, sm, logdet);
+        ADKF_ES(4);
         float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // tr(Ainv G), a^T G a, tr(Ainv), a^T a, y^T a
         float ai[RB], aj[CB];
 #pragma unroll
@@ -133,12 +166,8 @@ struct InnerEval {
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int c = 0; c < CB; ++c) {
-                // dK/dl regenerated from the distances (cheaper than 32 more live registers per lane);
-                // zero outside n x n because d2 is zero there
-                float k0, k1, k2;
-                const float u = d2.get(r, c) * il2;
-                if (fast) kappa3<KIND, true>(u, k0, k1, k2); else kappa3<KIND, false>(u, k0, k1, k2);
-                const float G = os * k1 * u * gl;
+                // dK/dl = s kappa'(u) u (-2/l): kappa'(u) u was parked in LDS by the build (zero outside n x n)
+                const float G = os * gl * cache[(r * CB + c) * NT + tid];
                 acc[0] -= m[r][c] * G;
                 acc[1] += ai[r] * aj[c] * G;
                 if (SW::row(r) == j0 + c && SW::row(r) < n) acc[2] -= m[r][c];
@@ -148,8 +177,12 @@ struct InnerEval {
             acc[3] = a * a;
             acc[4] = sm.vec_in[tid] * a;
         }
+        ADKF_ES(5);
         block_sum<5, NT>(acc, sm.red);
+        ADKF_ES(6);
+        if (tid >= 64) { f = 0.f; return info; }   // the scalar epilogue is consumed by lane 0 only: one wave computes it
         inner_finalize(n, x, pri, logdet, acc, f, g, extra);
+        ADKF_ES(7);
         if (info != 0 || !(f == f)) {
             f = INFINITY;
             return info != 0 ? info : n + 1;
@@ -299,6 +332,7 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
     constexpr int RB = SW::RB, CB = SW::CB;
     __shared__ SweepSmem<NMAX, NT> sm;
     __shared__ FitShared fs;
+    extern __shared__ float inner_cache[];   // NT * RB * CB floats (launch_inner_k sets the dynamic size)
     int t, tile;
     if (!task_tile(a.T, 1, t, tile)) return;
     const int tid = threadIdx.x;
@@ -328,7 +362,7 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
     while (true) {
         const int phase = fs.phase;
         xe[0] = fs.xe[0]; xe[1] = fs.xe[1]; xe[2] = fs.xe[2];
-        const int ie = EV::run(sm, d2, m, n, xe, pri, fe, ge, extra, phase != PH_FINAL);
+        const int ie = EV::run(sm, d2, m, n, xe, pri, fe, ge, extra, phase != PH_FINAL, inner_cache);
         if (phase == PH_FINAL) { info = ie; evals = fs.evals + 1; break; }
         if (tid == 0) fit_advance(fs, a, fe, ge, ie);
         __syncthreads();

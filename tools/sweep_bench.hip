@@ -16,6 +16,8 @@ __global__ __launch_bounds__(NT) void k_sweep(const float* A, float* out, int n,
     float a[RB][CB], m[RB][CB];
     for (int r = 0; r < RB; ++r) for (int c = 0; c < CB; ++c) a[r][c] = At[SW::row(r) * n + j0 + c];
     float acc = 0.f;
+    unsigned long long t_begin = 0;
+    if (threadIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_begin) :: "memory");
     for (int it = 0; it < reps; ++it) {
         for (int r = 0; r < RB; ++r) for (int c = 0; c < CB; ++c) m[r][c] = a[r][c];
         __syncthreads();
@@ -30,7 +32,12 @@ __global__ __launch_bounds__(NT) void k_sweep(const float* A, float* out, int n,
         }
         acc += m[0][0];
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = acc + m[1][1];
+    if (threadIdx.x == 0) {
+        unsigned long long t_end;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end) :: "memory");
+        if (blockIdx.x == 8) ((unsigned long long*)(out + 1536))[0] = (t_end - t_begin) / reps;   // s_memtime ticks per sweep
+        out[blockIdx.x] = acc + m[1][1];
+    }
 #if ADKF_STAMP
     if (blockIdx.x == 3 && threadIdx.x < 128 && VAR == 0) ((unsigned long long*)(out + 1024))[threadIdx.x] = sm.stamp[threadIdx.x];
 #endif
@@ -65,7 +72,10 @@ int main(int argc, char** argv) {
         for (int w = 0; w < 8; ++w) { printf("wave %d:", w); for (int s_ = 0; s_ < 11; ++s_) printf(" %6lld", st[w * 16 + s_] ? (long long)(st[w * 16 + s_] - t0) : -1ll); printf("\n"); }
     }
 #endif
-    printf("T=%d  us per sweep:  full %.1f | update-only %.1f | barriers-only %.1f\n", T,
-           run<0>(dA, dout, T, n, reps), run<1>(dA, dout, T, n, reps), run<3>(dA, dout, T, n, reps));
+    const float full = run<0>(dA, dout, T, n, reps);
+    unsigned long long ticks = 0;
+    hipMemcpy(&ticks, dout + 1536, 8, hipMemcpyDeviceToHost);
+    printf("T=%d  us per sweep:  full %.1f (%llu s_memtime ticks: %.2f ticks/ns) | update-only %.1f | barriers-only %.1f\n", T, full, ticks,
+           ticks / (full * 1e3), run<1>(dA, dout, T, n, reps), run<3>(dA, dout, T, n, reps));
     return 0;
 }
