@@ -366,6 +366,12 @@ struct Sweep {
         if (wave == owner_wave(0)) publish<0>(m, 0, 0, sm);
         phase<0>(m, nq, sm);
         __syncthreads();
+        // Opaque re-definition of the block: without it the pairing (SLP) choices of whatever consumes m next leak back
+        // into the sweep's register assignment (~190 extra v_mov per two block steps, +34 % sweep time, measured in k_inner).
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < CB; ++c) asm volatile("" : "+v"(m[r][c]));
     }
 
     // log-determinant and info from the pivots.  Contains barriers; all threads call; all get the same values.

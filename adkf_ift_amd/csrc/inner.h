@@ -113,14 +113,14 @@ struct InnerEval {
     // (this thread's block), sm.vec_out = alpha.  extra (9 floats) receives the scalars later stages reuse.
     // cache: NT * RB * CB floats of LDS; carries kappa'(u) u from the kernel build to the trace pass (no second exp).
     __device__ static __forceinline__ int run(SweepSmem<NMAX, NT>& sm, const D2& d2, float (&m)[RB][CB], int n,
-                                              const float* x, const float* pri, float& f, float* g, float* extra,
-                                              bool fast, float* cache) {
+                                              const float* x, const float* tr, const float* pri, float& f, float* g,
+                                              float* extra, bool fast, float* cache) {
         const int j0 = SW::bc() * CB, tid = threadIdx.x;
 #if ADKF_EVAL_STAMP
         const bool adkf_stamp_on = fast;   // the search evaluations (the final one uses libm expf)
 #endif
         ADKF_ES(0);
-        const float noise = softplus_f(x[0]) + NOISE_LB, os = softplus_f(x[1]), ls = softplus_f(x[2]);
+        const float noise = tr[0], os = tr[1], ls = tr[2];   // softplus of x, computed once per trial point (FitShared)
         const float il2 = 1.f / (ls * ls), gl = -2.f / ls;
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
@@ -144,19 +144,12 @@ struct InnerEval {
         __syncthreads();  // previous readers of sm (cross/vec_out) are done
         ADKF_ES(10);
         SW::run(m, n, sm);
-        // Opaque re-definition of the block: without it the pairing (SLP) choices of the consumers below leak back into
-        // the sweep's register assignment and cost ~190 extra v_mov per two block steps (+34 % sweep time, measured).
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int c = 0; c < CB; ++c) asm volatile("" : "+v"(m[r][c]));
         ADKF_ES(2);
         SW::solve(m, sm.vec_in, sm.vec_out);  // alpha = A^-1 y
         ADKF_ES(3);
-        float logdet;
-        const int info = SW::finish(n, sm, logdet);
         ADKF_ES(4);
-        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // tr(Ainv G), a^T G a, tr(Ainv), a^T a, y^T a
+        // tr(Ainv G), a^T G a, tr(Ainv), a^T a, y^T a, log|A|, number of non-positive pivots: ONE block reduction
+        float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float ai[RB], aj[CB];
 #pragma unroll
         for (int r = 0; r < RB; ++r) ai[r] = sm.vec_out[SW::row(r)];
@@ -176,10 +169,16 @@ struct InnerEval {
             const float a = sm.vec_out[tid];
             acc[3] = a * a;
             acc[4] = sm.vec_in[tid] * a;
+            const float p = sm.pivs[tid];
+            acc[5] = logf(p);
+            acc[6] = (p > 0.f) ? 0.f : 1.f;
         }
         ADKF_ES(5);
-        block_sum<5, NT>(acc, sm.red);
+        block_sum<7, NT>(acc, sm.red);
         ADKF_ES(6);
+        float logdet = acc[5];
+        int info = 0;
+        if (acc[6] > 0.f) info = SW::finish(n, sm, logdet);   // rare: locate the first non-positive pivot (uniform branch)
         if (tid >= 64) { f = 0.f; return info; }   // the scalar epilogue is consumed by lane 0 only: one wave computes it
         inner_finalize(n, x, pri, logdet, acc, f, g, extra);
         ADKF_ES(7);
@@ -264,7 +263,11 @@ struct Bfgs {
 struct FitShared {
     Bfgs st;
     float xe[3];
+    float tr[3];      // (noise, outputscale, lengthscale) at xe: computed once by the lane that moves xe, read by everybody
     int phase, evals;
+    __device__ __forceinline__ void set_transforms() {
+        tr[0] = softplus_f(xe[0]) + NOISE_LB; tr[1] = softplus_f(xe[1]); tr[2] = softplus_f(xe[2]);
+    }
 };
 
 enum { PH_INIT = 0, PH_SEARCH, PH_BURN, PH_FINAL };
@@ -310,6 +313,7 @@ __device__ __forceinline__ void fit_advance(FitShared& fs, const InnerArgs& a, f
     } else {
         st.trial(fs.xe);
     }
+    fs.set_transforms();
     fs.phase = phase;
 }
 
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
         fs.st.f = INFINITY;
         fs.phase = (a.max_evals > 0) ? PH_INIT : PH_FINAL;
         fs.evals = 0;
+        fs.set_transforms();
     }
     __syncthreads();
 
@@ -362,7 +367,8 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
     while (true) {
         const int phase = fs.phase;
         xe[0] = fs.xe[0]; xe[1] = fs.xe[1]; xe[2] = fs.xe[2];
-        const int ie = EV::run(sm, d2, m, n, xe, pri, fe, ge, extra, phase != PH_FINAL, inner_cache);
+        const float tr[3] = {fs.tr[0], fs.tr[1], fs.tr[2]};
+        const int ie = EV::run(sm, d2, m, n, xe, tr, pri, fe, ge, extra, phase != PH_FINAL, inner_cache);
         if (phase == PH_FINAL) { info = ie; evals = fs.evals + 1; break; }
         if (tid == 0) fit_advance(fs, a, fe, ge, ie);
         __syncthreads();
