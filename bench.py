@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--inner-evals", type=int, default=20)
     ap.add_argument("--kernel", default="rbf", choices=["rbf", "matern"])
     ap.add_argument("--converge", action="store_true", help="run the inner fit to convergence instead of a fixed I")
+    ap.add_argument("--graph", action="store_true", help="replay the GP section of the step from a captured HIP graph")
     ap.add_argument("--ard", action="store_true", help="ARD kernel (h = 2 + d inner parameters): device L-BFGS + HVP/CG; not the headline config")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -50,7 +51,7 @@ def main():
     import __graft_entry__ as ge
     from adkf_ift_amd import gp_ops, roofline
     from adkf_ift_amd.synthetic import LinearFeatureMap, make_tasks
-    from adkf_ift_amd.trainer import MetaStepConfig, meta_step
+    from adkf_ift_amd.trainer import GraphedGPBackend, MetaStepConfig, meta_step
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -77,6 +78,7 @@ def main():
     cfg = MetaStepConfig(gp_kernel=args.kernel, inner_max_evals=(200 if args.converge else I),
                          inner_exact_evals=not args.converge, clip_value=1.0, use_ard=args.ard)
     inv_sqrt_d = 1.0 / math.sqrt(d)
+    backend = GraphedGPBackend() if args.graph else None
 
     features = LinearFeatureMap(X_s, X_q, W)  # one GEMM for support+query rows; chunked-bmm backward
 
@@ -92,11 +94,11 @@ def main():
             torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        meta_step(features, [W], opt, y_s, y_q, cfg, distributed=distributed)
+        meta_step(features, [W], opt, y_s, y_q, cfg, distributed=distributed, backend=backend)
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        losses, phi = meta_step(features, [W], opt, y_s, y_q, cfg, distributed=distributed, fit_events=ev[k])
+        losses, phi = meta_step(features, [W], opt, y_s, y_q, cfg, distributed=distributed, fit_events=ev[k], backend=backend)
     sync()
     dt = time.perf_counter() - t0
     if distributed:

@@ -346,3 +346,22 @@ def test_bayes_opt_gp_ei_loop(dev):
                           init_from=20, noise_init=0.01, noise_prior=True, rng=np.random.default_rng(0))
     assert len(rec) == 1 + 8 * 2 and len(set(rec[1:])) == 16
     assert min(rec) <= 2          # reaches (one of) the best three points out of 60 within 16 queries
+
+
+def test_graph_replay_equals_eager(dev):
+    """GraphedGPBackend: the captured init -> fit -> hypergradient sequence replayed on new inputs gives exactly what the
+    eager backend computes (the library enqueues only kernels/memsets, so it is graph-capturable as the ABI promises)."""
+    from adkf_ift_amd.synthetic import make_tasks
+    from adkf_ift_amd.trainer import GraphedGPBackend, HipGPBackend, MetaStepConfig
+
+    cfg = MetaStepConfig(gp_kernel="matern", inner_max_evals=60)
+    graphed, eager = GraphedGPBackend(), HipGPBackend()
+    for first in (0, 50):     # second round: same shapes, different data -> pure replay
+        tasks = make_tasks(6, 24, 16, N_q=20, first_task=first)
+        Zs, Zq = tasks.features()
+        args = (Zs.to(dev), tasks.y_s.to(dev), Zq.to(dev), tasks.y_q.to(dev), cfg)
+        got = [t.clone() for t in graphed.run(*args)]
+        want = eager.run(*args)
+        for a, b, name in zip(got, want, ("phi", "f_out", "dZ_s", "dZ_q", "info_fit", "info")):
+            assert torch.equal(a, b), name
+    assert len(graphed._graphs) == 1
