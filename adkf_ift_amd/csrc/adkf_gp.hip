@@ -272,10 +272,8 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
     const int T = b->T, ns = b->ns_max, nq = b->nq_max, d = b->d;
     int rc = stage_dist(b, w, true, st);
     if (rc) return rc;
-    if (b->flags & ADKF_BATCH_REUSE_INNER) {
-        // A^-1, alpha and the per-task scalars of phi are already in the workspace (left by adkf_fit)
-        hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)T, st);
-    } else {
+    const bool reuse_inner = (b->flags & ADKF_BATCH_REUSE_INNER) != 0;
+    if (!reuse_inner) {
         InnerArgs ia = inner_args(b, w, const_cast<float*>(phi), info);
         rc = launch_inner(ia, w, st);
         if (rc) return rc;
@@ -304,23 +302,25 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
     launch_gemm(pc, T, nq, ns, st);
     ProbS ps; ps.tv = tv; ps.C = w.C; ps.D2qs = w.D2qs; ps.D2qq = w.D2qq; ps.S = w.S;
     launch_gemm(ps, T, nq, nq, st);
-    OuterArgs oa{tv, w.C, w.S, b->y_s, b->y_q, w.vecs, w.scal, f_out, info, T};
+    // (reused inner stage: A^-1, alpha and the scalars of phi are in the workspace, info[] is written by the outer factor)
+    OuterArgs oa{tv, w.C, w.S, b->y_s, b->y_q, w.vecs, w.scal, f_out, info, T, reuse_inner ? 1 : 0};
     rc = launch_outer_factor(oa, w, nq, st);
     if (rc) return rc;
     ProbOC po; po.tv = tv; po.Sinv = w.S; po.C = w.C; po.D2qs = w.D2qs; po.OC = w.OC; po.Wqs = w.Wqs; po.part = w.part_oc; po.ntiles = w.nt_oc; po.dirscale = dirscale;
     launch_gemm(po, T, nq, ns, st);
     ProbMA pm; pm.tv = tv; pm.C = w.C; pm.OC = w.OC; pm.D2ss = w.D2ss; pm.Wss = w.Wss; pm.part = w.part_ma; pm.ntiles = w.nt_ma; pm.dirscale = dirscale;
     launch_gemm(pm, T, ns, ns, st);
-    WqqArgs wq{tv, w.S, w.D2qq, w.Wqq, w.scal, dirscale, T};
+    SolveArgs sa{tv, w.scal, w.vecs, w.part_oc, w.part_ma, w.nt_oc, w.nt_ma, flags, g_phi_out, v_out, H_out, T, with_hessian ? 1 : 0};
+    WqqArgs wq{tv, w.S, w.D2qq, w.Wqq, w.scal, dirscale, T, 0, sa};
     if (nq > REG_POINTS) {
         LgWqq lw{wq, w.lg_part, tmq * tmq, tmq};
         k_lg_wqq<<<grid_for(T, tmq * tmq), 256, 0, st>>>(lw);
         k_lg_wqq_fin<<<T, 64, 0, st>>>(lw);
+        k_solve_v<<<T, 64, 0, st>>>(sa);
     } else {
+        wq.do_solve = 1;   // g_out, v and w in the tail of the same workgroup
         k_wqq<<<grid_for(T, 1), SMALL_NT, 0, st>>>(wq);
     }
-    SolveArgs sa{tv, w.scal, w.vecs, w.part_oc, w.part_ma, w.nt_oc, w.nt_ma, flags, g_phi_out, v_out, H_out, T, with_hessian ? 1 : 0};
-    k_solve_v<<<T, 64, 0, st>>>(sa);
     if (corrscale != 0.f) {
         ProbMixed px; px.tv = tv; px.Ainv = w.Ainv; px.P = w.P; px.D2ss = w.D2ss; px.Wss = w.Wss; px.corrscale = corrscale;
         launch_gemm(px, T, ns, ns, st);
@@ -329,12 +329,12 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         RowsumArgs ra{tv, w.Wss, w.Wqs, w.Wqq, w.vecs, T};
         launch_rowsums(ra, w, st);
         if (dZ_s) {
-            hipMemsetAsync(dZ_s, 0, (size_t)T * ns * d * sizeof(float), st);
+            if (b->n_s) hipMemsetAsync(dZ_s, 0, (size_t)T * ns * d * sizeof(float), st);   // padded rows only exist in ragged batches
             ProbDZ<false> pz; pz.tv = tv; pz.Wss = w.Wss; pz.Wqs = w.Wqs; pz.Wqq = w.Wqq; pz.Zs = b->Z_s; pz.Zq = b->Z_q; pz.dZ = dZ_s; pz.d = d;
             launch_gemm(pz, T, ns, d, st);
         }
         if (dZ_q) {
-            hipMemsetAsync(dZ_q, 0, (size_t)T * nq * d * sizeof(float), st);
+            if (b->n_q) hipMemsetAsync(dZ_q, 0, (size_t)T * nq * d * sizeof(float), st);
             ProbDZ<true> pz; pz.tv = tv; pz.Wss = w.Wss; pz.Wqs = w.Wqs; pz.Wqq = w.Wqq; pz.Zs = b->Z_s; pz.Zq = b->Z_q; pz.dZ = dZ_q; pz.d = d;
             launch_gemm(pz, T, nq, d, st);
         }
@@ -604,17 +604,13 @@ size_t adkf_workspace_bytes(int32_t T, int32_t ns_max, int32_t nq_max, int32_t d
     return carve(nullptr, T, ns_max, nq_max, d).bytes;
 }
 
-int adkf_median_lengthscale(const adkf_batch_t* b, float* l0, void* ws, size_t ws_bytes, void* stream) {
-    int rc = check_batch(b, false);
+// median heuristic (+ optionally a4 in the same launch); returns true through *fused when init was applied
+static int median_core(const adkf_batch_t* b, const Workspace& w, float* l0, const InitArgs& init, bool* fused, hipStream_t st) {
+    int rc = stage_dist(b, w, has_query(b), st);
     if (rc) return rc;
-    if (!l0 || !ws) return ADKF_E_BADARG;
-    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
-    if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    rc = stage_dist(b, w, has_query(b), st);
-    if (rc) return rc;
-    if (b->ns_max <= 128) k_median<512, 32><<<grid_for(b->T, 1), 512, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T);
-    else if (b->ns_max <= 256) k_median<1024, 64><<<grid_for(b->T, 1), 1024, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T);
+    *fused = b->ns_max <= 256;
+    if (b->ns_max <= 128) k_median<512, 32><<<grid_for(b->T, 1), 512, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T, init);
+    else if (b->ns_max <= 256) k_median<1024, 64><<<grid_for(b->T, 1), 1024, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T, init);
     else {
         LgMedian lm{w.D2ss, b->n_s, b->ns_max, l0, b->T, reinterpret_cast<uint32_t*>(w.lg_med), w.lg_med + b->T, w.lg_med + 2 * (size_t)b->T};
         hipMemsetAsync(lm.hist, 0, sizeof(int) * 256 * (size_t)b->T, st);
@@ -628,6 +624,16 @@ int adkf_median_lengthscale(const adkf_batch_t* b, float* l0, void* ws, size_t w
     return 0;
 }
 
+int adkf_median_lengthscale(const adkf_batch_t* b, float* l0, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_batch(b, false);
+    if (rc) return rc;
+    if (!l0 || !ws) return ADKF_E_BADARG;
+    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
+    if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
+    bool fused;
+    return median_core(b, w, l0, InitArgs{0, 0, nullptr, nullptr}, &fused, static_cast<hipStream_t>(stream));
+}
+
 int adkf_init_params(const adkf_batch_t* b, int32_t use_numeric_labels, int32_t use_lengthscale_prior, float* phi,
                      float* priors, float* l0, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_batch(b, false);
@@ -636,18 +642,19 @@ int adkf_init_params(const adkf_batch_t* b, int32_t use_numeric_labels, int32_t 
     Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     float* l0p = l0 ? l0 : w.l0;
-    rc = adkf_median_lengthscale(b, l0p, ws, ws_bytes, stream);
-    if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    InitArgs init{use_numeric_labels, use_lengthscale_prior, phi, priors};
+    ArdWs a{};
     if (is_ard(b)) {  // every lengthscale starts at the median heuristic (adaptive_dkt.py:101)
-        ArdWs a = carve_ard(ws, w.bytes, b->T, b->ns_max, b->nq_max, b->d);
+        a = carve_ard(ws, w.bytes, b->T, b->ns_max, b->nq_max, b->d);
         if (ws_bytes < a.bytes) return ADKF_E_WORKSPACE;
-        k_init_params<<<ceil_div(b->T, 64), 64, 0, st>>>(l0p, b->T, use_numeric_labels, use_lengthscale_prior, a.phi3, priors);
-        k_ard_expand_phi<<<dim3(ceil_div(2 + b->d, 256), b->T), 256, 0, st>>>(a.phi3, phi, b->T, 2 + b->d);
-        LAUNCH_OK();
-        return 0;
+        init.phi = a.phi3;
     }
-    k_init_params<<<ceil_div(b->T, 64), 64, 0, st>>>(l0p, b->T, use_numeric_labels, use_lengthscale_prior, phi, priors);
+    bool fused = false;
+    rc = median_core(b, w, l0p, init, &fused, st);
+    if (rc) return rc;
+    if (!fused) k_init_params<<<ceil_div(b->T, 64), 64, 0, st>>>(l0p, b->T, init);
+    if (is_ard(b)) k_ard_expand_phi<<<dim3(ceil_div(2 + b->d, 256), b->T), 256, 0, st>>>(a.phi3, phi, b->T, 2 + b->d);
     LAUNCH_OK();
     return 0;
 }

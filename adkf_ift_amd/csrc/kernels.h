@@ -80,12 +80,32 @@ struct ProbDist {
     __device__ void store_red(int, const float*) const {}
 };
 
+// ---- a4: fresh phi and priors ---------------------------------------------------------------------------
+struct InitArgs { int numeric, use_ls_prior; float* phi; float* priors; };   // phi == null: nothing to initialise
+
+__device__ __forceinline__ void init_params_task(const InitArgs& a, int t, float l0) {
+    const float scale = 0.25f;
+    const float mode = a.numeric ? 0.01f : 0.1f;
+    a.phi[t * 3 + 0] = inv_softplus_f(mode - NOISE_LB);
+    a.phi[t * 3 + 1] = 0.f;
+    a.phi[t * 3 + 2] = inv_softplus_f(l0);
+    a.priors[t * 4 + 0] = logf(mode) + scale * scale;
+    a.priors[t * 4 + 1] = scale;
+    a.priors[t * 4 + 2] = a.use_ls_prior ? logf(l0) + scale * scale : 0.f;
+    a.priors[t * 4 + 3] = a.use_ls_prior ? scale : -1.f;
+}
+
+__global__ void k_init_params(const float* l0, int T, InitArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) init_params_task(a, t, l0[t]);
+}
+
 // ---- K10: median heuristic.  Exact lower median of the positive strict-upper-triangle entries by a
 // 31-step radix select on the float bit patterns (positive floats order like their bits). ---------------
 // One workgroup per task; the (at most 128 x 128) candidates are loaded ONCE into registers (32 per lane), every
 // radix step is then 32 compares + a wave/LDS count reduction, no memory traffic.
 template <int NT, int EPT>  // NT * EPT >= ld * ld: <512, 32> up to 128 points, <1024, 64> up to 256
-__global__ __launch_bounds__(NT) void k_median(const float* D2ss, const int32_t* n_s, int ld, float* l0, int T) {
+__global__ __launch_bounds__(NT) void k_median(const float* D2ss, const int32_t* n_s, int ld, float* l0, int T, InitArgs init) {
     __shared__ int red[NT / 64];
     int t, tile;
     if (!task_tile(T, 1, t, tile)) return;
@@ -102,7 +122,7 @@ __global__ __launch_bounds__(NT) void k_median(const float* D2ss, const int32_t*
         cnt += (v[r] != 0u);
     }
     const int total = block_sum_i<NT>(cnt, red);
-    if (total == 0) { if (tid == 0) l0[t] = 0.f; return; }
+    if (total == 0) { if (tid == 0) { l0[t] = 0.f; if (init.phi) init_params_task(init, t, 0.f); } return; }
     int rank = (total - 1) / 2;  // torch.median: lower median
     uint32_t prefix = 0;
     for (int bit = 30; bit >= 0; --bit) {
@@ -113,22 +133,11 @@ __global__ __launch_bounds__(NT) void k_median(const float* D2ss, const int32_t*
         c0 = block_sum_i<NT>(c0, red);
         if (rank >= c0) { rank -= c0; prefix |= (1u << bit); }
     }
-    if (tid == 0) l0[t] = sqrtf(0.5f * __uint_as_float(prefix));
-}
-
-// ---- a4: fresh phi and priors ---------------------------------------------------------------------------
-__global__ void k_init_params(const float* l0, int T, int numeric, int use_ls_prior, float* phi, float* priors) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
-    const float scale = 0.25f;
-    const float mode = numeric ? 0.01f : 0.1f;
-    phi[t * 3 + 0] = inv_softplus_f(mode - NOISE_LB);
-    phi[t * 3 + 1] = 0.f;
-    phi[t * 3 + 2] = inv_softplus_f(l0[t]);
-    priors[t * 4 + 0] = logf(mode) + scale * scale;
-    priors[t * 4 + 1] = scale;
-    priors[t * 4 + 2] = use_ls_prior ? logf(l0[t]) + scale * scale : 0.f;
-    priors[t * 4 + 3] = use_ls_prior ? scale : -1.f;
+    if (tid == 0) {
+        const float l = sqrtf(0.5f * __uint_as_float(prefix));
+        l0[t] = l;
+        if (init.phi) init_params_task(init, t, l);   // a4 in the same launch
+    }
 }
 
 // ---- Stage C: beta = G alpha, gamma = Ainv alpha, delta = Ainv beta, traces, 3x3 Hessian ------------------
@@ -215,7 +224,8 @@ __global__ __launch_bounds__(SMALL_NT) void k_hess(HessArgs a) {
 }
 
 // ---- Stage D core: mu = C y, r = y_q - mu, factor S, e = S^-1 r, f_out, Cte = C^T e --------------------
-struct OuterArgs { TaskView tv; const float* C; float* S; const float* y_s; const float* y_q; float* vecs; float* scal; float* f_out; int32_t* info; int T; };
+struct OuterArgs { TaskView tv; const float* C; float* S; const float* y_s; const float* y_q; float* vecs; float* scal; float* f_out; int32_t* info; int T;
+                   int reset_info; };  // reset_info: info[] holds nothing yet (the inner stage was reused): write, do not merge
 
 template <int NMAX, int NT>
 __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
@@ -282,37 +292,9 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
         a.scal[(size_t)t * NSCAL + S_FOUT] = f;
         a.scal[(size_t)t * NSCAL + S_LOGDETS] = logdet;
         if (a.f_out) a.f_out[t] = (info == 0) ? f : NAN;
-        if (info != 0 && a.info[t] == 0) a.info[t] = 100000 + info;
+        if (a.reset_info) a.info[t] = info != 0 ? 100000 + info : 0;
+        else if (info != 0 && a.info[t] == 0) a.info[t] = 100000 + info;
     }
-}
-
-// ---- W_qq = dir * Omega . s kappa'(u_qq)/l^2 and its three reductions -------------------------------------
-struct WqqArgs { TaskView tv; const float* Sinv; const float* D2qq; float* Wqq; float* scal; float dirscale; int T; };
-
-__global__ __launch_bounds__(SMALL_NT) void k_wqq(WqqArgs a) {
-    constexpr int NT = SMALL_NT;
-    __shared__ float red[3 * (NT / 64)];
-    int t, tile;
-    if (!task_tile(a.T, 1, t, tile)) return;
-    const int m = a.tv.nq(t), ld = a.tv.nq_ld, tid = threadIdx.x;
-    float* sc = a.scal + (size_t)t * NSCAL;
-    const float os = sc[S_OS], ls = sc[S_LS], il2 = 1.f / (ls * ls);
-    const float* Si = a.Sinv + (size_t)t * ld * ld;
-    const float* D2 = a.D2qq + (size_t)t * ld * ld;
-    float* Wo = a.Wqq + (size_t)t * ld * ld;
-    const float* ev = a.tv.vec_ptr(t, V_E);
-    float acc[3] = {0.f, 0.f, 0.f};
-    for (int e = tid; e < m * m; e += NT) {
-        const int i = e / m, j = e - i * m;
-        const float om = 0.5f * (Si[(size_t)i * ld + j] - ev[i] * ev[j]);
-        float k0, k1, k2; const float u = D2[(size_t)i * ld + j] * il2; kappa3(a.tv.kind, u, k0, k1, k2);
-        Wo[(size_t)i * ld + j] = a.dirscale * om * os * k1 * il2;
-        if (i == j) acc[0] += om;
-        acc[1] += om * k0;
-        acc[2] += om * os * k1 * u * (-2.f / ls);
-    }
-    block_sum<3, NT>(acc, red);
-    if (tid == 0) { sc[S_QQ_TR] = acc[0]; sc[S_QQ_K] = acc[1]; sc[S_QQ_L] = acc[2]; }
 }
 
 // ---- W_ss for d f_in / dZ:  Q . s kappa'/l^2,  Q = (Ainv - alpha alpha^T) / (2n) -------------------------
@@ -338,9 +320,8 @@ __global__ __launch_bounds__(256) void k_win(WinArgs a) {
 // ---- g_out, v = H^-1 g_out, coefficients and the vector w = A^-1 B_v alpha -------------------------------
 struct SolveArgs { TaskView tv; float* scal; float* vecs; const float* part_oc; const float* part_ma; int nt_oc, nt_ma; int flags; float* g_phi_out; float* v_out; float* H_out; int T; int with_hessian; };
 
-__global__ __launch_bounds__(64) void k_solve_v(SolveArgs a) {
-    const int t = blockIdx.x;
-    if (t >= a.T) return;
+// Called by ALL threads of a workgroup (any size >= 64); contains one barrier.
+__device__ __forceinline__ void solve_v_task(const SolveArgs& a, int t) {
     float* sc = a.scal + (size_t)t * NSCAL;
     const int n = a.tv.ns(t), lane = threadIdx.x;
     __shared__ float sh[8];
@@ -380,10 +361,51 @@ __global__ __launch_bounds__(64) void k_solve_v(SolveArgs a) {
     if (a.with_hessian) {
         const float cn = sh[0], cs = sh[1], cl = sh[2], noise = sh[3];
         float* vb = a.vecs + (size_t)t * NVEC * a.tv.vld;
-        for (int i = lane; i < n; i += 64) {
+        for (int i = lane; i < n; i += (int)blockDim.x) {
             const float al = vb[V_ALPHA * a.tv.vld + i], ga = vb[V_GAMMA * a.tv.vld + i], de = vb[V_DELTA * a.tv.vld + i];
             vb[V_W * a.tv.vld + i] = cn * ga + cs * (al - noise * ga) + cl * de;
         }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_solve_v(SolveArgs a) {
+    const int t = blockIdx.x;
+    if (t >= a.T) return;
+    solve_v_task(a, t);
+}
+
+// ---- W_qq = dir * Omega . s kappa'(u_qq)/l^2 and its three reductions -------------------------------------
+struct WqqArgs { TaskView tv; const float* Sinv; const float* D2qq; float* Wqq; float* scal; float dirscale; int T;
+                 int do_solve; SolveArgs solve; };  // do_solve: finish with solve_v_task (saves the k_solve_v launch)
+
+__global__ __launch_bounds__(SMALL_NT) void k_wqq(WqqArgs a) {
+    constexpr int NT = SMALL_NT;
+    __shared__ float red[3 * (NT / 64)];
+    int t, tile;
+    if (!task_tile(a.T, 1, t, tile)) return;
+    const int m = a.tv.nq(t), ld = a.tv.nq_ld, tid = threadIdx.x;
+    float* sc = a.scal + (size_t)t * NSCAL;
+    const float os = sc[S_OS], ls = sc[S_LS], il2 = 1.f / (ls * ls);
+    const float* Si = a.Sinv + (size_t)t * ld * ld;
+    const float* D2 = a.D2qq + (size_t)t * ld * ld;
+    float* Wo = a.Wqq + (size_t)t * ld * ld;
+    const float* ev = a.tv.vec_ptr(t, V_E);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int e = tid; e < m * m; e += NT) {
+        const int i = e / m, j = e - i * m;
+        const float om = 0.5f * (Si[(size_t)i * ld + j] - ev[i] * ev[j]);
+        float k0, k1, k2; const float u = D2[(size_t)i * ld + j] * il2; kappa3(a.tv.kind, u, k0, k1, k2);
+        Wo[(size_t)i * ld + j] = a.dirscale * om * os * k1 * il2;
+        if (i == j) acc[0] += om;
+        acc[1] += om * k0;
+        acc[2] += om * os * k1 * u * (-2.f / ls);
+    }
+    block_sum<3, NT>(acc, red);
+    if (tid == 0) { sc[S_QQ_TR] = acc[0]; sc[S_QQ_K] = acc[1]; sc[S_QQ_L] = acc[2]; }
+    if (a.do_solve) {
+        __threadfence_block();
+        __syncthreads();
+        solve_v_task(a.solve, t);
     }
 }
 

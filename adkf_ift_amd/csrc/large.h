@@ -359,7 +359,8 @@ __global__ __launch_bounds__(64) void k_lg_outer_fin(LgOuterFin a) {
         a.o.scal[(size_t)t * NSCAL + S_FOUT] = f;
         a.o.scal[(size_t)t * NSCAL + S_LOGDETS] = logdet;
         if (a.o.f_out) a.o.f_out[t] = (info == 0) ? f : NAN;
-        if (info != 0 && a.o.info[t] == 0) a.o.info[t] = 100000 + info;
+        if (a.o.reset_info) a.o.info[t] = info != 0 ? 100000 + info : 0;
+        else if (info != 0 && a.o.info[t] == 0) a.o.info[t] = 100000 + info;
     }
 }
 

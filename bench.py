@@ -99,6 +99,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         losses, phi = meta_step(features, [W], opt, y_s, y_q, cfg, distributed=distributed, fit_events=ev[k], backend=backend)
+    t_host = time.perf_counter() - t0   # when the host finished ENQUEUEING the K steps (== dt would mean host-bound)
     sync()
     dt = time.perf_counter() - t0
     if distributed:
@@ -175,6 +176,7 @@ def main():
                          "bound": "mfma", "achieved": achieved, "peak": roofline.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / roofline.PEAK_FP32_TFLOPS, "traffic": traffic,
                          "flops_per_launch": fit_flops, "avg_launch_ms": fit_ms},
+            "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             "cpu_baseline": cpu_baseline,
             "parity": parity,
         }
