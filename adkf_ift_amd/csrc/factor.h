@@ -23,6 +23,9 @@
 // waits for it; measured ~0.4 us against ~0.23 us of bulk FMAs per step, tools/chain_bench.hip), so:
 //   * a thread's RB rows are G = RB/CB groups of B rows that lie NMAX/G apart, and consecutive logical block
 //     rows live in DIFFERENT waves: the ownership of the chain rotates over the waves from step to step;
+//   * (measured and rejected: sending the NEXT diagonal block from its holder before step q's update and letting every
+//     lane of the block row update a private copy - 10 x 4 FMAs - instead of waiting for the post-update broadcast:
+//     27.4 -> 32.7 us per sweep, the extra scalar FMAs and vector reads cost more than the ~450 cycles they hide)
 //   * the owning wave updates only the next pivot rows, runs the chain at raised priority and goes straight to
 //     the barrier; it applies the REST of that step's update one step later, when another wave is on the chain
 //     (vector slots are triple-buffered so the old vectors are still there).
@@ -219,10 +222,8 @@ struct Sweep {
 #pragma unroll
             for (int a = 0; a < B; ++a)
 #pragma unroll
-                for (int c = 0; c < CB; ++c) {
-                    sm.fvec[slot][a][j0 + c] = F[a][c];
+                for (int c = 0; c < CB; ++c) sm.fvec[slot][a][j0 + c] = F[a][c];
             ADKF_TS(6);
-                }
         }
         } else {
             // 64 matrix elements per lane: no registers to spare, form C and F straight from the matrix registers
