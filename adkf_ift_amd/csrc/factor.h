@@ -25,7 +25,8 @@
 //     rows live in DIFFERENT waves: the ownership of the chain rotates over the waves from step to step;
 //   * (measured and rejected: sending the NEXT diagonal block from its holder before step q's update and letting every
 //     lane of the block row update a private copy - 10 x 4 FMAs - instead of waiting for the post-update broadcast:
-//     27.4 -> 32.7 us per sweep, the extra scalar FMAs and vector reads cost more than the ~450 cycles they hide)
+//     27.4 -> 32.7 us per sweep, the extra scalar FMAs and vector reads cost more than the ~450 cycles they hide;
+//     nor a store / read-back of the block through LDS inside the owning wave instead of the ten ds_bpermute: 29.2 us)
 //   * the owning wave updates only the next pivot rows, runs the chain at raised priority and goes straight to
 //     the barrier; it applies the REST of that step's update one step later, when another wave is on the chain
 //     (vector slots are triple-buffered so the old vectors are still there).
