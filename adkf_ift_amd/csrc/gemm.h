@@ -11,6 +11,8 @@
 // Tile size: the 128 x 128 tile halves the L2 -> CU operand traffic of the 64 x 64 one, but with 256 threads it leaves
 // one wave per SIMD and nothing to cover the stage/barrier phases: measured 1.4-1.8x SLOWER on every C2 stage, so the
 // host (adkf_gp.hip::tile_edge) always picks 64; the variant stays for experiments with more waves per tile.
+// Also measured without gain: a double-buffered LDS tile with one barrier per chunk (1.530 -> 1.549 ms per C2 step:
+// the second buffer halves the workgroups per CU, which costs more than the removed barrier).
 //
 // A problem type P provides
 //   static constexpr bool A_KCONTIG / B_KCONTIG : is the operand contiguous in memory along k?  (chooses
