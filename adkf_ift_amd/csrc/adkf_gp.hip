@@ -351,7 +351,7 @@ struct ArdWs {
     float *mu, *ell, *Zt_s, *Zt_q, *G, *Gd_s, *Gd_q, *Gdot, *phi3, *pri3, *f3, *g3, *g3o, *S1, *gt, *coldot;
     float *c, *ut2, *wn, *Ddot, *Wdot, *adot, *S2;
     ArdFitState* fst; float *x, *g, *p, *xe, *ge, *S, *Y, *fe; int32_t* info3;
-    ArdCgState* cst; float *cx, *cr, *cp, *cHp, *gout;
+    ArdCgState* cst; float *cx, *cr, *cp, *cHp, *gout; int32_t* n_eff;
     size_t bytes;
 };
 
@@ -373,6 +373,7 @@ ArdWs carve_ard(void* base, size_t off0, int T, int ns, int nq, int d) {
     a.info3 = reinterpret_cast<int32_t*>(take(Tz));
     a.cst = reinterpret_cast<ArdCgState*>(take(Tz * ((sizeof(ArdCgState) + 3) / 4)));
     a.cx = take(Tz * h); a.cr = take(Tz * h); a.cp = take(Tz * h); a.cHp = take(Tz * h); a.gout = take(Tz * h);
+    a.n_eff = reinterpret_cast<int32_t*>(take(Tz));
     a.bytes = off;
     return a;
 }
@@ -402,8 +403,9 @@ int ard_setup(const adkf_batch_t* b, void* ws, size_t ws_bytes, hipStream_t st, 
 }
 
 // d f / d Z~_s for the weights in w.Wss (symmetric) -> out
-void ard_dz_support(ArdCtx& c, const float* W, float* out) {
+void ard_dz_support(ArdCtx& c, const float* W, float* out, const int32_t* n_override = nullptr) {
     TaskView tv = make_tv(&c.bt, c.w, false);
+    if (n_override) tv.n_s = n_override;
     RowsumArgs ra{tv, W, nullptr, nullptr, c.w.vecs, c.T};
     launch_rowsums(ra, c.w, c.st);
     ProbDZ<false> pz; pz.tv = tv; pz.Wss = W; pz.Wqs = nullptr; pz.Wqq = nullptr; pz.Zs = c.a.Zt_s; pz.Zq = nullptr; pz.dZ = out; pz.d = c.d;
@@ -434,9 +436,11 @@ int ard_eval(ArdCtx& c, const float* x, float* f, float* g, int32_t* info3) {
     return 0;
 }
 
-ArdHvp ard_hvp_args(ArdCtx& c, const float* x, const float* u, float* Hu, const ArdCgState* cg) {
+// masked = true: sizes come from n_eff (0 for tasks whose CG has converged), so every kernel of the product skips them
+ArdHvp ard_hvp_args(ArdCtx& c, const float* x, const float* u, float* Hu, const ArdCgState* cg, bool masked = false) {
     ArdHvp hv;
     hv.v = c.v; hv.tv = make_tv(&c.bt, c.w, false); hv.x = x; hv.u = u; hv.Hu = Hu;
+    if (masked) { hv.v.n_s = c.a.n_eff; hv.tv.n_s = c.a.n_eff; }
     hv.c = c.a.c; hv.ut2 = c.a.ut2; hv.wn = c.a.wn; hv.D2 = c.w.D2ss; hv.Ainv = c.w.Ainv;
     hv.Ddot = c.a.Ddot; hv.X = c.w.P; hv.Wdot = c.a.Wdot; hv.adot = c.a.adot;
     hv.part = c.w.part_ma; hv.ntiles = c.w.nt_ma; hv.G = c.a.G; hv.Gdot = c.a.Gdot; hv.S2 = c.a.S2; hv.cg = cg;
@@ -452,13 +456,13 @@ void ard_hvp_core(ArdCtx& c, const ArdHvp& hv) {
     ProbArdX px; px.h = hv; launch_gemm(px, c.T, c.ns, c.ns, st);
     k_ard_adot<<<dim3(ceil_div(c.ns, 4), c.T), 256, 0, st>>>(hv);
     ProbArdY py; py.h = hv; launch_gemm(py, c.T, c.ns, c.ns, st);
-    ard_dz_support(c, c.a.Wdot, c.a.Gdot);
+    ard_dz_support(c, c.a.Wdot, c.a.Gdot, hv.tv.n_s);
 }
 
 void ard_hvp(ArdCtx& c, const float* x, const float* u, float* Hu, const ArdCgState* cg) {
-    ArdHvp hv = ard_hvp_args(c, x, u, Hu, cg);
+    ArdHvp hv = ard_hvp_args(c, x, u, Hu, cg, cg != nullptr);
     ard_hvp_core(c, hv);
-    ArdColdot cd{c.a.Zt_s, c.a.Gdot, c.b->n_s, c.ns, nullptr, nullptr, nullptr, 0, c.a.S2, c.d};
+    ArdColdot cd{c.a.Zt_s, c.a.Gdot, hv.tv.n_s, c.ns, nullptr, nullptr, nullptr, 0, c.a.S2, c.d};
     k_ard_coldot<<<dim3(ceil_div(c.d, 64), c.T), 256, 0, c.st>>>(cd);
     k_ard_hvp_fin<<<c.T, 256, 0, c.st>>>(hv);
 }
@@ -561,7 +565,7 @@ int ard_ift(const adkf_batch_t* b, const float* phi, int flags, bool with_hessia
     if (g_phi_out) hipMemcpyAsync(g_phi_out, c.a.gout, hb, hipMemcpyDeviceToDevice, st);
     const bool correct = with_hessian && !(flags & ADKF_IGNORE_GRAD_CORRECTION);
     if (correct) {
-        ArdCg cg{c.T, c.h, cg_tol, c.a.cst, c.a.gout, c.a.cx, c.a.cr, c.a.cp, c.a.cHp};
+        ArdCg cg{c.T, c.h, cg_tol, c.a.cst, c.a.gout, c.a.cx, c.a.cr, c.a.cp, c.a.cHp, b->n_s, c.ns, c.a.n_eff};
         k_ard_cg_begin<<<c.T, 256, 0, st>>>(cg);
         for (int it = 0; it < cg_maxiter; ++it) {
             ard_hvp(c, phi, c.a.cp, c.a.cHp, c.a.cst);

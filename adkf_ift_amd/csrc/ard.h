@@ -464,7 +464,8 @@ __global__ __launch_bounds__(256) void k_ard_hvp_fin(ArdHvp a) {
 }
 
 // ---- conjugate gradients (one workgroup per task) -------------------------------------------------------------------------
-struct ArdCg { int T, h; float tol; ArdCgState* st; const float* b; float *x, *r, *p; const float* Hp; };
+struct ArdCg { int T, h; float tol; ArdCgState* st; const float* b; float *x, *r, *p; const float* Hp;
+               const int32_t* n_s; int ns_ld; int32_t* n_eff; };  // n_eff[t] = 0 once task t has converged: every kernel of the next HVP skips it
 
 __global__ __launch_bounds__(256) void k_ard_cg_begin(ArdCg a) {
     __shared__ float red[4];
@@ -476,7 +477,10 @@ __global__ __launch_bounds__(256) void k_ard_cg_begin(ArdCg a) {
         s += v * v;
     }
     s = bsum256(s, red);
-    if (tid == 0) { ArdCgState& c = a.st[t]; c.rs = s; c.b2 = s; c.pHp = 0.f; c.done = (s == 0.f) ? 1 : 0; c.iters = 0; c.breakdown = 0; }
+    if (tid == 0) {
+        ArdCgState& c = a.st[t]; c.rs = s; c.b2 = s; c.pHp = 0.f; c.done = (s == 0.f) ? 1 : 0; c.iters = 0; c.breakdown = 0;
+        a.n_eff[t] = c.done ? 0 : (a.n_s ? a.n_s[t] : a.ns_ld);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_ard_cg_step(ArdCg a) {
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(256) void k_ard_cg_step(ArdCg a) {
     pHp = bsum256(pHp, red);
     const float rs = c.rs;
     if (!(pHp > 0.f)) {  // negative curvature or NaN: H is not positive definite along p - keep the current iterate
-        if (tid == 0) { c.done = 1; c.breakdown = 1; }
+        if (tid == 0) { c.done = 1; c.breakdown = 1; a.n_eff[t] = 0; }
         return;
     }
     const float al = rs / pHp;
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(256) void k_ard_cg_step(ArdCg a) {
     rn = bsum256(rn, red);
     const float beta = rn / rs;
     for (int k = tid; k < h; k += 256) p[k] = r[k] + beta * p[k];
-    if (tid == 0) { c.rs = rn; c.pHp = pHp; c.iters += 1; if (rn <= a.tol * a.tol * c.b2) c.done = 1; }
+    if (tid == 0) { c.rs = rn; c.pHp = pHp; c.iters += 1; if (rn <= a.tol * a.tol * c.b2) { c.done = 1; a.n_eff[t] = 0; } }
 }
 
 // ---- outer gradient in the h raw parameters, final feature gradients ------------------------------------------------------
