@@ -79,7 +79,7 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
     w.l0 = take(Tz);
     w.lg_Dinv = w.lg_C = w.lg_F = w.lg_logdet = w.lg_part = nullptr; w.lg_info = w.lg_med = nullptr; w.lg_fit = nullptr;
     if (w.vld > REG_POINTS) {
-        w.lg_Dinv = take(2 * Tz * LB * LB);   // two buffers: look-ahead of lg_sweep
+        w.lg_Dinv = take(Tz * LB * LB);
         w.lg_C = take(Tz * LB * w.vld);
         w.lg_F = take(Tz * LB * w.vld);
         w.lg_logdet = take(Tz);
@@ -178,48 +178,15 @@ LgMat lg_mat(const Workspace& w, float* M, int ld, const int32_t* n_arr, const F
     return m;
 }
 
-// One side stream + two events per host thread for the look-ahead of lg_sweep (created on first use).
-struct LgSide { hipStream_t s = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr; };
-LgSide& lg_side() {
-    thread_local LgSide x;
-    if (!x.s) {
-        hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking);
-        hipEventCreateWithFlags(&x.ev_a, hipEventDisableTiming);
-        hipEventCreateWithFlags(&x.ev_b, hipEventDisableTiming);
-    }
-    return x;
-}
-
-// M -> -(M^-1) in place by 128-pivot block steps (large.h).  Look-ahead: as soon as step k has updated the NEXT
-// diagonal block (a 2 x 2-tile launch), its factorisation - one latency-bound workgroup per task - runs on a side
-// stream while the rest of step k's update fills the chip; the fork/join is two events, so the sequence stays
-// graph-capturable.  D^-1 alternates between two buffers because step k's update still reads D_k^-1.
-void lg_sweep(const LgMat& m0, hipStream_t st) {
-    const int nb = ceil_div(m0.ld, LB), tn = ceil_div(m0.ld, GT);
-    LgSide& side = lg_side();
-    LgMat m = m0;
-    float* dinv[2] = {m0.Dinv, m0.Dinv + (size_t)m0.T * LB * LB};
-    m.Dinv = dinv[0];
-    k_lg_diag<<<grid_for(m.T, 1), 512, 0, st>>>(m, 0);
+// M -> -(M^-1) in place by 128-pivot block steps (large.h)
+void lg_sweep(const LgMat& m, hipStream_t st) {
+    const int nb = ceil_div(m.ld, LB), tn = ceil_div(m.ld, GT);
     for (int step = 0; step < nb; ++step) {
-        m.Dinv = dinv[step & 1];
+        k_lg_diag<<<grid_for(m.T, 1), 512, 0, st>>>(m, step);
         ProbLgPanel pp; pp.m = m; pp.step = step;
         k_bgemm<ProbLgPanel><<<grid_for(m.T, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn);
         ProbLgUpdate pu; pu.m = m; pu.step = step;
-        if (step + 1 < nb) {
-            pu.part = 1;
-            k_bgemm<ProbLgUpdate><<<grid_for(m.T, tn * tn), 256, 0, st>>>(pu, m.T, tn, tn);
-            hipEventRecord(side.ev_a, st);
-            hipStreamWaitEvent(side.s, side.ev_a, 0);
-            LgMat mn = m; mn.Dinv = dinv[(step + 1) & 1];
-            k_lg_diag<<<grid_for(m.T, 1), 512, 0, side.s>>>(mn, step + 1);
-            hipEventRecord(side.ev_b, side.s);
-            pu.part = 2;
-            k_bgemm<ProbLgUpdate><<<grid_for(m.T, tn * tn), 256, 0, st>>>(pu, m.T, tn, tn);
-            hipStreamWaitEvent(st, side.ev_b, 0);
-        } else {
-            k_bgemm<ProbLgUpdate><<<grid_for(m.T, tn * tn), 256, 0, st>>>(pu, m.T, tn, tn);
-        }
+        k_bgemm<ProbLgUpdate><<<grid_for(m.T, tn * tn), 256, 0, st>>>(pu, m.T, tn, tn);
     }
 }
 

@@ -7,6 +7,8 @@
 //     ProbLgUpdate  M_RR -= C_R^T F_R (n x n, K = 128);  pivot-row / pivot-column / pivot-block tiles do no product,
 //                   their epilogue writes F_R, F_R^T and -Dinv
 //   after the last step M = -(A^-1).
+// (A look-ahead that factorises the next diagonal block on a side stream while the rest of the update runs was measured:
+//  the two event hand-offs per block step cost more than the overlap buys - C5 15.6 -> 17.4 ms, N = 256: 4.8 -> 5.3 ms.)
 //
 // One MLL evaluation = k_lg_build (kernel matrix from the squared distances) + the block steps + k_lg_matvec (alpha) +
 // k_lg_traces (the three O(N^2) reductions; also flips the sign in place) + k_lg_advance (value, gradient, and one
@@ -25,7 +27,7 @@ enum { PH_DONE = 4 };
 struct LgMat {
     float* M; int ld; const int32_t* n_arr;
     const FitShared* fit;   // null: every task is active
-    float* Dinv;            // [T, LB, LB] of the CURRENT block step (two buffers alternate: see lg_sweep's look-ahead)
+    float* Dinv;            // [T, LB, LB]
     float* Cbuf;            // [T, LB, ld]
     float* Fbuf;            // [T, LB, ld]
     float* logdet;          // [T] running log-determinant
@@ -101,7 +103,6 @@ struct ProbLgUpdate {
     static constexpr bool A_KCONTIG = false, B_KCONTIG = false;
     static constexpr int NRED = 0;
     LgMat m; int step;
-    int part = 0;   // 0: every tile;  1: only the tiles of the NEXT diagonal block;  2: every tile but those (look-ahead)
     int n, p0, nloc; const float *Dv, *Cb, *Fb; float* Mi; bool vec;
     __device__ bool setup(int t) {
         if (!m.active(t)) return false;
@@ -113,11 +114,6 @@ struct ProbLgUpdate {
     }
     __device__ int M() const { return n; } __device__ int N() const { return n; } __device__ int K() const { return nloc; }
     __device__ bool in_p(int i) const { return i >= p0 && i < p0 + LB; }
-    __device__ bool in_next(int i) const { return i >= p0 + LB && i < p0 + 2 * LB; }
-    __device__ bool active(int m0, int n0) const {
-        const bool nx = in_next(m0) && in_next(n0);
-        return part == 0 || (part == 1 ? nx : !nx);
-    }
     // M stays symmetric: only tiles on or above the diagonal are computed, their epilogue also writes the mirror image
     __device__ bool skip(int m0, int n0) const { return in_p(m0) || in_p(n0) || m0 > n0; }
     __device__ float a(int i, int k) const { return Cb[(size_t)k * m.ld + i]; }
