@@ -187,24 +187,50 @@ __global__ __launch_bounds__(SMALL_NT) void k_hess(HessArgs a) {
     float* de = a.vecs + ((size_t)t * NVEC + V_DELTA) * a.tv.vld;
     const int kind = a.tv.kind;
     // wave per row: beta_i = sum_j G_ij alpha_j ; gamma_i = sum_j Ainv_ij alpha_j
-    for (int i = wv; i < n; i += NW) {
-        float sb = 0.f, sg = 0.f;
+    // (four rows in flight per wave in both mat-vec passes: a row at a time is a chain of L2 round trips)
+    for (int i0 = wv; i0 < n; i0 += 4 * NW) {
+        float sb[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
         for (int j = lane; j < n; j += 64) {
-            float k0, k1, k2; const float u = D2[(size_t)i * ld + j] * il2; kappa3(kind, u, k0, k1, k2);
             const float aj = al[j];
-            sb += os * k1 * u * (-2.f / ls) * aj;
-            sg += Ai[(size_t)i * ld + j] * aj;
+            float d2v[4], av[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * NW;
+                d2v[q] = i < n ? D2[(size_t)i * ld + j] : 0.f;
+                av[q] = i < n ? Ai[(size_t)i * ld + j] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float k0, k1, k2; const float u = d2v[q] * il2; kappa3(kind, u, k0, k1, k2);
+                sb[q] += os * k1 * u * (-2.f / ls) * aj;
+                sg[q] += av[q] * aj;
+            }
         }
-        sb = wave_sum(sb); sg = wave_sum(sg);
-        if (lane == 0) { be[i] = sb; ga[i] = sg; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * NW;
+            const float b_ = wave_sum(sb[q]), g_ = wave_sum(sg[q]);
+            if (lane == 0 && i < n) { be[i] = b_; ga[i] = g_; }
+        }
     }
     __threadfence_block();
     __syncthreads();
-    for (int i = wv; i < n; i += NW) {
-        float sd = 0.f;
-        for (int j = lane; j < n; j += 64) sd += Ai[(size_t)i * ld + j] * be[j];
-        sd = wave_sum(sd);
-        if (lane == 0) de[i] = sd;
+    for (int i0 = wv; i0 < n; i0 += 4 * NW) {
+        float sd[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = lane; j < n; j += 64) {
+            const float bj = be[j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * NW;
+                if (i < n) sd[q] += Ai[(size_t)i * ld + j] * bj;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * NW;
+            const float d_ = wave_sum(sd[q]);
+            if (lane == 0 && i < n) de[i] = d_;
+        }
     }
     __threadfence_block();
     __syncthreads();
@@ -452,6 +478,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_rowsums(RowsumArgs a) {
     __syncthreads();
     for (int i = wv; i < n; i += NW) {
         float s = 0.f;
+#pragma unroll 4
         for (int j = lane; j < n; j += 64) s += Wss[(size_t)i * a.tv.ns_ld + j];
         s = wave_sum(s);
         if (lane == 0) {
