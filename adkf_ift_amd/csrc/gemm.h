@@ -25,6 +25,8 @@
 //   __device__ void  store_red(int tile, const float* red)   (only when NRED > 0; called by thread 0)
 //   __device__ bool  skip(int m0, int n0)        : OPTIONAL - true when the tile at (m0, n0) needs no product (its
 //                                                  epilogue still runs, with acc = 0)
+//   __device__ bool  active(int m0, int n0)      : OPTIONAL - false: the tile at (m0, n0) is not computed at all (e.g. the
+//                                                  lower tiles of a symmetric result, written by their mirror images)
 //   __device__ void  epi4(int i0, int j, const float (&acc)[4], float* red) : OPTIONAL - four consecutive rows of one
 //                                                  column at once (what one lane holds after the MFMA), all in range
 #pragma once
@@ -43,6 +45,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <class P, class = void> struct has_skip : std::false_type {};
 template <class P> struct has_skip<P, std::void_t<decltype(&P::skip)>> : std::true_type {};
+template <class P, class = void> struct has_active : std::false_type {};
+template <class P> struct has_active<P, std::void_t<decltype(&P::active)>> : std::true_type {};
 template <class P, class = void> struct has_epi4 : std::false_type {};
 template <class P> struct has_epi4<P, std::void_t<decltype(&P::epi4)>> : std::true_type {};
 
@@ -133,6 +137,9 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (has_active<P>::value) {
+        if (!p.active(m0, n0)) return;
+    }
     if constexpr (has_skip<P>::value) {
         if (p.skip(m0, n0)) K = 0;
     }

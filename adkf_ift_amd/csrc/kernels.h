@@ -72,10 +72,28 @@ struct ProbDist {
 #pragma unroll
         for (int x = 0; x < 4; ++x) v[x] -= m4[x];
     }
+    // symmetric (X == Y): only the tiles on or above the diagonal are computed; they also write their mirror image, so
+    // the result is EXACTLY symmetric
+    __device__ bool active(int m0, int n0) const { return !symmetric || m0 <= n0; }
+    __device__ float value(int i, int j, float acc) const {
+        const float v = fmaxf(nxi[i] + nyi[j] - 2.f * acc, 0.f);
+        return (symmetric && i == j) ? 0.f : v;
+    }
     __device__ void epi(int i, int j, float acc, float*) const {
-        float v = fmaxf(nxi[i] + nyi[j] - 2.f * acc, 0.f);
-        if (symmetric && i == j) v = 0.f;
+        const float v = value(i, j, acc);
         Do[(size_t)i * y_ld + j] = v;
+        if (symmetric && (i / GT) < (j / GT)) Do[(size_t)j * y_ld + i] = v;
+    }
+    __device__ void epi4(int i0, int j, const float (&acc)[4], float* red) const {   // mirror image as ONE 16-byte store
+        if (!(symmetric && vec && (i0 / GT) < (j / GT))) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) epi(i0 + r, j, acc[r], red);
+            return;
+        }
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = value(i0 + r, j, acc[r]); Do[(size_t)(i0 + r) * y_ld + j] = v[r]; }
+        *reinterpret_cast<float4*>(Do + (size_t)j * y_ld + i0) = make_float4(v[0], v[1], v[2], v[3]);
     }
     __device__ void store_red(int, const float*) const {}
 };

@@ -102,8 +102,26 @@ struct ProbS {
 #pragma unroll
         for (int x = 0; x < 4; ++x) v[x] = os * kappa0(tv.kind, v[x] * il2);
     }
+    // S is symmetric: tiles below the diagonal are written by their mirror images (exactly symmetric result)
+    __device__ bool active(int m0, int n0) const { return m0 <= n0; }
+    __device__ float value(int i, int j, float acc) const {
+        return os * kappa0(tv.kind, Dqq[(size_t)i * tv.nq_ld + j] * il2) - acc + (i == j ? noise : 0.f);
+    }
     __device__ void epi(int i, int j, float acc, float*) const {
-        So[(size_t)i * tv.nq_ld + j] = os * kappa0(tv.kind, Dqq[(size_t)i * tv.nq_ld + j] * il2) - acc + (i == j ? noise : 0.f);
+        const float v = value(i, j, acc);
+        So[(size_t)i * tv.nq_ld + j] = v;
+        if ((i / GT) < (j / GT)) So[(size_t)j * tv.nq_ld + i] = v;
+    }
+    __device__ void epi4(int i0, int j, const float (&acc)[4], float* red) const {
+        if (!(vec && (i0 / GT) < (j / GT))) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) epi(i0 + r, j, acc[r], red);
+            return;
+        }
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = value(i0 + r, j, acc[r]); So[(size_t)(i0 + r) * tv.nq_ld + j] = v[r]; }
+        *reinterpret_cast<float4*>(So + (size_t)j * tv.nq_ld + i0) = make_float4(v[0], v[1], v[2], v[3]);
     }
     __device__ void store_red(int, const float*) const {}
 };
