@@ -138,7 +138,14 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
         for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if constexpr (has_active<P>::value) {
-        if (!p.active(m0, n0)) return;
+        if (!p.active(m0, n0)) {   // not computed here: contributes zero partials
+            if (P::NRED > 0 && threadIdx.x == 0) {
+                float z[(P::NRED > 0 ? P::NRED : 1)];
+                for (int q = 0; q < (P::NRED > 0 ? P::NRED : 1); ++q) z[q] = 0.f;
+                p.store_red(tile, z);
+            }
+            return;
+        }
     }
     if constexpr (has_skip<P>::value) {
         if (p.skip(m0, n0)) K = 0;
