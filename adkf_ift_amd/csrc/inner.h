@@ -60,8 +60,7 @@ struct D2Block {
     }
     __device__ __forceinline__ float fetch(int r, int c) const {
         const int i = SW::row(r), j = SW::col(c);
-        const int hi = i > j ? i : j, lo = i > j ? j : i;  // exactly symmetric input to the sweep
-        return (i < n && j < n) ? base[(size_t)hi * ld + lo] : 0.f;
+        return (i < n && j < n) ? base[(size_t)i * ld + j] : 0.f;  // exactly symmetric by construction (ProbDist mirrors its tiles)
     }
     __device__ __forceinline__ float get(int r, int c) const {
         if constexpr (REGS) return reg[r][c];

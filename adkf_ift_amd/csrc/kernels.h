@@ -307,15 +307,14 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
             if (lane == 0 && i < m) { vbase[V_MU * a.tv.vld + i] = t_; sm.vec_in[i] = yq[i] - t_; }
         }
     }
-    // this thread's block of S, symmetrised from the lower triangle, identity-padded
+    // this thread's block of S (exactly symmetric by construction), identity-padded
     float mm[RB][CB];
 #pragma unroll
     for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
             const int i = SW::row(r), j = j0 + c;
-            const int hi = i > j ? i : j, lo = i > j ? j : i;
-            mm[r][c] = (i < m && j < m) ? Si[(size_t)hi * a.tv.nq_ld + lo] : (i == j ? 1.f : 0.f);
+            mm[r][c] = (i < m && j < m) ? Si[(size_t)i * a.tv.nq_ld + j] : (i == j ? 1.f : 0.f);   // ProbS mirrors its tiles
         }
     __syncthreads();
     SW::run(mm, m, sm);
