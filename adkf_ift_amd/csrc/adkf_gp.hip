@@ -190,6 +190,42 @@ void lg_sweep(const LgMat& m, hipStream_t st) {
     }
 }
 
+// Convergence-mode early exit for the fits that are a sequence of launches (blocked path, ARD): every POLL_EVERY
+// evaluations the number of unfinished tasks goes to pinned host memory and the stream is synchronised, so a fit that
+// converges after 15 evaluations does not enqueue the other 185 rounds of (skipped) kernels.  Never in exact-evals mode
+// (deterministic work, no synchronisation) and never while the stream is being captured into a graph.
+constexpr int POLL_EVERY = 8;
+
+__global__ void k_count_unfinished(const char* base, size_t stride, size_t phase_offset, int T, int32_t* out) {
+    int c = 0;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) c += *reinterpret_cast<const int*>(base + (size_t)t * stride + phase_offset) != PH_DONE;
+    c = wave_sum_i(c);
+    if (threadIdx.x == 0) *out = c;
+}
+
+struct FitPoll {
+    bool enabled = false;
+    int32_t* host = nullptr;
+    int32_t* dev;
+    FitPoll(bool convergence_mode, int max_evals, int32_t* dev_counter, hipStream_t st) : dev(dev_counter) {
+        if (!convergence_mode || max_evals <= 2 * POLL_EVERY) return;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+        thread_local int32_t* pinned = nullptr;
+        if (!pinned && hipHostMalloc(reinterpret_cast<void**>(&pinned), sizeof(int32_t), hipHostMallocDefault) != hipSuccess) return;
+        host = pinned;
+        enabled = true;
+    }
+    // true when every task has finished (call after the advance kernel of evaluation e)
+    bool finished(int e, const void* state, size_t stride, size_t phase_offset, int T, hipStream_t st) {
+        if (!enabled || (e + 1) % POLL_EVERY != 0) return false;
+        k_count_unfinished<<<1, 64, 0, st>>>(static_cast<const char*>(state), stride, phase_offset, T, dev);
+        if (hipMemcpyAsync(host, dev, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+        if (hipStreamSynchronize(st) != hipSuccess) return false;
+        return *host == 0;
+    }
+};
+
 int launch_inner_large(const InnerArgs& a, const Workspace& w, hipStream_t st) {
     LgInner li;
     li.in = a; li.fit = w.lg_fit; li.part = w.lg_part;
@@ -198,12 +234,14 @@ int launch_inner_large(const InnerArgs& a, const Workspace& w, hipStream_t st) {
     LgMatvecArgs mv{li.mat, a.y_s, (size_t)a.ld, a.vecs + (size_t)V_ALPHA * a.vld, (size_t)NVEC * a.vld, -1.f};
     k_lg_begin<<<ceil_div(a.T, 64), 64, 0, st>>>(li);
     const int n_evals = a.max_evals > 0 ? a.max_evals : 1;
+    FitPoll poll(a.max_evals > 0 && !a.exact_evals, a.max_evals, w.lg_info, st);   // lg_info[0] is free between block sweeps
     for (int e = 0; e < n_evals; ++e) {
         k_lg_build<<<grid_for(a.T, li.ntiles), 256, 0, st>>>(li);
         lg_sweep(li.mat, st);
         k_lg_matvec<<<dim3(ceil_div(a.ld, 4), a.T), 256, 0, st>>>(mv);
         k_lg_traces<<<grid_for(a.T, li.ntiles), 256, 0, st>>>(li);
         k_lg_advance<<<a.T, 64, 0, st>>>(li);
+        if (poll.finished(e, w.lg_fit, sizeof(FitShared), offsetof(FitShared, phase), a.T, st)) break;
     }
     LAUNCH_OK();
     return 0;
@@ -491,10 +529,12 @@ int ard_fit(const adkf_batch_t* b, float* phi, const adkf_fit_options_t* opt, fl
     fa.fe = c.a.fe; fa.info_eval = c.a.info3; fa.phi = phi; fa.f_final = f_final; fa.gnorm = gnorm; fa.nevals = n_evals; fa.info = info;
     k_ard_fit_begin<<<dim3(ceil_div(c.h, 256), c.T), 256, 0, st>>>(fa);
     if (opt->ev_start && hipEventRecord(static_cast<hipEvent_t>(opt->ev_start), st) != hipSuccess) return ADKF_E_LAUNCH;
+    FitPoll poll(!opt->exact_evals, opt->max_evals, c.a.n_eff, st);   // n_eff[0] is only used by the CG of the hypergradient
     for (int e = 0; e < opt->max_evals; ++e) {
         rc = ard_eval(c, c.a.xe, c.a.fe, c.a.ge, c.a.info3);
         if (rc) return rc;
         k_ard_advance<<<c.T, 256, 0, st>>>(fa);
+        if (poll.finished(e, c.a.fst, sizeof(ArdFitState), offsetof(ArdFitState, phase), c.T, st)) break;
     }
     if (opt->ev_stop && hipEventRecord(static_cast<hipEvent_t>(opt->ev_stop), st) != hipSuccess) return ADKF_E_LAUNCH;
     LAUNCH_OK();

@@ -125,7 +125,11 @@ int adkf_mll_value_grad(const adkf_batch_t* b, const float* phi, float* f_in, fl
 
 /* a7: botorch.optim.fit.fit_gpytorch_scipy(model.mll) (fs_mol/utils/adaptive_dkt_utils.py:91): minimise
  * f_inner over phi, all tasks at once, on the device (quasi-Newton with the exact analytic gradient).
- * phi [T,3] in/out; f_final [T], gnorm [T] (max|grad| at the result), n_evals [T] are nullable. */
+ * phi [T,3] in/out ([T, 2 + d] for ARD batches); f_final [T], gnorm [T] (max|grad| at the result), n_evals [T] are
+ * nullable.  Up to 128 support points the whole optimisation is ONE kernel launch.  Larger sets and ARD batches are a
+ * sequence of launches per evaluation; there, in convergence mode (exact_evals == 0, max_evals > 16) and outside
+ * stream capture, the call synchronises the stream every 8 evaluations to stop enqueueing once every task has
+ * finished - with exact_evals != 0 nothing is ever synchronised. */
 int adkf_fit(const adkf_batch_t* b, float* phi, const adkf_fit_options_t* opt, float* f_final, float* gnorm,
              int32_t* n_evals, int32_t* info, void* ws, size_t ws_bytes, void* stream);
 
