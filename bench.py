@@ -26,8 +26,8 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tasks", type=int, default=256, help="tasks per GPU per step (weak scaling)")
     ap.add_argument("--n-support", type=int, default=128)
     ap.add_argument("--n-query", type=int, default=128)
