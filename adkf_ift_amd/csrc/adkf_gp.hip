@@ -5,6 +5,7 @@
 
 #include "../../include/adkf_gp.h"
 #include "ard.h"
+#include "pna.h"
 
 using namespace adkf;
 
@@ -836,6 +837,26 @@ int adkf_ift_hypergrad_cg(const adkf_batch_t* b, const float* phi, int32_t flags
     if (!phi || !f_out || !dZ_s || !dZ_q || !info || !ws || !b->y_s || !b->y_q || !b->priors) return ADKF_E_BADARG;
     return ard_ift(b, phi, flags, true, cg_maxiter, cg_tol, f_out, dZ_s, dZ_q, g_phi_out, v, cg_iters, info, ws, ws_bytes,
                    static_cast<hipStream_t>(stream));
+}
+
+int adkf_pna_aggregate(const float* msgs, const int64_t* perm, const int64_t* rowptr, int32_t V, int32_t H, int32_t m, float* agg,
+                       int32_t* argmax, void* stream) {
+    (void)hipGetLastError();
+    if (!msgs || !perm || !rowptr || !agg || !argmax || V <= 0 || H <= 0 || m <= 0) return ADKF_E_BADARG;
+    PnaArgs a{msgs, perm, rowptr, agg, argmax, nullptr, nullptr, V, H, m};
+    k_pna_fwd<<<V, 256, 0, static_cast<hipStream_t>(stream)>>>(a);
+    LAUNCH_OK();
+    return 0;
+}
+
+int adkf_pna_aggregate_backward(const float* msgs, const int64_t* perm, const int64_t* rowptr, const float* agg, const int32_t* argmax,
+                                const float* d_agg, int32_t V, int32_t H, int32_t m, float* d_msgs, void* stream) {
+    (void)hipGetLastError();
+    if (!msgs || !perm || !rowptr || !agg || !argmax || !d_agg || !d_msgs || V <= 0 || H <= 0 || m <= 0) return ADKF_E_BADARG;
+    PnaArgs a{msgs, perm, rowptr, const_cast<float*>(agg), const_cast<int32_t*>(argmax), d_agg, d_msgs, V, H, m};
+    k_pna_bwd<<<V, 256, 0, static_cast<hipStream_t>(stream)>>>(a);
+    LAUNCH_OK();
+    return 0;
 }
 
 int adkf_check_info(const int32_t* info, int32_t T, void* stream) {

@@ -109,8 +109,12 @@ class _GraphPlan:
         self.tgts = [a[:, 1] for a in adjacency_lists]
         self.all_tgts = torch.cat(self.tgts) if self.tgts else torch.zeros(0, dtype=torch.long)
         self.num_nodes = num_nodes
-        deg = torch.bincount(self.all_tgts, minlength=num_nodes).to(dtype)
+        counts = torch.bincount(self.all_tgts, minlength=num_nodes)
+        deg = counts.to(dtype)
         self.inv_count = 1.0 / deg.clamp(min=1.0)                      # scatter_mean: empty segment -> 0
+        # segments of the concatenated message list by target node, for the fused aggregation kernel (csrc/pna.h)
+        self.perm = torch.argsort(self.all_tgts, stable=True)
+        self.rowptr = torch.cat((counts.new_zeros(1), torch.cumsum(counts, 0)))
         if pna:
             log_deg = torch.log(deg + 1.0)
             self.amplify = (log_deg / PNA_DELTA).unsqueeze(-1)                      # gnn.py:241
@@ -166,6 +170,14 @@ class TowerMessagePassing(nn.Module):
         tg = plan.all_tgts
         if self.kind == "plain":
             return x.new_zeros(V, H, m).index_add_(0, tg, msgs).reshape(V, -1)
+        if msgs.is_cuda and msgs.dtype == torch.float32:
+            # one HIP kernel for sum | mean | std | max (and one for their backward) instead of the ~15 (~30) element-wise,
+            # index and scatter launches below per layer; no fallback on the GPU: a missing library raises
+            agg = _PNAAggregate.apply(msgs.contiguous(), plan.perm, plan.rowptr, V)
+            if self.kind == "pna":
+                amp, att = plan.amplify.unsqueeze(-1).to(x.dtype), plan.attenuate.unsqueeze(-1).to(x.dtype)
+                agg = torch.cat((agg, amp * agg, att * agg), dim=2)
+            return agg.reshape(V, -1)
         s_sum = x.new_zeros(V, H, m).index_add_(0, tg, msgs[..., :m])
         mean_msgs = msgs[..., m:2 * m]
         s_mean = x.new_zeros(V, H, m).index_add_(0, tg, mean_msgs) * plan.inv_count.view(V, 1, 1).to(x.dtype)
@@ -178,6 +190,42 @@ class TowerMessagePassing(nn.Module):
             amp, att = plan.amplify.unsqueeze(-1).to(x.dtype), plan.attenuate.unsqueeze(-1).to(x.dtype)
             agg = torch.cat((agg, amp * agg, att * agg), dim=2)                # gnn.py:244-251
         return agg.reshape(V, -1)
+
+
+class _PNAAggregate(torch.autograd.Function):
+    """[E, H, 3m] messages -> [V, H, 4m] (sum | mean | std | max) through ``adkf_pna_aggregate`` (csrc/pna.h)."""
+
+    @staticmethod
+    def forward(ctx, msgs, perm, rowptr, V):
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        E, H, m3 = msgs.shape
+        m = m3 // 3
+        agg = torch.empty(V, H, 4 * m, dtype=torch.float32, device=msgs.device)
+        argmax = torch.empty(V, H, m, dtype=torch.int32, device=msgs.device)
+        st = C.c_void_p(torch.cuda.current_stream(msgs.device).cuda_stream)
+        _lib.check(lib.adkf_pna_aggregate(C.c_void_p(msgs.data_ptr()), C.c_void_p(perm.data_ptr()), C.c_void_p(rowptr.data_ptr()),
+                                          V, H, m, C.c_void_p(agg.data_ptr()), C.c_void_p(argmax.data_ptr()), st), "adkf_pna_aggregate")
+        ctx.save_for_backward(msgs, perm, rowptr, agg, argmax)
+        return agg
+
+    @staticmethod
+    def backward(ctx, d_agg):
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        msgs, perm, rowptr, agg, argmax = ctx.saved_tensors
+        V, H, m4 = agg.shape
+        d_agg = d_agg.contiguous()
+        d_msgs = torch.empty_like(msgs)
+        st = C.c_void_p(torch.cuda.current_stream(msgs.device).cuda_stream)
+        _lib.check(lib.adkf_pna_aggregate_backward(C.c_void_p(msgs.data_ptr()), C.c_void_p(perm.data_ptr()), C.c_void_p(rowptr.data_ptr()),
+                                                   C.c_void_p(agg.data_ptr()), C.c_void_p(argmax.data_ptr()), C.c_void_p(d_agg.data_ptr()),
+                                                   V, H, m4 // 4, C.c_void_p(d_msgs.data_ptr()), st), "adkf_pna_aggregate_backward")
+        return d_msgs, None, None, None
 
 
 class BOOMLayer(nn.Module):

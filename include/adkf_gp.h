@@ -164,6 +164,17 @@ int adkf_ift_hypergrad_cg(const adkf_batch_t* b, const float* phi, int32_t flags
                           float* f_out, float* dZ_s, float* dZ_q, float* g_phi_out, float* v, int32_t* cg_iters,
                           int32_t* info, void* ws, size_t ws_bytes, void* stream);
 
+/* a1 (aggregation inside RelationalMultiAggrMP._aggregate_messages, fs_mol/modules/gnn.py:197-265; torch_scatter's
+ * scatter_sum / scatter_mean / scatter_max there): SUM | MEAN | STD | MAX of the incoming messages of every target
+ * node in one pass.  msgs [E, H, 3m] post-ReLU messages (per tower: sum-part | mean/std-part | max-part), perm [E] the
+ * message ids sorted by target, rowptr [V+1]; agg [V, H, 4m], argmax [V, H, m] (message id of the maximum, -1 for an
+ * empty segment, whose aggregates are 0).  The backward writes every element of d_msgs [E, H, 3m] exactly once. */
+int adkf_pna_aggregate(const float* msgs, const int64_t* perm, const int64_t* rowptr, int32_t V, int32_t H, int32_t m,
+                       float* agg, int32_t* argmax, void* stream);
+int adkf_pna_aggregate_backward(const float* msgs, const int64_t* perm, const int64_t* rowptr, const float* agg,
+                                const int32_t* argmax, const float* d_agg, int32_t V, int32_t H, int32_t m,
+                                float* d_msgs, void* stream);
+
 /* Synchronises `stream`, then returns 0 or (index+1) of the first task with info != 0. */
 int adkf_check_info(const int32_t* info, int32_t T, void* stream);
 

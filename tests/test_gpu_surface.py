@@ -365,3 +365,38 @@ def test_graph_replay_equals_eager(dev):
         for a, b, name in zip(got, want, ("phi", "f_out", "dZ_s", "dZ_q", "info_fit", "info")):
             assert torch.equal(a, b), name
     assert len(graphed._graphs) == 1
+
+
+@pytest.mark.parametrize("kind", ["PNA", "MultiAggr"])
+def test_fused_pna_aggregation_equals_torch_path(dev, kind):
+    """csrc/pna.h: the fused sum | mean | std | max aggregation (forward and backward) against the index_add /
+    scatter_reduce formulation it replaces (which tests/test_gnn.py pins to the naive restatement of the reference):
+    same extractor, float32 on the GPU (fused) vs float64 on the CPU (PyTorch ops)."""
+    from adkf_ift_amd.gnn import GNNConfig, GraphFeatureExtractor, GraphFeatureExtractorConfig, GraphReadoutConfig
+    from test_gnn import random_graphs
+
+    torch.manual_seed(0)
+    cfg = GraphFeatureExtractorConfig(gnn_config=GNNConfig(type=kind, hidden_dim=16, num_heads=4, per_head_dim=6, intermediate_dim=24,
+                                                          num_layers=3),
+                                      readout_config=GraphReadoutConfig(num_heads=3, head_dim=5, output_dim=10))
+    ref = GraphFeatureExtractor(cfg).double()
+    with torch.no_grad():
+        for blk in ref.gnn.gnn_blocks:
+            blk.alpha.fill_(0.6)
+    gpu = GraphFeatureExtractor(cfg).to(dev)
+    gpu.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    batch = random_graphs(9, seed=4, empty_type=1)      # isolated nodes, a single-atom graph, an empty edge type
+    out_ref = ref(batch)
+    b32 = batch.to(dev)
+    b32.node_features = b32.node_features.float()
+    out = gpu(b32)
+    assert (out.double().cpu() - out_ref).abs().max().item() <= 2e-5 * out_ref.abs().max().item()
+    w = torch.randn(out_ref.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    (out_ref * w).sum().backward()
+    (out * w.float().to(dev)).sum().backward()
+    scale = max(p.grad.abs().max().item() for n, p in ref.named_parameters() if p.grad is not None)
+    for (n, p), (_, q) in zip(ref.named_parameters(), gpu.named_parameters()):
+        if p.grad is None:
+            assert q.grad is None, n
+            continue
+        assert (q.grad.double().cpu() - p.grad).abs().max().item() <= 2e-4 * scale, n
