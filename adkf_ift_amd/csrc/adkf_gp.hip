@@ -839,6 +839,38 @@ int adkf_ift_hypergrad_cg(const adkf_batch_t* b, const float* phi, int32_t flags
                    static_cast<hipStream_t>(stream));
 }
 
+int adkf_msg_forward(const float* x, const int64_t* src, const int64_t* tgt, const float* W, const float* bias, int32_t E, int32_t H,
+                     int32_t in, int32_t out, int64_t e_off, float* msgs, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !W || !bias || !msgs || E < 0 || H <= 0 || in <= 0 || out <= 0 || (E > 0 && (!src || !tgt))) return ADKF_E_BADARG;
+    if (E == 0) return 0;
+    MsgArgs m{};
+    m.x = x; m.src = src; m.tgt = tgt; m.W = W; m.bias = bias; m.msgs = msgs; m.E = E; m.H = H; m.in = in; m.out = out; m.e_off = e_off;
+    m.vec = (in % 4 == 0) && (out % 4 == 0) && aligned16(x) && aligned16(W) && aligned16(msgs);
+    ProbMsgFwd p; p.m = m;
+    launch_gemm(p, H, E, out, static_cast<hipStream_t>(stream));
+    LAUNCH_OK();
+    return 0;
+}
+
+int adkf_msg_backward(const float* x, const int64_t* src, const int64_t* tgt, const float* W, const float* msgs, const float* d_msgs,
+                      int32_t E, int32_t H, int32_t in, int32_t out, int64_t e_off, float* dx, float* dW, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !W || !msgs || !d_msgs || !dx || !dW || E < 0 || H <= 0 || in <= 0 || out <= 0 || (E > 0 && (!src || !tgt))) return ADKF_E_BADARG;
+    if (E == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MsgArgs m{};
+    m.x = x; m.src = src; m.tgt = tgt; m.W = W; m.msgs = const_cast<float*>(msgs); m.d_msgs = d_msgs; m.dx = dx; m.dW = dW;
+    m.E = E; m.H = H; m.in = in; m.out = out; m.e_off = e_off; m.chunk = 512;
+    m.vec = (in % 4 == 0) && (out % 4 == 0) && aligned16(x) && aligned16(W) && aligned16(msgs) && aligned16(d_msgs);
+    ProbMsgBwdX px; px.m = m;
+    launch_gemm(px, H, E, 2 * in, st);
+    ProbMsgBwdW pw; pw.m = m; pw.nsplit = ceil_div(E, m.chunk);
+    launch_gemm(pw, H * pw.nsplit, 2 * in, out, st);
+    LAUNCH_OK();
+    return 0;
+}
+
 int adkf_pna_aggregate(const float* msgs, const int64_t* perm, const int64_t* rowptr, int32_t V, int32_t H, int32_t m, float* agg,
                        int32_t* argmax, void* stream) {
     (void)hipGetLastError();

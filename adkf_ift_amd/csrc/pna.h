@@ -88,3 +88,107 @@ __global__ __launch_bounds__(256) void k_pna_bwd(PnaArgs a) {
 }
 
 }  // namespace adkf
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Message functions of one edge type for all towers (fs_mol/modules/gnn.py:95-148, depth-1 message MLP):
+//     msgs[e, h, :] = relu( cat(x[src_e, h, :], x[tgt_e, h, :]) W[h] + b[h] )
+// as ONE batched MFMA GEMM whose A operand is gathered on the fly (no [E, H, 2 in] concatenation, no separate bias /
+// ReLU passes), and the two backward products with the ReLU mask fused into their operand loads:
+//     d x[src_e / tgt_e, h, :] += (d msgs . [msgs > 0]) W[h]^T          (atomic scatter-add in the epilogue)
+//     d W[h] += cat(x)^T (d msgs . [msgs > 0])                          (split over chunks of edges, atomic accumulate)
+// "task" of k_bgemm = tower (forward, d x) or (tower, edge chunk) (d W).
+// ---------------------------------------------------------------------------------------------------------------------
+#include "problems.h"
+namespace adkf {
+
+struct MsgArgs {
+    const float* x;            // [V, H, in]
+    const int64_t *src, *tgt;  // [E]
+    const float* W;            // [H, 2 in, out]
+    const float* bias;         // [H, out]
+    float* msgs;               // [E_all, H, out] (this edge type starts at row e_off)
+    const float* d_msgs;       // backward
+    float* dx;                 // [V, H, in]   (zero-initialised by the caller, accumulated atomically)
+    float* dW;                 // [H, 2 in, out]
+    int E, H, in, out, chunk;  // chunk: edges per split of the d W product
+    int64_t e_off;
+    bool vec;
+};
+
+struct ProbMsgFwd {
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = false;
+    static constexpr int NRED = 0;
+    MsgArgs m; int h; bool vec;
+    __device__ bool setup(int t) { h = t; vec = m.vec; return m.E > 0; }
+    __device__ int M() const { return m.E; } __device__ int N() const { return m.out; } __device__ int K() const { return 2 * m.in; }
+    __device__ const float* arow(int i, int k) const {
+        const int64_t node = k < m.in ? m.src[i] : m.tgt[i];
+        return m.x + ((size_t)node * m.H + h) * m.in + (k < m.in ? k : k - m.in);
+    }
+    __device__ float a(int i, int k) const { return *arow(i, k); }
+    __device__ float b(int k, int j) const { return m.W[((size_t)h * 2 * m.in + k) * m.out + j]; }
+    __device__ void a4(int i, int k, float (&v)[4]) const { ld4(arow(i, k), v); }   // in % 4 == 0: a group never straddles the halves
+    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(m.W + ((size_t)h * 2 * m.in + k) * m.out + j, v); }
+    __device__ void epi(int i, int j, float acc, float*) const {
+        m.msgs[((size_t)(m.e_off + i) * m.H + h) * m.out + j] = fmaxf(acc + m.bias[h * m.out + j], 0.f);
+    }
+    __device__ void store_red(int, const float*) const {}
+};
+
+struct ProbMsgBwdX {
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
+    static constexpr int NRED = 0;
+    MsgArgs m; int h; bool vec;
+    __device__ bool setup(int t) { h = t; vec = m.vec; return m.E > 0; }
+    __device__ int M() const { return m.E; } __device__ int N() const { return 2 * m.in; } __device__ int K() const { return m.out; }
+    __device__ float a(int i, int k) const {
+        const size_t o = ((size_t)(m.e_off + i) * m.H + h) * m.out + k;
+        return m.msgs[o] > 0.f ? m.d_msgs[o] : 0.f;
+    }
+    __device__ float b(int k, int j) const { return m.W[((size_t)h * 2 * m.in + j) * m.out + k]; }
+    __device__ void a4(int i, int k, float (&v)[4]) const {
+        const size_t o = ((size_t)(m.e_off + i) * m.H + h) * m.out + k;
+        float ms[4];
+        ld4(m.d_msgs + o, v); ld4(m.msgs + o, ms);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ms[q] > 0.f ? v[q] : 0.f;
+    }
+    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(m.W + ((size_t)h * 2 * m.in + j) * m.out + k, v); }
+    __device__ void epi(int i, int j, float acc, float*) const {
+        const int64_t node = j < m.in ? m.src[i] : m.tgt[i];
+        atomicAdd(m.dx + ((size_t)node * m.H + h) * m.in + (j < m.in ? j : j - m.in), acc);
+    }
+    __device__ void store_red(int, const float*) const {}
+};
+
+struct ProbMsgBwdW {
+    static constexpr bool A_KCONTIG = false, B_KCONTIG = false;
+    static constexpr int NRED = 0;
+    MsgArgs m; int nsplit; int h, e0, len; bool vec;
+    __device__ bool setup(int t) {
+        h = t / nsplit; e0 = (t % nsplit) * m.chunk; len = min(m.chunk, m.E - e0); vec = m.vec;
+        return len > 0;
+    }
+    __device__ int M() const { return 2 * m.in; } __device__ int N() const { return m.out; } __device__ int K() const { return len; }
+    __device__ const float* arow(int i, int k) const {
+        const int64_t node = i < m.in ? m.src[e0 + k] : m.tgt[e0 + k];
+        return m.x + ((size_t)node * m.H + h) * m.in + (i < m.in ? i : i - m.in);
+    }
+    __device__ float a(int i, int k) const { return *arow(i, k); }
+    __device__ float b(int k, int j) const {
+        const size_t o = ((size_t)(m.e_off + e0 + k) * m.H + h) * m.out + j;
+        return m.msgs[o] > 0.f ? m.d_msgs[o] : 0.f;
+    }
+    __device__ void a4(int i, int k, float (&v)[4]) const { ld4(arow(i, k), v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const {
+        const size_t o = ((size_t)(m.e_off + e0 + k) * m.H + h) * m.out + j;
+        float ms[4];
+        ld4(m.d_msgs + o, v); ld4(m.msgs + o, ms);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ms[q] > 0.f ? v[q] : 0.f;
+    }
+    __device__ void epi(int i, int j, float acc, float*) const { atomicAdd(m.dW + ((size_t)h * 2 * m.in + i) * m.out + j, acc); }
+    __device__ void store_red(int, const float*) const {}
+};
+
+}  // namespace adkf

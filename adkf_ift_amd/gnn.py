@@ -105,8 +105,8 @@ class _GraphPlan:
                  dtype: torch.dtype = torch.float32):
         if bidirectional:  # fs_mol/modules/gnn.py:540-544
             adjacency_lists = [torch.cat((a, a.flip(1)), dim=0) for a in adjacency_lists]
-        self.srcs = [a[:, 0] for a in adjacency_lists]
-        self.tgts = [a[:, 1] for a in adjacency_lists]
+        self.srcs = [a[:, 0].contiguous() for a in adjacency_lists]   # contiguous: the HIP kernels index them directly
+        self.tgts = [a[:, 1].contiguous() for a in adjacency_lists]
         self.all_tgts = torch.cat(self.tgts) if self.tgts else torch.zeros(0, dtype=torch.long)
         self.num_nodes = num_nodes
         counts = torch.bincount(self.all_tgts, minlength=num_nodes)
@@ -157,6 +157,15 @@ class TowerMessagePassing(nn.Module):
     def forward(self, x: torch.Tensor, plan: _GraphPlan) -> torch.Tensor:
         V, H, m = x.shape[0], self.H, self.msg
         xt = x.view(V, H, self.in_dim)
+        if x.is_cuda and x.dtype == torch.float32 and self.depth == 1 and self.kind != "plain":
+            # GPU fast path (csrc/pna.h): per edge type ONE batched MFMA GEMM that gathers source / target states on the fly
+            # and applies bias + ReLU in its epilogue, then ONE aggregation kernel; no fallback here - a missing library raises
+            msgs = _MessageFunction.apply(x.contiguous(), plan, H, self.in_dim, self.out_msg, *self.weights, *self.biases)
+            agg = _PNAAggregate.apply(msgs, plan.perm, plan.rowptr, V)
+            if self.kind == "pna":
+                amp, att = plan.amplify.unsqueeze(-1).to(x.dtype), plan.attenuate.unsqueeze(-1).to(x.dtype)
+                agg = torch.cat((agg, amp * agg, att * agg), dim=2)
+            return agg.reshape(V, -1)
         msgs = []
         for et in range(len(plan.srcs)):
             h = torch.cat((xt[plan.srcs[et]], xt[plan.tgts[et]]), dim=2)       # [E, H, 2 in]
@@ -190,6 +199,59 @@ class TowerMessagePassing(nn.Module):
             amp, att = plan.amplify.unsqueeze(-1).to(x.dtype), plan.attenuate.unsqueeze(-1).to(x.dtype)
             agg = torch.cat((agg, amp * agg, att * agg), dim=2)                # gnn.py:244-251
         return agg.reshape(V, -1)
+
+
+class _MessageFunction(torch.autograd.Function):
+    """relu(cat(x[src], x[tgt]) W_et + b_et) for every edge type and tower -> [E_all, H, out] (``adkf_msg_forward`` /
+    ``adkf_msg_backward``, csrc/pna.h).  x [V, H*in] float32 contiguous; weights[et] [H, 2 in, out], biases[et] [H, out]."""
+
+    @staticmethod
+    def forward(ctx, x, plan, H, in_dim, out_dim, *params):
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        n_et = len(params) // 2
+        weights, biases = params[:n_et], params[n_et:]
+        E_all = int(plan.all_tgts.shape[0])
+        msgs = torch.empty(E_all, H, out_dim, dtype=torch.float32, device=x.device)
+        st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        off = 0
+        for et in range(n_et):
+            E = int(plan.srcs[et].shape[0])
+            w, b = weights[et].contiguous(), biases[et].contiguous()
+            _lib.check(lib.adkf_msg_forward(C.c_void_p(x.data_ptr()), C.c_void_p(plan.srcs[et].data_ptr()), C.c_void_p(plan.tgts[et].data_ptr()),
+                                            C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), E, H, in_dim, out_dim, off,
+                                            C.c_void_p(msgs.data_ptr()), st), "adkf_msg_forward")
+            off += E
+        ctx.save_for_backward(x, msgs, *weights)
+        ctx.plan, ctx.dims, ctx.n_et = plan, (H, in_dim, out_dim), n_et
+        return msgs
+
+    @staticmethod
+    def backward(ctx, d_msgs):
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        x, msgs, *weights = ctx.saved_tensors
+        plan, (H, in_dim, out_dim), n_et = ctx.plan, ctx.dims, ctx.n_et
+        d_msgs = d_msgs.contiguous()
+        dx = torch.zeros_like(x)
+        st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        dWs, dbs, off = [], [], 0
+        for et in range(n_et):
+            E = int(plan.srcs[et].shape[0])
+            w = weights[et].contiguous()
+            dW = torch.zeros_like(w)
+            _lib.check(lib.adkf_msg_backward(C.c_void_p(x.data_ptr()), C.c_void_p(plan.srcs[et].data_ptr()), C.c_void_p(plan.tgts[et].data_ptr()),
+                                             C.c_void_p(w.data_ptr()), C.c_void_p(msgs.data_ptr()), C.c_void_p(d_msgs.data_ptr()), E, H, in_dim,
+                                             out_dim, off, C.c_void_p(dx.data_ptr()), C.c_void_p(dW.data_ptr()), st), "adkf_msg_backward")
+            sl = slice(off, off + E)
+            dbs.append((d_msgs[sl] * (msgs[sl] > 0)).sum(0))
+            dWs.append(dW)
+            off += E
+        return (dx, None, None, None, None, *dWs, *dbs)
 
 
 class _PNAAggregate(torch.autograd.Function):

@@ -164,6 +164,17 @@ int adkf_ift_hypergrad_cg(const adkf_batch_t* b, const float* phi, int32_t flags
                           float* f_out, float* dZ_s, float* dZ_q, float* g_phi_out, float* v, int32_t* cg_iters,
                           int32_t* info, void* ws, size_t ws_bytes, void* stream);
 
+/* a1 (message functions of RelationalMP, fs_mol/modules/gnn.py:95-148, for the default depth-1 message MLP): all towers of
+ * one edge type in one batched GEMM with the source / target node states gathered on the fly:
+ *   msgs[e_off + e, h, :] = relu(cat(x[src_e, h, :], x[tgt_e, h, :]) W[h] + bias[h]),
+ * x [V, H, in], W [H, 2 in, out], bias [H, out], msgs [E_all, H, out].  The backward accumulates ATOMICALLY into dx
+ * [V, H, in] and dW [H, 2 in, out] (both must be initialised by the caller; d bias = column sums of d_msgs . [msgs > 0]). */
+int adkf_msg_forward(const float* x, const int64_t* src, const int64_t* tgt, const float* W, const float* bias, int32_t E,
+                     int32_t H, int32_t in, int32_t out, int64_t e_off, float* msgs, void* stream);
+int adkf_msg_backward(const float* x, const int64_t* src, const int64_t* tgt, const float* W, const float* msgs,
+                      const float* d_msgs, int32_t E, int32_t H, int32_t in, int32_t out, int64_t e_off, float* dx,
+                      float* dW, void* stream);
+
 /* a1 (aggregation inside RelationalMultiAggrMP._aggregate_messages, fs_mol/modules/gnn.py:197-265; torch_scatter's
  * scatter_sum / scatter_mean / scatter_max there): SUM | MEAN | STD | MAX of the incoming messages of every target
  * node in one pass.  msgs [E, H, 3m] post-ReLU messages (per tower: sum-part | mean/std-part | max-part), perm [E] the
