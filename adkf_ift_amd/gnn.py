@@ -154,7 +154,9 @@ class TowerMessagePassing(nn.Module):
         per_tower = {"plain": self.msg, "multiaggr": 4 * self.msg, "pna": 12 * self.msg}[self.kind]
         return self.H * per_tower
 
-    def forward(self, x: torch.Tensor, plan: _GraphPlan) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, plan: _GraphPlan, scale: bool = True) -> torch.Tensor:
+        """scale=False (PNA only): return the UNSCALED aggregates [V, H * 4m]; the caller folds the identity / amplify /
+        attenuate scalers into the output projection (GNNBlock) instead of materialising the [V, H * 12m] concatenation."""
         V, H, m = x.shape[0], self.H, self.msg
         xt = x.view(V, H, self.in_dim)
         if x.is_cuda and x.dtype == torch.float32 and self.depth == 1 and self.kind != "plain":
@@ -162,7 +164,7 @@ class TowerMessagePassing(nn.Module):
             # and applies bias + ReLU in its epilogue, then ONE aggregation kernel; no fallback here - a missing library raises
             msgs = _MessageFunction.apply(x.contiguous(), plan, H, self.in_dim, self.out_msg, *self.weights, *self.biases)
             agg = _PNAAggregate.apply(msgs, plan.perm, plan.rowptr, V)
-            if self.kind == "pna":
+            if self.kind == "pna" and scale:
                 amp, att = plan.amplify.unsqueeze(-1).to(x.dtype), plan.attenuate.unsqueeze(-1).to(x.dtype)
                 agg = torch.cat((agg, amp * agg, att * agg), dim=2)
             return agg.reshape(V, -1)
@@ -195,7 +197,7 @@ class TowerMessagePassing(nn.Module):
         idx = tg.view(-1, 1, 1).expand(-1, H, m)
         s_max = x.new_zeros(V, H, m).scatter_reduce_(0, idx, msgs[..., 2 * m:3 * m], reduce="amax", include_self=False)
         agg = torch.cat((s_sum, s_mean, s_std, s_max), dim=2)                  # [V, H, 4m], tower-major like the reference cat
-        if self.kind == "pna":
+        if self.kind == "pna" and scale:
             amp, att = plan.amplify.unsqueeze(-1).to(x.dtype), plan.attenuate.unsqueeze(-1).to(x.dtype)
             agg = torch.cat((agg, amp * agg, att * agg), dim=2)                # gnn.py:244-251
         return agg.reshape(V, -1)
@@ -320,7 +322,17 @@ class GNNBlock(nn.Module):
         self.dropout_layer = nn.Dropout(config.dropout_rate)
 
     def forward(self, x: torch.Tensor, plan: _GraphPlan) -> torch.Tensor:
-        new = self.dropout_layer(self.msg_out_projection(self.mp(x, plan)))
+        if self.mp.kind == "pna":
+            # W_out cat(a, amp a, att a) = W_0 a + amp (W_1 a) + att (W_2 a): one [V, H 4m] x [H 4m, 3 hidden] product and a
+            # per-node combination, instead of writing and re-reading the [V, H 12m] (3072-wide) concatenation
+            H, q, hid = self.mp.H, 4 * self.mp.msg, self.config.hidden_dim
+            w = self.msg_out_projection.weight.view(hid, H, 3, q).permute(2, 0, 1, 3).reshape(3 * hid, H * q)
+            p = F.linear(self.mp(x, plan, scale=False), w)
+            new = p[:, :hid] + plan.amplify.to(x.dtype) * p[:, hid:2 * hid] + plan.attenuate.to(x.dtype) * p[:, 2 * hid:] \
+                + self.msg_out_projection.bias
+            new = self.dropout_layer(new)
+        else:
+            new = self.dropout_layer(self.msg_out_projection(self.mp(x, plan)))
         if self.config.use_rezero_scaling:
             new = self.alpha * new
         x = x + new
