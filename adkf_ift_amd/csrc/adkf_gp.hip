@@ -854,9 +854,9 @@ int adkf_msg_forward(const float* x, const int64_t* src, const int64_t* tgt, con
 }
 
 int adkf_msg_backward(const float* x, const int64_t* src, const int64_t* tgt, const float* W, const float* msgs, const float* d_msgs,
-                      int32_t E, int32_t H, int32_t in, int32_t out, int64_t e_off, float* dx, float* dW, void* stream) {
+                      int32_t E, int32_t H, int32_t in, int32_t out, int64_t e_off, float* dx, float* dW, float* db, void* stream) {
     (void)hipGetLastError();
-    if (!x || !W || !msgs || !d_msgs || !dx || !dW || E < 0 || H <= 0 || in <= 0 || out <= 0 || (E > 0 && (!src || !tgt))) return ADKF_E_BADARG;
+    if (!x || !W || !msgs || !d_msgs || !dx || !dW || !db || E < 0 || H <= 0 || in <= 0 || out <= 0 || (E > 0 && (!src || !tgt))) return ADKF_E_BADARG;
     if (E == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     MsgArgs m{};
@@ -867,6 +867,7 @@ int adkf_msg_backward(const float* x, const int64_t* src, const int64_t* tgt, co
     launch_gemm(px, H, E, 2 * in, st);
     ProbMsgBwdW pw; pw.m = m; pw.nsplit = ceil_div(E, m.chunk);
     launch_gemm(pw, H * pw.nsplit, 2 * in, out, st);
+    k_msg_dbias<<<dim3(ceil_div(H * out, 64), ceil_div(E, DB_ROWS)), 256, 0, st>>>(m, db);
     LAUNCH_OK();
     return 0;
 }

@@ -115,6 +115,36 @@ struct MsgArgs {
     bool vec;
 };
 
+// d bias[h, j] += sum_e (d msgs . [msgs > 0])[e, h, j]: 64 columns x 4 row groups per workgroup over a chunk of 256 rows
+// (grid: ceil(H * out / 64) x ceil(E / 256)), eight loads in flight per thread, atomically accumulated
+constexpr int DB_ROWS = 256;
+__global__ __launch_bounds__(256) void k_msg_dbias(MsgArgs m, float* db) {
+    __shared__ float part[4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, width = m.H * m.out;
+    const int e0 = blockIdx.y * DB_ROWS, e1 = min(m.E, e0 + DB_ROWS);
+    float s = 0.f;
+    if (c < width) {
+        int e = e0 + g;
+        for (; e + 28 < e1; e += 32) {
+            float dv[8], mv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const size_t o = (size_t)(m.e_off + e + 4 * u) * width + c;
+                dv[u] = m.d_msgs[o]; mv[u] = m.msgs[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += mv[u] > 0.f ? dv[u] : 0.f;
+        }
+        for (; e < e1; e += 4) {
+            const size_t o = (size_t)(m.e_off + e) * width + c;
+            s += m.msgs[o] > 0.f ? m.d_msgs[o] : 0.f;
+        }
+    }
+    part[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && c < width) atomicAdd(db + c, (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]));
+}
+
 struct ProbMsgFwd {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = false;
     static constexpr int NRED = 0;

@@ -241,16 +241,18 @@ class _MessageFunction(torch.autograd.Function):
         d_msgs = d_msgs.contiguous()
         dx = torch.zeros_like(x)
         st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        db_all = torch.zeros(n_et, H, out_dim, dtype=torch.float32, device=x.device)   # one fill for all edge types
         dWs, dbs, off = [], [], 0
         for et in range(n_et):
             E = int(plan.srcs[et].shape[0])
             w = weights[et].contiguous()
             dW = torch.zeros_like(w)
+            db = db_all[et]
             _lib.check(lib.adkf_msg_backward(C.c_void_p(x.data_ptr()), C.c_void_p(plan.srcs[et].data_ptr()), C.c_void_p(plan.tgts[et].data_ptr()),
                                              C.c_void_p(w.data_ptr()), C.c_void_p(msgs.data_ptr()), C.c_void_p(d_msgs.data_ptr()), E, H, in_dim,
-                                             out_dim, off, C.c_void_p(dx.data_ptr()), C.c_void_p(dW.data_ptr()), st), "adkf_msg_backward")
-            sl = slice(off, off + E)
-            dbs.append((d_msgs[sl] * (msgs[sl] > 0)).sum(0))
+                                             out_dim, off, C.c_void_p(dx.data_ptr()), C.c_void_p(dW.data_ptr()), C.c_void_p(db.data_ptr()), st),
+                       "adkf_msg_backward")
+            dbs.append(db)
             dWs.append(dW)
             off += E
         return (dx, None, None, None, None, *dWs, *dbs)

@@ -168,12 +168,12 @@ int adkf_ift_hypergrad_cg(const adkf_batch_t* b, const float* phi, int32_t flags
  * one edge type in one batched GEMM with the source / target node states gathered on the fly:
  *   msgs[e_off + e, h, :] = relu(cat(x[src_e, h, :], x[tgt_e, h, :]) W[h] + bias[h]),
  * x [V, H, in], W [H, 2 in, out], bias [H, out], msgs [E_all, H, out].  The backward accumulates ATOMICALLY into dx
- * [V, H, in] and dW [H, 2 in, out] (both must be initialised by the caller; d bias = column sums of d_msgs . [msgs > 0]). */
+ * [V, H, in], dW [H, 2 in, out] and db [H, out] (all three must be initialised by the caller). */
 int adkf_msg_forward(const float* x, const int64_t* src, const int64_t* tgt, const float* W, const float* bias, int32_t E,
                      int32_t H, int32_t in, int32_t out, int64_t e_off, float* msgs, void* stream);
 int adkf_msg_backward(const float* x, const int64_t* src, const int64_t* tgt, const float* W, const float* msgs,
                       const float* d_msgs, int32_t E, int32_t H, int32_t in, int32_t out, int64_t e_off, float* dx,
-                      float* dW, void* stream);
+                      float* dW, float* db, void* stream);
 
 /* a1 (aggregation inside RelationalMultiAggrMP._aggregate_messages, fs_mol/modules/gnn.py:197-265; torch_scatter's
  * scatter_sum / scatter_mean / scatter_max there): SUM | MEAN | STD | MAX of the incoming messages of every target
