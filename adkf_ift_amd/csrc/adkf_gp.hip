@@ -32,13 +32,8 @@ inline int tiles_of(int M, int N) { const int e = tile_edge(M, N); return ceil_d
 
 template <class P>
 void launch_gemm(const P& p, int T, int M, int N, hipStream_t st) {
-    if (tile_edge(M, N) == GTL) {
-        const int tm = ceil_div(M, GTL), tn = ceil_div(N, GTL);
-        k_bgemm<P, GTL><<<((T + 7) / 8) * 8 * tm * tn, 256, 0, st>>>(p, T, tm, tn);
-    } else {
-        const int tm = ceil_div(M, GT), tn = ceil_div(N, GT);
-        k_bgemm<P, GT><<<((T + 7) / 8) * 8 * tm * tn, 256, 0, st>>>(p, T, tm, tn);
-    }
+    const int tm = ceil_div(M, GT), tn = ceil_div(N, GT);   // (k_bgemm<P, GTL> is not instantiated: see tile_edge)
+    k_bgemm<P, GT><<<((T + 7) / 8) * 8 * tm * tn, 256, 0, st>>>(p, T, tm, tn);
 }
 
 struct Workspace {
