@@ -7,6 +7,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadkf_gp.so")
+if os.environ.get("ADKF_LIB"):   # diagnostics: an alternative build of the same sources (e.g. with -DADKF_* experiment macros)
+    LIB_PATH = os.environ["ADKF_LIB"]
 
 KERNEL_RBF = 0
 KERNEL_MATERN52 = 1

@@ -26,7 +26,8 @@
 //   * (measured and rejected: sending the NEXT diagonal block from its holder before step q's update and letting every
 //     lane of the block row update a private copy - 10 x 4 FMAs - instead of waiting for the post-update broadcast:
 //     27.4 -> 32.7 us per sweep, the extra scalar FMAs and vector reads cost more than the ~450 cycles they hide;
-//     nor a store / read-back of the block through LDS inside the owning wave instead of the ten ds_bpermute: 29.2 us)
+//     nor a store / read-back of the block through LDS inside the owning wave instead of the ten ds_bpermute: 29.2 us;
+//     nor publishing C and D^-1 only and letting every consumer form F = D^-1 C for its own rows: 40.9 us)
 //   * the owning wave updates only the next pivot rows, runs the chain at raised priority and goes straight to
 //     the barrier; it applies the REST of that step's update one step later, when another wave is on the chain
 //     (vector slots are triple-buffered so the old vectors are still there).
