@@ -192,9 +192,9 @@ void lg_sweep(const LgMat& m, hipStream_t st) {
 // (deterministic work, no synchronisation) and never while the stream is being captured into a graph.
 constexpr int POLL_EVERY = 8;
 
-__global__ void k_count_unfinished(const char* base, size_t stride, size_t phase_offset, int T, int32_t* out) {
+__global__ void k_count_unfinished(const char* base, size_t stride, size_t phase_offset, int T, int done_value, int32_t* out) {
     int c = 0;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) c += *reinterpret_cast<const int*>(base + (size_t)t * stride + phase_offset) != PH_DONE;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) c += *reinterpret_cast<const int*>(base + (size_t)t * stride + phase_offset) != done_value;
     c = wave_sum_i(c);
     if (threadIdx.x == 0) *out = c;
 }
@@ -213,9 +213,9 @@ struct FitPoll {
         enabled = true;
     }
     // true when every task has finished (call after the advance kernel of evaluation e)
-    bool finished(int e, const void* state, size_t stride, size_t phase_offset, int T, hipStream_t st) {
+    bool finished(int e, const void* state, size_t stride, size_t phase_offset, int T, hipStream_t st, int done_value = PH_DONE) {
         if (!enabled || (e + 1) % POLL_EVERY != 0) return false;
-        k_count_unfinished<<<1, 64, 0, st>>>(static_cast<const char*>(state), stride, phase_offset, T, dev);
+        k_count_unfinished<<<1, 64, 0, st>>>(static_cast<const char*>(state), stride, phase_offset, T, done_value, dev);
         if (hipMemcpyAsync(host, dev, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
         if (hipStreamSynchronize(st) != hipSuccess) return false;
         return *host == 0;
@@ -603,9 +603,11 @@ int ard_ift(const adkf_batch_t* b, const float* phi, int flags, bool with_hessia
     if (correct) {
         ArdCg cg{c.T, c.h, cg_tol, c.a.cst, c.a.gout, c.a.cx, c.a.cr, c.a.cp, c.a.cHp, b->n_s, c.ns, c.a.n_eff};
         k_ard_cg_begin<<<c.T, 256, 0, st>>>(cg);
+        FitPoll poll(true, cg_maxiter, c.a.info3, st);   // info3 was merged into info above; free as a counter now
         for (int it = 0; it < cg_maxiter; ++it) {
             ard_hvp(c, phi, c.a.cp, c.a.cHp, c.a.cst);
             k_ard_cg_step<<<c.T, 256, 0, st>>>(cg);
+            if (poll.finished(it, c.a.cst, sizeof(ArdCgState), offsetof(ArdCgState, done), c.T, st, 1)) break;
         }
         k_ard_cg_info<<<ceil_div(c.T, 64), 64, 0, st>>>(c.a.cst, info, cg_iters, c.T);
         if (v_out) hipMemcpyAsync(v_out, c.a.cx, hb, hipMemcpyDeviceToDevice, st);

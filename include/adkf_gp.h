@@ -159,7 +159,8 @@ size_t adkf_workspace_bytes_ard(int32_t T, int32_t ns_max, int32_t nq_max, int32
 
 /* adkf_ift_hypergrad for ARD batches with explicit conjugate-gradient controls (the north-star's "HVP + CG"):
  * at most cg_maxiter iterations, stop at |r| <= cg_tol |grad f_out|; cg_iters [T] (nullable) receives the iterations
- * each task used.  Exactly cg_maxiter rounds of kernels are enqueued (no host synchronisation); converged tasks idle. */
+ * each task used.  Converged tasks drop out of the products; outside stream capture (and for cg_maxiter > 16) the call
+ * synchronises the stream every 8 iterations to stop enqueueing once every task has converged. */
 int adkf_ift_hypergrad_cg(const adkf_batch_t* b, const float* phi, int32_t flags, int32_t cg_maxiter, float cg_tol,
                           float* f_out, float* dZ_s, float* dZ_q, float* g_phi_out, float* v, int32_t* cg_iters,
                           int32_t* info, void* ws, size_t ws_bytes, void* stream);
