@@ -55,7 +55,6 @@ template <int NMAX, int NT> struct SweepCfg;
 #define ADKF_CFG128_CB 4
 #endif
 template <> struct SweepCfg<128, 512> { static constexpr int RB = ADKF_CFG128_RB, CB = ADKF_CFG128_CB; };
-template <> struct SweepCfg<256, 1024> { static constexpr int RB = 16, CB = 4; };  // 64 elements per lane; functional, not tuned (spills: see DESIGN.md)
 template <> struct SweepCfg<64, 256> { static constexpr int RB = 4, CB = 4; };
 template <> struct SweepCfg<32, 256> { static constexpr int RB = 2, CB = 2; };
 template <> struct SweepCfg<16, 256> { static constexpr int RB = 1, CB = 1; };
@@ -178,8 +177,7 @@ struct Sweep {
                 D[b][a] = D[a][b];
             }
         ADKF_TS(3);
-        if constexpr (RB * CB <= 32) {
-            // private copies of C and F: fastest when registers are plentiful (<= 128 points)
+        // private copies of C and F (registers are plentiful: at most 32 matrix elements per lane)
         if (br() == bl) {
             const int j0 = bc() * CB;
             float C[B][CB], F[B][CB], piv[B];
@@ -227,55 +225,9 @@ struct Sweep {
                 for (int c = 0; c < CB; ++c) sm.fvec[slot][a][j0 + c] = F[a][c];
             ADKF_TS(6);
         }
-        } else {
-            // 64 matrix elements per lane: no registers to spare, form C and F straight from the matrix registers
-        if (br() == bl) {
-            const int j0 = bc() * CB;
-            const float hold = (bc() == q) ? 1.f : 0.f;  // this thread holds D: C := D - I at the pivot columns
-            float piv[B];
-            // C rows straight from the matrix registers (no private copy: the 256-point config has no registers to
-            // spare); they are final, so their stores fly under the inverse
-#pragma unroll
-            for (int a = 0; a < B; ++a)
-#pragma unroll
-                for (int c = 0; c < CB; ++c) sm.cross[slot][a][j0 + c] = m[RO + a][c] - (a == c ? hold : 0.f);
-#if ADKF_ABLATE & 1
-            for (int a = 0; a < B; ++a) piv[a] = D[a][a];
-#else
-            InvSpd<B>::run(D, piv);
-#endif
-            ADKF_TS(4);
-            if (bc() == q) {
-#pragma unroll
-                for (int a = 0; a < B; ++a) sm.pivs[q * B + a] = piv[a];
-            }
-#pragma unroll
-            for (int a = 0; a < B; ++a) {
-                float f[CB];
-#pragma unroll
-                for (int c = 0; c < CB; ++c) {
-#if ADKF_ABLATE & 4
-                    f[c] = m[RO + a][c] * D[a][a];
-#else
-                    float s = 0.f;
-#pragma unroll
-                    for (int b = 0; b < B; ++b) s = fmaf(D[a][b], m[RO + b][c] - (b == c ? hold : 0.f), s);
-                    f[c] = s;
-#endif
-                }
-#pragma unroll
-                for (int c = 0; c < CB; ++c) sm.fvec[slot][a][j0 + c] = f[c];
-            }
-            // M_PP := D - 2I (see header): only now, after C and F have been formed from the unmodified rows
-#pragma unroll
-            for (int a = 0; a < B; ++a) m[RO + a][a] -= 2.f * hold;
-            ADKF_TS(6);
-        }
-        }
     }
 
-    // rank-B update of local rows [R0, R1) of this thread's block from the vectors of block step `slot`; the vectors
-    // are fetched one pivot (a) at a time so that at most RB + CB of them are live (RB = 16 in the 256-point config)
+    // rank-B update of local rows [R0, R1) of this thread's block from the vectors of block step `slot`
     template <int R0, int R1>
     __device__ static __forceinline__ void apply_pivot(float (&m)[RB][CB], int slot, int a, SweepSmem<NMAX, NT>& sm) {
         const int j0 = bc() * CB;
@@ -292,17 +244,10 @@ struct Sweep {
     template <int R0, int R1>
     __device__ static __forceinline__ void apply_step(float (&m)[RB][CB], int slot, SweepSmem<NMAX, NT>& sm) {
         if constexpr (R0 < R1) {
-            if constexpr (RB * CB > 32) {
-                // 64 matrix elements per lane: keep only one pivot's vectors live at a time (128-VGPR budget)
-#pragma unroll 1
-                for (int a = 0; a < B; ++a) apply_pivot<R0, R1>(m, slot, a, sm);
-            } else {
 #pragma unroll
-                for (int a = 0; a < B; ++a) apply_pivot<R0, R1>(m, slot, a, sm);
-            }
+            for (int a = 0; a < B; ++a) apply_pivot<R0, R1>(m, slot, a, sm);
         }
     }
-
     // (for the ablation harness tools/sweep_bench.hip)
     __device__ static __forceinline__ void step(float (&m)[RB][CB], int q, SweepSmem<NMAX, NT>& sm) {
         apply_step<0, RB>(m, q % 3, sm);

@@ -39,33 +39,22 @@ struct InnerArgs {
     float gtol, ftol;
 };
 
-// The squared distances of this thread's block: register-resident for the whole fit (<= 128 points), or re-read
-// from L2 at every evaluation in the 256-point configuration (64 more live registers per lane would not fit the
-// 128-VGPR budget of a 1024-thread workgroup; the re-read is 64 floats per lane against a ~70 us sweep).
-template <int NMAX, int NT, bool REGS>
+// The squared distances of this thread's block: register-resident for the whole fit.
+template <int NMAX, int NT>
 struct D2Block {
     using SW = Sweep<NMAX, NT>;
     static constexpr int RB = SW::RB, CB = SW::CB;
-    float reg[REGS ? RB : 1][REGS ? CB : 1];
-    const float* base;
-    int ld, n;
-    __device__ __forceinline__ void init(const float* D2, int ld_, int n_) {
-        base = D2; ld = ld_; n = n_;
-        if constexpr (REGS) {
+    float reg[RB][CB];
+    __device__ __forceinline__ void init(const float* D2, int ld, int n) {
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
+        for (int r = 0; r < RB; ++r)
 #pragma unroll
-                for (int c = 0; c < CB; ++c) reg[r][c] = fetch(r, c);
-        }
+            for (int c = 0; c < CB; ++c) {
+                const int i = SW::row(r), j = SW::col(c);
+                reg[r][c] = (i < n && j < n) ? D2[(size_t)i * ld + j] : 0.f;  // exactly symmetric by construction (ProbDist mirrors its tiles)
+            }
     }
-    __device__ __forceinline__ float fetch(int r, int c) const {
-        const int i = SW::row(r), j = SW::col(c);
-        return (i < n && j < n) ? base[(size_t)i * ld + j] : 0.f;  // exactly symmetric by construction (ProbDist mirrors its tiles)
-    }
-    __device__ __forceinline__ float get(int r, int c) const {
-        if constexpr (REGS) return reg[r][c];
-        else return fetch(r, c);
-    }
+    __device__ __forceinline__ float get(int r, int c) const { return reg[r][c]; }
 };
 
 // f_inner = (nll - log priors) / n and its raw-parameter gradient from the five reductions
@@ -103,8 +92,7 @@ __device__ __forceinline__ void inner_finalize(int n, const float* x, const floa
 
 template <int NMAX, int NT, int KIND>
 struct InnerEval {
-    static constexpr bool D2_REGS = NMAX <= 128;
-    using D2 = D2Block<NMAX, NT, D2_REGS>;
+    using D2 = D2Block<NMAX, NT>;
     using SW = Sweep<NMAX, NT>;
     static constexpr int RB = SW::RB, CB = SW::CB;
 
