@@ -2,8 +2,9 @@
 // (oracle/closed_form.py::inner_stage) and, in fit mode, runs the whole quasi-Newton inner optimisation
 // (the reference's host-side SciPy L-BFGS-B, fs_mol/utils/adaptive_dkt_utils.py:91) inside this one launch.
 // Everything big lives in REGISTERS for the entire fit: each thread owns one RB x CB block of the squared
-// distances, of the kernel matrix being swept into -(A^-1) (factor.h) and of dK/dl; LDS only carries the pivot row
-// of the current sweep step, y, alpha and reduction scratch (< 4 KB), so several tasks can share a CU.
+// distances and of the kernel matrix being swept into -(A^-1) (factor.h); LDS carries the pivot rows of the current
+// sweep steps, y, alpha, reduction scratch, the optimiser state (FitShared) and one float per matrix element
+// (kappa'(u) u, parked by the kernel build for the trace pass): ~14 KB static + NMAX^2 * 4 bytes dynamic.
 #pragma once
 #include "factor.h"
 
