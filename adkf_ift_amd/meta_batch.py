@@ -125,6 +125,22 @@ def collate_meta_batch(tasks: Sequence[DKTBatch], pad_to: int = 4) -> MetaBatch:
                      torch.tensor(nq, dtype=torch.int32), sl, snl, ql, qnl)
 
 
+def shard_tasks_by_nodes(tasks: Sequence[DKTBatch], world: int, rank: int) -> List[int]:
+    """Indices of the tasks rank ``rank`` of ``world`` owns, balanced by GRAPH NODE count rather than task count
+    (with the GNN on the path a task costs what its molecules cost, and query sets range from 16 to 256
+    molecules).  Longest-processing-time greedy: heaviest task first onto the lightest rank; ties break on the lower
+    index, so every rank computes the same assignment from the same task list without talking to the others.  Ranks
+    may end up with different task counts: run the step with ``MetaStepConfig(uneven_shards=True)``."""
+    cost = [int(t.support_features.node_features.shape[0]) + int(t.query_features.node_features.shape[0]) for t in tasks]
+    order = sorted(range(len(tasks)), key=lambda i: (-cost[i], i))
+    load, owner = [0] * world, [0] * len(tasks)
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[i] = r
+        load[r] += cost[i]
+    return [i for i in range(len(tasks)) if owner[i] == rank]
+
+
 def meta_features(model, mb: MetaBatch):
     """ONE forward of the deep-kernel feature extractor for the whole meta-batch ->
     ``Z_s [T, Ns_max, d]``, ``Z_q [T, Nq_max, d]`` (padded rows are zero and receive zero gradient)."""
@@ -134,7 +150,8 @@ def meta_features(model, mb: MetaBatch):
     return Z_s, Z_q
 
 
-def model_meta_step(model, optimizer, mb: MetaBatch, cfg=None, distributed: bool = False, check: bool = False):
+def model_meta_step(model, optimizer, mb: MetaBatch, cfg=None, distributed: bool = False, check: bool = False,
+                    uneven_shards: bool = False):
     """The batched counterpart of one iteration of ``ADKTModelTrainer.train_loop``
     (fs_mol/utils/adaptive_dkt_utils.py:352-413) for an ``ADKTModel``: returns per-task per-sample losses."""
     from .trainer import MetaStepConfig, meta_step
@@ -142,7 +159,8 @@ def model_meta_step(model, optimizer, mb: MetaBatch, cfg=None, distributed: bool
     if cfg is None:
         c = model.config
         cfg = MetaStepConfig(gp_kernel=c.gp_kernel, use_numeric_labels=c.use_numeric_labels, use_ard=c.use_ard,
-                             use_lengthscale_prior=c.use_lengthscale_prior, ignore_grad_correction=c.ignore_grad_correction)
+                             use_lengthscale_prior=c.use_lengthscale_prior, ignore_grad_correction=c.ignore_grad_correction,
+                             uneven_shards=uneven_shards)
     y_s, y_q = mb.labels(cfg.use_numeric_labels)
     return meta_step(lambda: meta_features(model, mb), list(model.feature_extractor_params()), optimizer, y_s, y_q, cfg,
                      n_s=mb.n_s, n_q=mb.n_q, distributed=distributed, check=check)

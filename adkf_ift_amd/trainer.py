@@ -30,6 +30,8 @@ class MetaStepConfig:
     inner_exact_evals: bool = False        # benchmark mode: exactly inner_max_evals evaluations per task
     inner_gtol: float = 1e-5
     inner_ftol: float = 1e-7
+    uneven_shards: bool = False            # ranks hold different numbers of tasks (node-balanced shards): the global
+                                           # task count rides in the gradient all-reduce
 
 
 class HipGPBackend:
@@ -96,17 +98,28 @@ class GraphedGPBackend(HipGPBackend):
         return phi, f_out, dZ_s, dZ_q, info_fit, info
 
 
-def allreduce_flat_grads(params: Sequence[torch.Tensor], group=None) -> None:
+def allreduce_flat_grads(params: Sequence[torch.Tensor], group=None, local_tasks: Optional[int] = None) -> Optional[int]:
     """One all-reduce(sum) over the concatenation of all gradients (one bucket: the payload is small next to
-    a meta-step and xGMI rings are per-link bound, so fewer, larger messages win)."""
+    a meta-step and xGMI rings are per-link bound, so fewer, larger messages win).  ``local_tasks`` rides in the same
+    message as one extra element and comes back as the GLOBAL task count, so shards balanced by node count (unequal
+    task counts per rank, SURVEY 8e caveat) still divide by the right T without a second collective.  The count
+    travels as three base-4096 digits, each exact in fp32 for any realistic number of ranks."""
     grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    parts = [g.reshape(-1) for g in grads]
+    if local_tasks is not None:
+        t = int(local_tasks)
+        parts.append(torch.tensor([t % 4096, (t // 4096) % 4096, t // (4096 * 4096)], dtype=grads[0].dtype, device=grads[0].device))
+    flat = torch.cat(parts)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
     for p, g in zip(params, grads):
         n = g.numel()
         p.grad = flat[off:off + n].view_as(g).clone()
         off += n
+    if local_tasks is None:
+        return None
+    d = flat[off:off + 3].double().round().tolist()
+    return int(d[0] + 4096 * d[1] + 4096 * 4096 * d[2])
 
 
 def _mean_and_clip_(params: Sequence[torch.Tensor], scale: float, clip_value: Optional[float]) -> None:
@@ -163,14 +176,18 @@ def meta_step(features_fn: Callable[[], Tuple[torch.Tensor, torch.Tensor]], para
         gp_ops.check_info(info_fit, "inner fit")
         gp_ops.check_info(info, "IFT hypergradient")
     # one backward through the feature extractor; task-mean over the GLOBAL meta-batch (adaptive_dkt_utils.py:402-407)
-    scale = 1.0 / float(T_local * world)
+    T_global = T_local
     if "out_dZ" in kw:
         feats.backward(dZ_all)
     else:
         torch.autograd.backward([Z_s, Z_q], [dZ_s.to(Z_s.dtype), dZ_q.to(Z_q.dtype)])
     if distributed and world > 1:
-        allreduce_flat_grads(params)
-    _mean_and_clip_(params, scale, cfg.clip_value)
+        if cfg.uneven_shards:
+            T_global = allreduce_flat_grads(params, local_tasks=T_local)   # host reads the count: one sync per step
+        else:
+            allreduce_flat_grads(params)
+            T_global = T_local * world
+    _mean_and_clip_(params, 1.0 / float(T_global), cfg.clip_value)
     if optimizer is not None:
         optimizer.step()
     nq = n_q.to(f_out.dtype) if n_q is not None else float(Z_q.shape[1])

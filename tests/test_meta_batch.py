@@ -55,3 +55,21 @@ def test_collate_matches_per_task_features():
         assert float(Z_s[t, task.num_support_samples:].abs().max() if task.num_support_samples < 8 else 0.0) == 0.0
     ys, yq = mb.labels(False)
     assert set(ys.unique().tolist()) <= {-1.0, 0.0, 1.0} and float(ys[2, 2:].abs().max()) == 0.0
+
+
+def test_shards_balance_by_node_count():
+    from adkf_ift_amd.meta_batch import shard_tasks_by_nodes
+    sizes = [(16, 256), (16, 16), (16, 32), (16, 200), (16, 24), (16, 64), (16, 128)]
+    tasks = [random_task(ns, nq, 10 + i) for i, (ns, nq) in enumerate(sizes)]
+    cost = [int(t.support_features.node_features.shape[0] + t.query_features.node_features.shape[0]) for t in tasks]
+    for world in (2, 3):
+        shards = [shard_tasks_by_nodes(tasks, world, r) for r in range(world)]
+        assert sorted(i for s in shards for i in s) == list(range(len(tasks)))       # a partition
+        loads = [sum(cost[i] for i in s) for s in shards]
+        # LPT bound: no rank exceeds the mean by more than the heaviest task
+        assert max(loads) <= sum(cost) / world + max(cost)
+        # and it beats the contiguous equal-count split whenever that one is lopsided
+        per = -(-len(tasks) // world)
+        naive = [sum(cost[r * per:(r + 1) * per]) for r in range(world)]
+        assert max(loads) <= max(naive)
+    assert len({len(s) for s in [shard_tasks_by_nodes(tasks, 2, r) for r in range(2)]}) > 1   # task counts DO differ
