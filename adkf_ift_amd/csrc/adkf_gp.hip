@@ -6,6 +6,7 @@
 #include "../../include/adkf_gp.h"
 #include "ard.h"
 #include "pna.h"
+#include "outer_step.h"
 
 using namespace adkf;
 
@@ -885,6 +886,33 @@ int adkf_pna_aggregate_backward(const float* msgs, const int64_t* perm, const in
     if (!msgs || !perm || !rowptr || !agg || !argmax || !d_agg || !d_msgs || V <= 0 || H <= 0 || m <= 0) return ADKF_E_BADARG;
     PnaArgs a{msgs, perm, rowptr, const_cast<float*>(agg), const_cast<int32_t*>(argmax), d_agg, d_msgs, V, H, m};
     k_pna_bwd<<<V, 256, 0, static_cast<hipStream_t>(stream)>>>(a);
+    LAUNCH_OK();
+    return 0;
+}
+
+int adkf_grad_sumsq(const float* g, int64_t n, float* partials, void* stream) {
+    (void)hipGetLastError();
+    if (!g || !partials || n <= 0 || (reinterpret_cast<uintptr_t>(g) & 15)) return ADKF_E_BADARG;
+    k_grad_sumsq<<<SUMSQ_PARTS, STEP_NT, 0, static_cast<hipStream_t>(stream)>>>(g, (long)n, partials);
+    LAUNCH_OK();
+    return 0;
+}
+
+int adkf_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* partials, int32_t n_partials, float scale,
+                        float clip, double lr, double beta1, double beta2, double eps, double weight_decay, int32_t step, void* stream) {
+    (void)hipGetLastError();
+    if (!p || !g || !m || !v || !partials || n <= 0 || n_partials <= 0 || step <= 0) return ADKF_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
+        return ADKF_E_BADARG;
+    // bias corrections in double on the host, as torch.optim.Adam does for a python-number step
+    const double bias1 = 1.0 - pow(beta1, (double)step);
+    const double bias2_sqrt = sqrt(1.0 - pow(beta2, (double)step));
+    AdamArgs a{p, g, m, v, (long)n, partials, n_partials, scale, clip, (float)(lr / bias1), (float)(1.0 - beta1), (float)beta2,
+               (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)bias2_sqrt};
+    const long n4 = (n + 3) / 4;
+    int grid = (int)((n4 + STEP_NT - 1) / STEP_NT);
+    grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
+    k_clip_adam<<<grid, STEP_NT, 0, static_cast<hipStream_t>(stream)>>>(a);
     LAUNCH_OK();
     return 0;
 }

@@ -202,11 +202,11 @@ __global__ __launch_bounds__(256) void k_ard_advance(ArdFitArgs a) {
         f = fe;
         hist = 0; head = 0;
         if (ie != 0 || !(fe < INFINITY)) stop = true;
-        else if (!exact && gmax <= a.gtol) stop = true;
+        else if (gmax <= a.gtol) stop = true;
         else new_dir = true;
         phase = PH_SEARCH;
     } else if (phase == PH_SEARCH) {
-        if (fe <= f + 1e-4f * step * gp) {  // Armijo
+        if (ie == 0 && fe <= f + 1e-4f * step * gp) {  // Armijo (a failed factorisation never counts as progress)
             float sy = 0.f, yy = 0.f, ss = 0.f;
             for (int k = tid; k < h; k += 256) { const float s_ = xe[k] - x[k], y_ = ge[k] - g[k]; sy += s_ * y_; yy += y_ * y_; ss += s_ * s_; }
             sy = bsum256(sy, red); yy = bsum256(yy, red); ss = bsum256(ss, red);
@@ -220,16 +220,13 @@ __global__ __launch_bounds__(256) void k_ard_advance(ArdFitArgs a) {
             const float fprev = f;
             for (int k = tid; k < h; k += 256) { x[k] = xe[k]; g[k] = ge[k]; }
             f = fe;
-            if (!exact && (gmax <= a.gtol || fabsf(fprev - fe) <= a.ftol * fmaxf(fmaxf(fabsf(fprev), fabsf(fe)), 1.f))) stop = true;
+            if (gmax <= a.gtol || fabsf(fprev - fe) <= a.ftol * fmaxf(fmaxf(fabsf(fprev), fabsf(fe)), 1.f)) stop = true;
             else new_dir = true;
         } else {
             const float denom = 2.f * (fe - f - gp * step);
             const float sq = (denom > 0.f && fe < INFINITY) ? (-gp * step * step / denom) : 0.5f * step;
             step = fminf(fmaxf(sq, 0.1f * step), 0.5f * step);
-            if (++bt >= 12) {
-                if (!exact) stop = true;
-                else { hist = 0; new_dir = true; }
-            }
+            if (++bt >= 12) stop = true;  // converged to working precision (exact mode: burns the rest of the budget here)
         }
     }
     __syncthreads();  // S.rho[head] visible; x, g final
@@ -255,17 +252,22 @@ __global__ __launch_bounds__(256) void k_ard_advance(ArdFitArgs a) {
             const float cf = alpha_s[j] - b;
             for (int k = tid; k < h; k += 256) p[k] += cf * Sv[(size_t)idx * h + k];
         }
-        float dg = 0.f, g1 = 0.f, gg = 0.f;
-        for (int k = tid; k < h; k += 256) { p[k] = -p[k]; dg += g[k] * p[k]; g1 += fabsf(g[k]); gg += g[k] * g[k]; }
-        dg = bsum256(dg, red); g1 = bsum256(g1, red); gg = bsum256(gg, red);
+        float dg = 0.f, g1 = 0.f, gg = 0.f, pm = 0.f, gm = 0.f;
+        for (int k = tid; k < h; k += 256) {
+            p[k] = -p[k]; dg += g[k] * p[k]; g1 += fabsf(g[k]); gg += g[k] * g[k];
+            pm = fmaxf(pm, fabsf(p[k])); gm = fmaxf(gm, fabsf(g[k]));
+        }
+        dg = bsum256(dg, red); g1 = bsum256(g1, red); gg = bsum256(gg, red); pm = bmax256(pm, red); gm = bmax256(gm, red);
         if (!(dg < 0.f)) {  // not a descent direction (or NaN): restart from steepest descent
             hist = 0;
             for (int k = tid; k < h; k += 256) p[k] = -g[k];
             dg = -gg;
+            pm = gm;
             if (!(dg < 0.f)) stop = true;
         }
         gp = dg;
         step = hist > 0 ? 1.f : fminf(1.f, 1.f / g1);
+        step = fminf(step, MAX_MOVE / fmaxf(pm, 1e-30f));   // as Bfgs::direction: no raw parameter moves more than MAX_MOVE per trial
         bt = 0;
     }
     if (stop && exact) phase = PH_BURN;

@@ -179,6 +179,8 @@ struct InnerEval {
 };
 
 // Quasi-Newton driver state (identical in every lane: all inputs come from block-wide reductions).
+constexpr float MAX_MOVE = 16.f;
+
 struct Bfgs {
     float x[3], f, g[3];      // current accepted point
     float Hi[3][3];           // inverse-Hessian approximation
@@ -206,6 +208,10 @@ struct Bfgs {
             if (!(gp < 0.f)) return false;
         }
         step = first ? fminf(1.f, 1.f / (fabsf(g[0]) + fabsf(g[1]) + fabsf(g[2]))) : 1.f;
+        // no raw parameter moves by more than MAX_MOVE per trial: a quasi-Newton direction built from differences at
+        // the fp32 noise floor can be astronomically long, and far out (outputscale 1e8) the fp32 value is garbage
+        // that would pass the Armijo test
+        step = fminf(step, MAX_MOVE / fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fmaxf(fabsf(p[2]), 1e-30f)));
         bt = 0;
         return true;
     }
@@ -271,28 +277,28 @@ __device__ __forceinline__ void fit_advance(FitShared& fs, const InnerArgs& a, f
         st.f = fe;
         for (int q = 0; q < 3; ++q) st.g[q] = ge[q];
         if (ie != 0) stop = true;  // infeasible start: reported by the final evaluation
-        else if (!a.exact_evals && fmaxf(fabsf(ge[0]), fmaxf(fabsf(ge[1]), fabsf(ge[2]))) <= a.gtol) stop = true;
+        else if (fmaxf(fabsf(ge[0]), fmaxf(fabsf(ge[1]), fabsf(ge[2]))) <= a.gtol) stop = true;
         else if (!st.direction()) stop = true;
         phase = PH_SEARCH;
     } else if (phase == PH_SEARCH) {
-        if (fe <= st.f + 1e-4f * st.step * st.gp) {  // Armijo
+        if (ie == 0 && fe <= st.f + 1e-4f * st.step * st.gp) {  // Armijo (a failed factorisation never counts as progress)
             const float fprev = st.f;
             st.accept(fs.xe, fe, ge);
             const float gmax = fmaxf(fabsf(ge[0]), fmaxf(fabsf(ge[1]), fabsf(ge[2])));
-            if (!a.exact_evals && (gmax <= a.gtol || fabsf(fprev - fe) <= a.ftol * fmaxf(fmaxf(fabsf(fprev), fabsf(fe)), 1.f))) stop = true;
+            if (gmax <= a.gtol || fabsf(fprev - fe) <= a.ftol * fmaxf(fmaxf(fabsf(fprev), fabsf(fe)), 1.f)) stop = true;
             else if (!st.direction()) stop = true;
         } else {
             // safeguarded quadratic interpolation of the step
             const float denom = 2.f * (fe - st.f - st.gp * st.step);
             const float sq = (denom > 0.f && fe < INFINITY) ? (-st.gp * st.step * st.step / denom) : 0.5f * st.step;
             st.step = fminf(fmaxf(sq, 0.1f * st.step), 0.5f * st.step);
-            if (++st.bt >= 12) {  // line search failed: converged to working precision
-                if (!a.exact_evals) stop = true;
-                else { st.reset_H(); if (!st.direction()) stop = true; }
-            }
+            if (++st.bt >= 12) stop = true;  // line search failed: converged to working precision
         }
     }
-    if (stop && a.exact_evals) phase = PH_BURN;  // spend the remaining budget at the current point
+    // exact_evals (benchmark mode): the same stopping rules, but a converged task spends the rest of its budget
+    // re-evaluating at its optimum, so every task costs exactly max_evals evaluations and phi* does not depend on the
+    // mode.  (Iterating on past convergence instead feeds rounding noise to the quasi-Newton update.)
+    if (stop && a.exact_evals) phase = PH_BURN;
     if (evals >= budget || (stop && !a.exact_evals)) {
         phase = PH_FINAL;
         for (int q = 0; q < 3; ++q) fs.xe[q] = st.x[q];

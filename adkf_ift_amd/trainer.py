@@ -144,6 +144,65 @@ def _mean_and_clip_(params: Sequence[torch.Tensor], scale: float, clip_value: Op
         g.mul_(coef)
 
 
+class ClipAdam(torch.optim.Adam):
+    """``torch.optim.Adam`` whose ``clip_step(scale, clip_value)`` does {task-mean, clip-by-global-norm, Adam update}
+    (fs_mol/utils/adaptive_dkt_utils.py:402-413) in the HIP library: ``adkf_grad_sumsq`` + ``adkf_clip_adam_step`` per
+    tensor, i.e. 2 launches for the benchmark's single d x d parameter instead of norm + clamp + mul + a fused Adam
+    whose one 64 K chunk runs on a single workgroup (70 us -> 8 us).  State layout (``exp_avg``, ``exp_avg_sq``,
+    ``step``) is torch's, so ``state_dict`` / ``load_state_dict`` interchange with ``torch.optim.Adam`` and a plain
+    ``.step()`` still works.  Meant for a handful of tensors (``meta_step`` uses it when there are at most
+    ``MAX_TENSORS`` parameters); a 300-tensor model is better served by torch's multi-tensor kernels."""
+
+    MAX_TENSORS = 8
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False)
+        self._partials = None
+
+    def _tensors(self):
+        out = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    out.append((group, p))
+        return out
+
+    def clip_step(self, scale: float, clip_value: Optional[float]) -> None:
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        todo = self._tensors()
+        if not todo:
+            return
+        dev = todo[0][1].device
+        for _, p in todo:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
+                    and p.grad.dtype == torch.float32 and p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0):
+                raise RuntimeError("ClipAdam.clip_step needs contiguous, 16-byte aligned float32 parameters on the GPU")
+        parts = 256   # ADKF_SUMSQ_PARTS
+        if self._partials is None or self._partials.numel() != parts * len(todo) or self._partials.device != dev:
+            self._partials = torch.empty(parts * len(todo), dtype=torch.float32, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        for k, (_, p) in enumerate(todo):
+            _lib.check(lib.adkf_grad_sumsq(ptr(p.grad), p.numel(), C.c_void_p(self._partials.data_ptr() + 4 * parts * k), st),
+                       "adkf_grad_sumsq")
+        clip = float("inf") if clip_value is None else float(clip_value)
+        for group, p in todo:
+            state = self.state[p]
+            if len(state) == 0:
+                state["step"] = torch.tensor(0.0)
+                state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            state["step"] += 1
+            b1, b2 = group["betas"]
+            _lib.check(lib.adkf_clip_adam_step(ptr(p), ptr(p.grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]), p.numel(),
+                                               ptr(self._partials), self._partials.numel(), float(scale), clip, float(group["lr"]),
+                                               float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                               int(state["step"].item()), st), "adkf_clip_adam_step")
+
+
 def meta_step(features_fn: Callable[[], Tuple[torch.Tensor, torch.Tensor]], params: List[torch.Tensor],
               optimizer: Optional[torch.optim.Optimizer], y_s: torch.Tensor, y_q: torch.Tensor, cfg: MetaStepConfig,
               backend=None, n_s=None, n_q=None, distributed: bool = False, fit_events=None, check: bool = False):
@@ -187,8 +246,11 @@ def meta_step(features_fn: Callable[[], Tuple[torch.Tensor, torch.Tensor]], para
         else:
             allreduce_flat_grads(params)
             T_global = T_local * world
-    _mean_and_clip_(params, 1.0 / float(T_global), cfg.clip_value)
-    if optimizer is not None:
-        optimizer.step()
+    if isinstance(optimizer, ClipAdam) and len(params) <= ClipAdam.MAX_TENSORS and params[0].is_cuda:
+        optimizer.clip_step(1.0 / float(T_global), cfg.clip_value)
+    else:
+        _mean_and_clip_(params, 1.0 / float(T_global), cfg.clip_value)
+        if optimizer is not None:
+            optimizer.step()
     nq = n_q.to(f_out.dtype) if n_q is not None else float(Z_q.shape[1])
     return f_out / nq, phi

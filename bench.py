@@ -51,7 +51,7 @@ def main():
     import __graft_entry__ as ge
     from adkf_ift_amd import gp_ops, roofline
     from adkf_ift_amd.synthetic import LinearFeatureMap, make_tasks
-    from adkf_ift_amd.trainer import GraphedGPBackend, MetaStepConfig, meta_step
+    from adkf_ift_amd.trainer import ClipAdam, GraphedGPBackend, MetaStepConfig, meta_step
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -74,7 +74,7 @@ def main():
     tasks = make_tasks(T, N, d, N_q=Nq, first_task=rank * T)
     X_s, X_q, y_s, y_q = (a.to(dev) for a in (tasks.X_s, tasks.X_q, tasks.y_s, tasks.y_q))
     W = tasks.W.to(dev).clone().requires_grad_(True)
-    opt = torch.optim.Adam([W], lr=1e-4, fused=True)  # fs_mol/adaptive_dkt_train.py --lr default; fused: one kernel instead of nine
+    opt = ClipAdam([W], lr=1e-4)  # fs_mol/adaptive_dkt_train.py --lr default; mean + clip + Adam in the library (2 launches)
     cfg = MetaStepConfig(gp_kernel=args.kernel, inner_max_evals=(200 if args.converge else I),
                          inner_exact_evals=not args.converge, clip_value=1.0, use_ard=args.ard)
     inv_sqrt_d = 1.0 / math.sqrt(d)

@@ -187,6 +187,20 @@ int adkf_pna_aggregate_backward(const float* msgs, const int64_t* perm, const in
                                 const int32_t* argmax, const float* d_agg, int32_t V, int32_t H, int32_t m,
                                 float* d_msgs, void* stream);
 
+/* H (outer update of ADKTModelTrainer.train_loop, fs_mol/utils/adaptive_dkt_utils.py:402-413: task-mean of the
+ * accumulated gradients, torch.nn.utils.clip_grad_norm_, torch.optim.Adam.step) for a handful of parameter tensors.
+ *   adkf_grad_sumsq      partials[0 .. ADKF_SUMSQ_PARTS) = per-workgroup sums of g^2 (fixed partition: deterministic).
+ *   adkf_clip_adam_step  with |g| = sqrt(sum of the n_partials partials, i.e. those of ALL tensors laid side by side):
+ *                        g <- g * scale * min(1, clip / (scale |g| + 1e-6));  then Adam step number `step` (1-based;
+ *                        exp_avg m, exp_avg_sq v, no amsgrad, weight_decay added to g as torch does).  clip = +inf
+ *                        disables clipping.  Hyper-parameters are doubles: 1 - beta and lr / (1 - beta1^step) are formed in double
+ *                        and rounded once, as torch does.  All pointers 16-byte aligned, n elements each. */
+#define ADKF_SUMSQ_PARTS 256
+int adkf_grad_sumsq(const float* g, int64_t n, float* partials, void* stream);
+int adkf_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* partials, int32_t n_partials,
+                        float scale, float clip, double lr, double beta1, double beta2, double eps, double weight_decay,
+                        int32_t step, void* stream);
+
 /* Synchronises `stream`, then returns 0 or (index+1) of the first task with info != 0. */
 int adkf_check_info(const int32_t* info, int32_t T, void* stream);
 

@@ -3,6 +3,7 @@ linear-map theta-gradients produced by the REFERENCE's cauchy_hypergradient file
 C ABI (ctypes).  Tolerance: 1e-4 relative (BASELINE.json north_star) on log-marginal-likelihood and IFT
 gradients; matrices/vectors are compared in max-norm relative to the largest reference entry."""
 import glob
+import math
 import os
 
 import numpy as np
@@ -248,3 +249,43 @@ def test_c5_large_support_regime(dev):
     assert rel(out["v"][t].cpu().numpy(), q["v"]) <= TOL
     assert rel(out["dZ_s"][t].cpu().numpy(), q["dZs_total"]) <= TOL
     assert rel(out["dZ_q"][t].cpu().numpy(), q["dZq_total"]) <= TOL
+
+
+def test_fixed_evaluation_budget_does_not_iterate_past_convergence(golden_dir, dev):
+    """exact_evals mode (the benchmark's "exactly I evaluations") must stop MOVING once converged and spend the rest of
+    its budget at the optimum: quasi-Newton updates built from differences at the fp32 noise floor once sent the
+    captured task to outputscale 1e8 at evaluation 20, where the fp32 value is garbage that passes the Armijo test."""
+    from adkf_ift_amd import gp_ops
+    from adkf_ift_amd.synthetic import make_tasks
+
+    g = np.load(os.path.join(golden_dir, "fit_noise_floor_task.npz"))
+    Zs = torch.tensor(g["Z_s"])[None].to(dev)
+    ys = torch.tensor(g["y_s"])[None].to(dev)
+    pri = torch.empty(1, 4, device=dev)
+    b = gp_ops.GPBatch(Zs, ys, pri, "rbf")
+    phi0, _ = gp_ops.init_params_batch(b, False, True)
+    ref, f_ref, _, ne_ref, info = gp_ops.fit(b, phi0, 200)
+    gp_ops.check_info(info)
+    assert np.abs(ref[0].cpu().numpy() - g["phi_star"]).max() <= 2e-3          # the float64 L-BFGS-B optimum
+    for budget in (14, 20, 21, 33, 60):
+        phi, f, gn, ne, info = gp_ops.fit(b, phi0, budget, exact_evals=True)
+        gp_ops.check_info(info)
+        assert int(ne[0]) == budget
+        assert torch.isfinite(phi).all() and (phi - ref).abs().max().item() <= 1e-3, (budget, phi.tolist())
+        assert abs(f[0].item() - f_ref[0].item()) <= 1e-6
+
+    # the same property over a whole meta-batch: any budget >= the evaluations a task needs returns its optimum
+    tasks = make_tasks(64, 64, 32, N_q=8)
+    Zs = (tasks.X_s @ tasks.W / math.sqrt(32)).to(dev).contiguous()
+    b = gp_ops.GPBatch(Zs, tasks.y_s.to(dev), torch.empty(64, 4, device=dev), "matern")
+    phi0, _ = gp_ops.init_params_batch(b, False, True)
+    ref, f_ref, _, ne_ref, info = gp_ops.fit(b, phi0, 200)
+    gp_ops.check_info(info)
+    for budget in (40, 80):
+        phi, f, gn, ne, info = gp_ops.fit(b, phi0, budget, exact_evals=True)
+        gp_ops.check_info(info)
+        done = ne_ref <= budget
+        assert done.any() and (ne == budget).all()
+        assert torch.isfinite(phi).all()
+        assert (phi[done] - ref[done]).abs().max().item() <= 1e-3
+        assert (f[done] - f_ref[done]).abs().max().item() <= 1e-6

@@ -400,3 +400,59 @@ def test_fused_pna_aggregation_equals_torch_path(dev, kind):
             assert q.grad is None, n
             continue
         assert (q.grad.double().cpu() - p.grad).abs().max().item() <= 2e-4 * scale, n
+
+
+@pytest.mark.parametrize("clip, wd", [(1.0, 0.0), (1e9, 0.0), (None, 0.0), (0.3, 0.01)])
+def test_clip_adam_equals_clip_grad_norm_plus_torch_adam(dev, clip, wd):
+    """H: adkf_grad_sumsq + adkf_clip_adam_step == {grad *= 1/T, clip_grad_norm_, torch.optim.Adam.step} over several
+    steps, for sizes with and without a 4-element tail, and the optimiser state interchanges with torch's."""
+    from adkf_ift_amd.trainer import ClipAdam, _mean_and_clip_
+
+    g = torch.Generator().manual_seed(5)
+    shapes = [(256, 256), (1027,), (3, 5)]
+    ref = [torch.randn(s, generator=g).to(dev).requires_grad_(True) for s in shapes]
+    new = [p.detach().clone().requires_grad_(True) for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=1e-2, weight_decay=wd)
+    o_new = ClipAdam(new, lr=1e-2, weight_decay=wd)
+    scale = 1.0 / 16.0
+    for step in range(4):
+        grads = [torch.randn(s, generator=g).to(dev) * 10.0 ** (step - 1) for s in shapes]
+        for p, q, gr in zip(ref, new, grads):
+            p.grad = gr.clone()
+            q.grad = gr.clone()
+        if clip is None:
+            torch._foreach_mul_([p.grad for p in ref], scale)
+        else:
+            torch._foreach_mul_([p.grad for p in ref], scale)
+            torch.nn.utils.clip_grad_norm_(ref, clip)
+        o_ref.step()
+        o_new.clip_step(scale, clip)
+        for p, q in zip(ref, new):
+            assert (q.grad - p.grad).abs().max() <= 2e-6 * p.grad.abs().max(), (step, "clipped gradient")
+            assert (q - p).abs().max() <= 2e-6 * p.abs().max() + 1e-7, (step, "parameter")
+    for p, q in zip(ref, new):
+        sr, sn = o_ref.state[p], o_new.state[q]
+        assert float(sr["step"]) == float(sn["step"]) == 4.0
+        assert (sr["exp_avg"] - sn["exp_avg"]).abs().max() <= 2e-6 * sr["exp_avg"].abs().max()
+        assert (sr["exp_avg_sq"] - sn["exp_avg_sq"]).abs().max() <= 4e-6 * sr["exp_avg_sq"].abs().max()
+    # state interchange: a torch Adam continues from ClipAdam's state and vice versa
+    o_t = torch.optim.Adam(new, lr=1e-2, weight_decay=wd)
+    o_t.load_state_dict(o_new.state_dict())
+    o_c = ClipAdam(ref, lr=1e-2, weight_decay=wd)
+    o_c.load_state_dict(o_ref.state_dict())
+    for p, q in zip(ref, new):
+        gr = torch.randn(p.shape, generator=g).to(dev)
+        p.grad, q.grad = gr.clone(), gr.clone()
+    o_t.step()
+    o_c.clip_step(1.0, None)
+    for p, q in zip(ref, new):
+        assert (q - p).abs().max() <= 4e-6 * p.abs().max() + 1e-7
+    # determinism: the same gradient gives the same bits twice (fixed partial-sum order)
+    a = [torch.zeros(1 << 16, device=dev).requires_grad_(True) for _ in range(2)]
+    gr = torch.randn(1 << 16, generator=g).to(dev)
+    outs = []
+    for p in a:
+        p.grad = gr.clone()
+        ClipAdam([p], lr=1e-2).clip_step(1.0, 1.0)
+        outs.append(p.detach().clone())
+    assert torch.equal(outs[0], outs[1])
