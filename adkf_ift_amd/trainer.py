@@ -104,6 +104,9 @@ def allreduce_flat_grads(params: Sequence[torch.Tensor], group=None, local_tasks
     message as one extra element and comes back as the GLOBAL task count, so shards balanced by node count (unequal
     task counts per rank, SURVEY 8e caveat) still divide by the right T without a second collective.  The count
     travels as three base-4096 digits, each exact in fp32 for any realistic number of ranks."""
+    if len(params) == 1 and local_tasks is None and params[0].grad is not None:
+        dist.all_reduce(params[0].grad, op=dist.ReduceOp.SUM, group=group)   # nothing to pack
+        return None
     grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
     parts = [g.reshape(-1) for g in grads]
     if local_tasks is not None:

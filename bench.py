@@ -59,10 +59,17 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the GP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal of the N > 1 path on a one-GPU box: ADKF_BENCH_BACKEND=gloo lets several ranks share a card (RCCL
+    # refuses duplicate devices); the driver's runs use the default, one rank per GPU over RCCL
+    backend_name = os.environ.get("ADKF_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend_name == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if distributed:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend_name)
     if rank == 0:
         ge.build()
     if distributed:
