@@ -137,7 +137,7 @@ def run_on_batches(model, batches: List[DKTBatch], batch_labels: List[torch.Tens
 
 
 @torch.no_grad()
-def meta_test(model, mb: MetaBatch, max_evals: int = 200, gtol: float = 1e-5, ftol: float = 1e-7, want_var: bool = False):
+def meta_test(model, mb: MetaBatch, max_evals: int = 200, gtol: float = 1e-5, ftol: float = 2.22e-9, want_var: bool = False):
     """All tasks at once.  Returns (predictions [T, Nq_max], variance or None, phi* [T, 3], n_evals [T]); padded query
     slots hold 0.  Classification predictions are already passed through the sigmoid."""
     from . import gp_ops

@@ -33,6 +33,12 @@ def kernel_id(kernel) -> int:
     return KERNELS[kernel]
 
 
+# SciPy's L-BFGS-B default ftol (factr * eps = 2.22e-9), which is what botorch's fit_gpytorch_scipy runs with
+# (SURVEY App. A7).  On an fp32 objective of magnitude ~1 it means "stop when an accepted step does not lower f at all";
+# 1e-7 (one ulp) looked equivalent and was not: it stopped fits that were still creeping along the lengthscale valley.
+FTOL_DEFAULT = 2.22e-9
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -193,7 +199,7 @@ def mll_value_grad(b: GPBatch, phi: torch.Tensor, want_grad_phi=True, want_dZ=Fa
     return f, g, dZ, info
 
 
-def fit(b: GPBatch, phi0: torch.Tensor, max_evals: int = 200, gtol: float = 1e-5, ftol: float = 1e-7,
+def fit(b: GPBatch, phi0: torch.Tensor, max_evals: int = 200, gtol: float = 1e-5, ftol: float = FTOL_DEFAULT,
         exact_evals: bool = False, events: Optional[Tuple[torch.cuda.Event, torch.cuda.Event]] = None):
     """Batched inner optimisation; returns (phi*, f_final, gnorm, n_evals, info).  ``events`` = a pair of
     already-created timing events recorded right around the optimiser kernel (bench.py's roofline clock)."""

@@ -211,7 +211,7 @@ class _OuterNLLFunction(torch.autograd.Function):
         return grad_out * dZs, None, grad_out * dZq, None, grad_out * g, None, None, None
 
 
-def fit_gpytorch_scipy(mll: ExactMarginalLogLikelihood, max_evals: int = 200, gtol: float = 1e-5, ftol: float = 1e-7):
+def fit_gpytorch_scipy(mll: ExactMarginalLogLikelihood, max_evals: int = 200, gtol: float = 1e-5, ftol: float = gp_ops.FTOL_DEFAULT):
     """Drop-in for ``botorch.optim.fit.fit_gpytorch_scipy(model.mll)``: minimises -mll over the raw GP parameters on the
     GPU (in-kernel BFGS for the three-parameter kernel, device L-BFGS for ARD) and writes the optimum back into the
     module.  Returns ``(mll, info_dict)`` like BoTorch."""

@@ -29,7 +29,7 @@ class MetaStepConfig:
     inner_max_evals: int = 200
     inner_exact_evals: bool = False        # benchmark mode: exactly inner_max_evals evaluations per task
     inner_gtol: float = 1e-5
-    inner_ftol: float = 1e-7
+    inner_ftol: float = 2.22e-9            # SciPy L-BFGS-B default (factr * eps): on an fp32 objective "no decrease at all"
     uneven_shards: bool = False            # ranks hold different numbers of tasks (node-balanced shards): the global
                                            # task count rides in the gradient all-reduce
 
