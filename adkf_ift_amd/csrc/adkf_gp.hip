@@ -7,6 +7,7 @@
 #include "ard.h"
 #include "pna.h"
 #include "outer_step.h"
+#include "ldl.h"
 
 using namespace adkf;
 
@@ -255,6 +256,20 @@ int launch_inner(InnerArgs a, const Workspace& w, hipStream_t st) {
     return 0;
 }
 
+// After ProbC: tasks whose A is ill-conditioned get C = K_qs A^-1 and alpha = A^-1 y re-solved through an LDL^T
+// factorisation (ldl.h); everybody else leaves the kernel after one reduction.  Register-path sizes only.
+void launch_ldl(const TaskView& tv, const adkf_batch_t* b, const Workspace& w, hipStream_t st) {
+    if (b->ns_max > REG_POINTS) return;
+    const size_t smem = ldl_smem_bytes(b->ns_max);
+    static const bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ldl_c), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)ldl_smem_bytes(REG_POINTS)) == hipSuccess;
+    }();
+    (void)attr_set;
+    LdlArgs la{tv, w.D2ss, w.D2qs, w.Ainv, b->y_s, w.C, w.vecs, LDL_THRESHOLD, b->T};
+    k_ldl_c<<<b->T, LDL_NT, smem, st>>>(la);
+}
+
 int launch_outer_factor(const OuterArgs& a, const Workspace& w, int nq, hipStream_t st) {
     if (nq > REG_POINTS) {
         k_lg_resid<<<dim3(ceil_div(nq, 4), a.T), 256, 0, st>>>(a);
@@ -335,6 +350,7 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
     }
     ProbC pc; pc.tv = tv; pc.Ainv = w.Ainv; pc.D2qs = w.D2qs; pc.C = w.C;
     launch_gemm(pc, T, nq, ns, st);
+    launch_ldl(tv, b, w, st);
     ProbS ps; ps.tv = tv; ps.C = w.C; ps.D2qs = w.D2qs; ps.D2qq = w.D2qq; ps.S = w.S;
     launch_gemm(ps, T, nq, nq, st);
     // (reused inner stage: A^-1, alpha and the scalars of phi are in the workspace, info[] is written by the outer factor)
@@ -544,6 +560,7 @@ int predict_core(const adkf_batch_t* b, const Workspace& w, float* mean, float* 
     const int T = b->T;
     ProbC pc; pc.tv = tv; pc.Ainv = w.Ainv; pc.D2qs = w.D2qs; pc.C = w.C;
     launch_gemm(pc, T, b->nq_max, b->ns_max, st);
+    launch_ldl(tv, b, w, st);
     PredArgs pa{tv, w.C, w.D2qs, b->y_s, mean, var, w.scal, T};
     k_predict<<<grid_for(T, 1), 256, 0, st>>>(pa);
     if (cov) {

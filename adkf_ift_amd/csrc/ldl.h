@@ -1,0 +1,142 @@
+// Backward-stable replacement of  C = K_qs A^-1  and  alpha = A^-1 y  for ILL-CONDITIONED tasks.
+//
+// The pipeline keeps A^-1 explicitly (the sweep of factor.h yields it for free and the inner gradient needs all of it).
+// Products with an explicit fp32 inverse carry eps32 * cond(A) * |A^-1|, and Sigma_q = K_qq - C K_sq then loses its small
+// eigenvalues (~ noise) to an absolute error of ~1e-4: measured 2 % on f_out and 3e-3 on dL/dZ at cond(A) ~ 2e3 (noise
+// 0.01, clustered low-dimensional features), where GPyTorch's Cholesky solves are 100x closer to float64.  Everything in
+// the outer stage is a function of C and alpha (M_A = C^T Om C, M_B = -2 Om C - e alpha^T, mu = C y, Sigma_q), so solving
+//       A C^T = K_sq,   A alpha = y
+// by an LDL^T factorisation + two triangular substitutions for those tasks restores the factor-form accuracy (CPU
+// emulation: f_out 2.6e-2 -> 2.3e-4, dL/dZ 3.5e-3 -> 5e-5).  Well-conditioned tasks - every benchmark configuration -
+// leave after reading n numbers: the test is  (outputscale + noise) * max_i (A^-1)_ii > threshold,  a lower bound of cond(A).
+//
+// One workgroup (512 threads) per task, everything in LDS (n <= 128):
+//   L   [n][n+1]   lower triangle: A, then its Schur complements column by column (right-looking, ONE barrier per pivot,
+//                  columns kept unscaled until the end so that no entry is read and written in the same step)
+//   R   [n][130]   up to 128 right-hand sides at a time (alpha's y rides as the first column of the first chunk); four lanes
+//                  of one wave share a column: LDS executes a wave's accesses in order, no barrier inside the substitutions
+#pragma once
+#include "problems.h"
+
+namespace adkf {
+
+constexpr int LDL_NT = 512;
+constexpr int LDL_RC = 128;        // right-hand sides per chunk
+constexpr int LDL_RLD = LDL_RC + 2;
+constexpr float LDL_THRESHOLD = 25.f;
+
+struct LdlArgs {
+    TaskView tv;
+    const float* D2ss;   // [T, ns_ld, ns_ld]
+    const float* D2qs;   // [T, nq_ld, ns_ld]
+    const float* Ainv;   // [T, ns_ld, ns_ld]
+    const float* y_s;    // [T, ns_ld]
+    float* C;            // [T, nq_ld, ns_ld]   overwritten for flagged tasks
+    float* vecs;         // [T, NVEC, vld]      V_ALPHA overwritten for flagged tasks
+    float thresh;
+    int T;
+};
+
+inline size_t ldl_smem_bytes(int ns_ld) {
+    return sizeof(float) * ((size_t)ns_ld * (ns_ld + 1) + (size_t)ns_ld * LDL_RLD + ns_ld + 16);
+}
+
+__global__ __launch_bounds__(LDL_NT) void k_ldl_c(LdlArgs a) {
+    extern __shared__ float ldl_sm[];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    if (t >= a.T) return;
+    const int n = a.tv.ns(t), m = a.tv.nq(t), ld = a.tv.ns_ld, LD = ld + 1;
+    if (n <= 0 || m <= 0) return;
+    float* L = ldl_sm;
+    volatile float* R = ldl_sm + (size_t)ld * LD;
+    float* ipiv = ldl_sm + (size_t)ld * LD + (size_t)ld * LDL_RLD;
+    float* red = ipiv + ld;
+    const float* sc = a.tv.scal + (size_t)t * NSCAL;
+    const float os = sc[S_OS], ls = sc[S_LS], noise = sc[S_NOISE], il2 = 1.f / (ls * ls);
+    const int kind = a.tv.kind;
+
+    // ---- is this task ill-conditioned?  (os + noise) max_i (A^-1)_ii <= cond(A)
+    {
+        const float* Ai = a.Ainv + (size_t)t * ld * ld;
+        float mx = 0.f;
+        for (int i = tid; i < n; i += LDL_NT) mx = fmaxf(mx, Ai[(size_t)i * ld + i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        mx = red[0];
+        for (int w = 1; w < LDL_NT / 64; ++w) mx = fmaxf(mx, red[w]);
+        if (!((os + noise) * mx > a.thresh)) return;   // uniform over the workgroup
+    }
+
+    // ---- A (lower triangle) from the squared distances
+    const float* D2 = a.D2ss + (size_t)t * ld * ld;
+    for (int e = tid; e < n * n; e += LDL_NT) {
+        const int i = e / n, j = e - i * n;
+        if (j <= i) L[i * LD + j] = os * kappa0(kind, D2[(size_t)i * ld + j] * il2) + (i == j ? noise : 0.f);
+    }
+    __syncthreads();
+
+    // ---- right-looking LDL^T: after step k column k holds the (unscaled) Schur-complement column c_ik, L[k][k] = pivot p_k
+    {
+        const int tr = tid >> 5, tc = tid & 31;
+        for (int k = 0; k < n - 1; ++k) {
+            const float ip = 1.f / L[k * LD + k];
+            for (int i = k + 1 + tr; i < n; i += LDL_NT / 32) {
+                const float f = L[i * LD + k] * ip;
+                for (int j = k + 1 + tc; j <= i; j += 32) L[i * LD + j] -= f * L[j * LD + k];
+            }
+            __syncthreads();
+        }
+    }
+    // unit-lower factor: l_ik = c_ik / p_k;  ipiv[k] = 1 / p_k
+    for (int e = tid; e < n * n; e += LDL_NT) {
+        const int i = e / n, k = e - i * n;
+        if (k < i) L[i * LD + k] = L[i * LD + k] / L[k * LD + k];
+    }
+    __syncthreads();
+    if (tid < n) ipiv[tid] = 1.f / L[tid * LD + tid];
+    __syncthreads();
+
+    // ---- right-hand sides in chunks: column 0 of chunk 0 is y (-> alpha), the others are columns of K_sq (-> rows of C)
+    const float* Dqs = a.D2qs + (size_t)t * a.tv.nq_ld * ld;
+    const float* y = a.y_s + (size_t)t * ld;
+    float* Co = a.C + (size_t)t * a.tv.nq_ld * ld;
+    float* alpha = a.vecs + ((size_t)t * NVEC + V_ALPHA) * a.tv.vld;
+    const int total = m + 1;                      // logical right-hand sides: 0 = y, 1 + j = query j
+    for (int c0 = 0; c0 < total; c0 += LDL_RC) {
+        const int cols = min(LDL_RC, total - c0);
+        for (int e = tid; e < cols * n; e += LDL_NT) {
+            const int cc = e / n, k = e - cc * n, g = c0 + cc;
+            R[k * LDL_RLD + cc] = (g == 0) ? y[k] : os * kappa0(kind, Dqs[(size_t)(g - 1) * ld + k] * il2);
+        }
+        __syncthreads();
+        const int cc = tid >> 2, sub = tid & 3;   // four lanes of one wave per column
+        if (cc < cols) {
+            // forward: z = L^-1 b
+            for (int k = 0; k < n - 1; ++k) {
+                const float zk = R[k * LDL_RLD + cc];
+                for (int i = k + 1 + sub; i < n; i += 4) R[i * LDL_RLD + cc] = R[i * LDL_RLD + cc] - L[i * LD + k] * zk;
+            }
+            // D^-1
+            for (int k = sub; k < n; k += 4) R[k * LDL_RLD + cc] = R[k * LDL_RLD + cc] * ipiv[k];
+            // backward: x = L^-T z
+            for (int k = n - 2; k >= 0; --k) {
+                float s = 0.f;
+                for (int i = k + 1 + sub; i < n; i += 4) s += L[i * LD + k] * R[i * LDL_RLD + cc];
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                if (sub == 0) R[k * LDL_RLD + cc] = R[k * LDL_RLD + cc] - s;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < cols * n; e += LDL_NT) {
+            const int c2 = e / n, k = e - c2 * n, g = c0 + c2;
+            const float x = R[k * LDL_RLD + c2];
+            if (g == 0) alpha[k] = x; else Co[(size_t)(g - 1) * ld + k] = x;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace adkf

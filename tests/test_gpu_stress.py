@@ -82,12 +82,11 @@ def test_random_shapes_against_the_oracle(dev):
                    "pred_mean": mean[t, :m].cpu().numpy(), "pred_var": var[t, :m].cpu().numpy()}
             # Tolerance.  Well-conditioned tasks (cond(A), cond(Sigma_q) <= 100: every BASELINE configuration, noise 0.1 or
             # high-dimensional features): 1e-4, or 4x the error of the SAME restatement run in float32 on the CPU where
-            # plain float32 cannot do better.  Ill-conditioned tasks (noise ~0.01 with clustered low-dimensional
-            # features): the library forms A^-1 and Sigma_q^-1 EXPLICITLY in fp32, so products such as K_qs A^-1 K_sq
-            # carry eps32 |A^-1| |K|^2 where a Cholesky-factor formulation carries eps32 sqrt(cond) - a known accuracy
-            # deficit ("numerical envelope": at cond ~ 2e3 the cancelling grad_phi f_out can be 30 % off
-            # and dL/dZ 10 % where float32 Cholesky arithmetic is 0.2 % off).  There only a coarse guard on the outputs is
-            # asserted (50 %), and the worst ratios are printed.
+            # plain float32 cannot do better.  Ill-conditioned tasks (noise ~0.01 with clustered low-dimensional features,
+            # cond ~ 2e3): 2e-3 - the explicit fp32 inverses of the pipeline used to lose 2 % on f_out and 5-10 % on dL/dZ
+            # there; csrc/ldl.h re-solves C = K_qs A^-1 and alpha through an LDL^T factorisation for such tasks
+            # ("numerical envelope"); Sigma_q^-1 is still the explicit inverse of the sweep, whose error
+            # grows with cond(Sigma_q) (1.3e-3 on dL/dZ_q at cond 2.9e3), hence the linear factor beyond 1e3.
             noise, os_, ls = O.transform_phi(phi[t].double().cpu())
             A = O.kernel_matrix(zs.double(), zs.double(), os_, ls, kind) + noise * torch.eye(n, dtype=torch.float64)
             cond = max(float(torch.linalg.cond(A)), float(np.linalg.cond(q["pred_cov"])))
@@ -102,22 +101,27 @@ def test_random_shapes_against_the_oracle(dev):
             # (seen: |g| = 0.046 at f_out = 9.9), and the explicit A^-1 of the sweep carries eps32 * cond(A) into each of
             # them: g_out is held to 1e-4 of max(|g_out|, 0.01 |f_out|), and v = H^-1 g_out to what that allows.
             g_floor = 1e-2 * abs(q["f_out"])
-            slack = {"g_out": max(1.0, g_floor / np.abs(q["g_out"]).max()),
+            # f_out = (quad + logdet + m log 2pi) / 2 is itself a sum that can cancel (seen: 0.55 from terms of 58, -114, 57):
+            # its error is measured against the size of the terms
+            ld_q = float(np.linalg.slogdet(q["pred_cov"])[1])
+            quad = 2.0 * q["f_out"] - ld_q - m * math.log(2.0 * math.pi)
+            terms = 0.5 * (abs(quad) + abs(ld_q) + m * math.log(2.0 * math.pi))
+            slack = {"f_out": max(1.0, terms / abs(q["f_out"])),
+                     "g_out": max(1.0, g_floor / np.abs(q["g_out"]).max()),
                      "v": max(1.0, np.abs(np.linalg.inv(q["H"])).sum(1).max() * g_floor / np.abs(q["v"]).max())}
             for k, v in got.items():
                 e = _rel(v, q[k])
                 e32 = _rel(q32[k], q[k])
-                tol = max(TOL * slack.get(k, 1.0) * (condH if k in ("v", "dZs_total") else 1.0), 4.0 * e32) if well else 0.5
+                tol = max((TOL if well else 20.0 * TOL * max(1.0, cond / 1e3)) * slack.get(k, 1.0) * (condH if k in ("v", "dZs_total") else 1.0), 4.0 * e32)
                 worst[k] = max(worst.get(k, 0.0), e / tol)
                 if e > 0.1 * TOL:
                     kk = ("well " if well else "ill ") + k
-                    worst32[kk] = max(worst32.get(kk, (0.0, 0.0)), (float("%.1f" % (e / max(e32, 1e-12))), float("%.1e" % e)))
-                if well or k in ("f_in", "H", "dZs_total", "dZq_total", "pred_mean"):
-                    assert e <= (tol if well else 0.5), (desc, t, k, e, e32, cond)
+                    worst32[kk] = max(worst32.get(kk, 0.0), float("%.1e" % e))
+                assert e <= tol, (desc, t, k, e, e32, cond)
             assert float(out["dZ_s"][t, n:].abs().max() if n < N else 0.0) == 0.0, desc
             assert float(out["dZ_q"][t, m:].abs().max() if m < Nq else 0.0) == 0.0, desc
     print("worst error / tolerance:", {k: float("%.2f" % v) for k, v in worst.items()})
-    print("worst (error / float32-torch error, error) where error > 1e-5:", worst32)
+    print("worst relative error by regime (where > 1e-5):", worst32)
 
 
 @pytest.mark.parametrize("kernel, regression, exact", [("rbf", False, True), ("matern", True, True), ("matern", False, False)])
