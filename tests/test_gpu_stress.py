@@ -159,3 +159,34 @@ def test_long_training_runs_stay_finite(dev, kernel, regression, exact):
     assert not bool(spy.acc.any()), spy.acc.tolist()
     assert bool(torch.isfinite(W).all())
     assert last < first, (first, last)     # and the outer objective went down
+
+
+def test_ill_conditioned_regression_task_is_resolved_stably(dev):
+    """16 support / 31 query points in TWO dimensions with regression noise ~0.01: cond(A) = 1.3e3.  With the explicit fp32
+    inverse alone this task had f_out off by 2.2e-2 and dL/dZ by 3e-3; the LDL^T re-solve of C and alpha (csrc/ldl.h) brings
+    them to ~1e-3 / 1e-4 (f_out = 0.55 is itself a cancellation of terms of size 58, -114 and 57)."""
+    from adkf_ift_amd import gp_ops
+    from adkf_ift_amd.synthetic import make_tasks
+    from oracle import gp_oracle as O
+
+    tasks = make_tasks(3, 16, 2, N_q=64, regression=True, first_task=1800)
+    Zs, Zq = tasks.features()
+    t, n, m = 1, 15, 31
+    zs, ys, zq, yq = Zs[t, :n].contiguous(), tasks.y_s[t, :n].contiguous(), Zq[t, :m].contiguous(), tasks.y_q[t, :m].contiguous()
+    b = gp_ops.GPBatch(zs[None].to(dev), ys[None].to(dev), torch.empty(1, 4, device=dev), "rbf", Z_q=zq[None].to(dev), y_q=yq[None].to(dev))
+    phi0, _ = gp_ops.init_params_batch(b, True, True)
+    phi, _, _, _, info = gp_ops.fit(b, phi0, 200)
+    gp_ops.check_info(info)
+    out = gp_ops.ift_hypergrad(b, phi)
+    gp_ops.check_info(out["info"])
+    _, opri = O.init_phi(zs.double(), True, True)
+    q = O.full_reference_quantities(zs, ys, zq, yq, phi[0].double().cpu(), opri, 0)
+    noise, os_, ls = O.transform_phi(phi[0].double().cpu())
+    A = O.kernel_matrix(zs.double(), zs.double(), os_, ls, 0) + noise * torch.eye(n, dtype=torch.float64)
+    assert float(torch.linalg.cond(A)) > 500.0          # the regime this test is about
+    assert abs(out["f_out"][0].item() - q["f_out"]) <= 5e-3 * abs(q["f_out"])
+    assert _rel(out["dZ_s"][0].cpu().numpy(), q["dZs_total"]) <= 1e-3
+    assert _rel(out["dZ_q"][0].cpu().numpy(), q["dZq_total"]) <= 1e-3
+    mean, var, _, _ = gp_ops.predict(b, phi)
+    assert _rel(mean[0].cpu().numpy(), q["pred_mean"]) <= 2e-4
+    assert _rel(var[0].cpu().numpy(), q["pred_var"]) <= 2e-4
