@@ -129,13 +129,14 @@ inline bool has_query(const adkf_batch_t* b) { return b->nq_max > 0 && b->Z_q !=
 
 // Stage A: centring, row norms, squared distances.  Skipped when the caller promises (ADKF_BATCH_REUSE_DIST) that
 // this workspace already holds them for exactly this batch.
-// parts: 1 = the support block (mean, norms, D2ss), 2 = the query blocks (needs the support mean / norms in place).
+// parts: 1 = the support block (mean, norms, D2ss), 2 = the query blocks (needs the support mean / norms in place),
+// 4 = the features are already centred and w.mean holds zeros (ARD: Z~ = (Z - mu) / l has zero column mean by construction).
 int stage_dist(const adkf_batch_t* b, const Workspace& w, bool with_query, hipStream_t st, int parts = 3) {
     if (b->flags & ADKF_BATCH_REUSE_DIST) return 0;
     const int T = b->T, ns = b->ns_max, nq = with_query ? b->nq_max : 0, d = b->d;
     if (!(parts & 2)) with_query = false;
     if (parts & 1) {
-        k_colmean<<<dim3(ceil_div(d, 64), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, T);
+        if (!(parts & 4)) k_colmean<<<dim3(ceil_div(d, 64), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, T);
         k_rownorm<<<dim3(ceil_div(ns, 4), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, w.nrm_s, T);
     }
     if (with_query) k_rownorm<<<dim3(ceil_div(nq, 4), T), 256, 0, st>>>(b->Z_q, b->n_q, nq, d, w.mean, w.nrm_q, T);
@@ -450,6 +451,7 @@ int ard_setup(const adkf_batch_t* b, void* ws, size_t ws_bytes, hipStream_t st, 
     c.bt.Z_s = c.a.Zt_s; c.bt.Z_q = has_query(b) ? c.a.Zt_q : nullptr; c.bt.priors = c.a.pri3; c.bt.flags = 0;
     if (!(b->flags & ADKF_BATCH_REUSE_INNER))
         k_colmean<<<dim3(ceil_div(c.d, 64), c.T), 256, 0, st>>>(b->Z_s, b->n_s, c.ns, c.d, c.a.mu, c.T);
+    hipMemsetAsync(c.w.mean, 0, sizeof(float) * (size_t)c.T * c.d, st);   // the scaled features are centred already (stage_dist parts bit 4)
     return 0;
 }
 
@@ -469,15 +471,16 @@ int ard_eval(ArdCtx& c, const float* x, float* f, float* g, int32_t* info3) {
     hipStream_t st = c.st;
     k_ard_params<<<dim3(ceil_div(c.d, 256), c.T), 256, 0, st>>>(c.v, x);
     k_ard_scale<<<dim3(ceil_div(c.d, 256), c.ns, c.T), 256, 0, st>>>(c.v, c.b->Z_s, c.a.Zt_s, c.b->n_s, c.ns);
-    int rc = stage_dist(&c.bt, c.w, false, st, 1);
+    int rc = stage_dist(&c.bt, c.w, false, st, 1 | 4);
     if (rc) return rc;
     InnerArgs ia = inner_args(&c.bt, c.w, c.a.phi3, info3);
     ia.f_out = c.a.f3; ia.g_out = c.a.g3;
     rc = launch_inner(ia, c.w, st);
     if (rc) return rc;
     TaskView tv = make_tv(&c.bt, c.w, false);
-    WinArgs wa{tv, c.w.Ainv, c.w.D2ss, c.w.Wss, c.w.scal, c.T};
-    k_win<<<grid_for(c.T, 1), 256, 0, st>>>(wa);
+    const int win_tiles = std::max(1, std::min(64, c.ns * c.ns / 2048));
+    WinArgs wa{tv, c.w.Ainv, c.w.D2ss, c.w.Wss, c.w.scal, c.T, win_tiles};
+    k_win<<<grid_for(c.T, win_tiles), 256, 0, st>>>(wa);
     ard_dz_support(c, c.w.Wss, c.a.G);
     ArdColdot cd{c.a.Zt_s, c.a.G, c.b->n_s, c.ns, nullptr, nullptr, nullptr, 0, c.a.S1, c.d};
     k_ard_coldot<<<dim3(ceil_div(c.d, 64), c.T), 256, 0, st>>>(cd);
@@ -584,7 +587,7 @@ int ard_outer(ArdCtx& c, const float* phi, int flags, float* f_out, int32_t* inf
         hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)c.T, st);
     }
     k_ard_scale<<<dim3(ceil_div(c.d, 256), c.nq, c.T), 256, 0, st>>>(c.v, c.b->Z_q, c.a.Zt_q, c.b->n_q, c.nq);
-    rc = stage_dist(&c.bt, c.w, true, st, 2);
+    rc = stage_dist(&c.bt, c.w, true, st, 2 | 4);
     if (rc) return rc;
     if (!want_grads) return 0;
     adkf_batch_t bq = c.bt;
@@ -749,8 +752,9 @@ int adkf_mll_value_grad(const adkf_batch_t* b, const float* phi, float* f_in, fl
     if (rc) return rc;
     if (dZ_s) {
         TaskView tv = make_tv(b, w, false);
-        WinArgs wa{tv, w.Ainv, w.D2ss, w.Wss, w.scal, b->T};
-        k_win<<<grid_for(b->T, 1), 256, 0, st>>>(wa);
+        const int win_tiles = std::max(1, std::min(64, b->ns_max * b->ns_max / 2048));
+        WinArgs wa{tv, w.Ainv, w.D2ss, w.Wss, w.scal, b->T, win_tiles};
+        k_win<<<grid_for(b->T, win_tiles), 256, 0, st>>>(wa);
         RowsumArgs ra{tv, w.Wss, nullptr, nullptr, w.vecs, b->T};
         launch_rowsums(ra, w, st);
         hipMemsetAsync(dZ_s, 0, (size_t)b->T * b->ns_max * b->d * sizeof(float), st);

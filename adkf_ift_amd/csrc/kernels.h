@@ -358,11 +358,12 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
 }
 
 // ---- W_ss for d f_in / dZ:  Q . s kappa'/l^2,  Q = (Ainv - alpha alpha^T) / (2n) -------------------------
-struct WinArgs { TaskView tv; const float* Ainv; const float* D2ss; float* Wss; const float* scal; int T; };
+struct WinArgs { TaskView tv; const float* Ainv; const float* D2ss; float* Wss; const float* scal; int T; int tiles; };
 
+// `tiles` workgroups per task (one per task was 46 us at 256 x 128^2 - an element-wise pass should not be latency-bound)
 __global__ __launch_bounds__(256) void k_win(WinArgs a) {
     int t, tile;
-    if (!task_tile(a.T, 1, t, tile)) return;
+    if (!task_tile(a.T, a.tiles, t, tile)) return;
     const int n = a.tv.ns(t), ld = a.tv.ns_ld;
     const float* sc = a.scal + (size_t)t * NSCAL;
     const float os = sc[S_OS], ls = sc[S_LS], il2 = 1.f / (ls * ls);
@@ -370,10 +371,11 @@ __global__ __launch_bounds__(256) void k_win(WinArgs a) {
     const float* D2 = a.D2ss + (size_t)t * ld * ld;
     const float* al = a.tv.vec_ptr(t, V_ALPHA);
     float* Wo = a.Wss + (size_t)t * ld * ld;
-    for (int e = threadIdx.x; e < n * n; e += 256) {
+    const float cf = 0.5f / (float)n * os * il2;
+    for (int e = tile * 256 + threadIdx.x; e < n * n; e += 256 * a.tiles) {
         const int i = e / n, j = e - i * n;
         float k0, k1, k2; kappa3(a.tv.kind, D2[(size_t)i * ld + j] * il2, k0, k1, k2);
-        Wo[(size_t)i * ld + j] = 0.5f * (Ai[(size_t)i * ld + j] - al[i] * al[j]) / (float)n * os * k1 * il2;
+        Wo[(size_t)i * ld + j] = (Ai[(size_t)i * ld + j] - al[i] * al[j]) * cf * k1;
     }
 }
 
