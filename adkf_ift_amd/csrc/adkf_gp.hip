@@ -130,16 +130,17 @@ inline bool has_query(const adkf_batch_t* b) { return b->nq_max > 0 && b->Z_q !=
 // Stage A: centring, row norms, squared distances.  Skipped when the caller promises (ADKF_BATCH_REUSE_DIST) that
 // this workspace already holds them for exactly this batch.
 // parts: 1 = the support block (mean, norms, D2ss), 2 = the query blocks (needs the support mean / norms in place),
-// 4 = the features are already centred and w.mean holds zeros (ARD: Z~ = (Z - mu) / l has zero column mean by construction).
+// 4 = the features are already centred and w.mean holds zeros (ARD: Z~ = (Z - mu) / l has zero column mean by construction),
+// 8 / 16 = the support / query row norms are already in w.nrm_s / w.nrm_q (ARD: k_ard_scale_norm wrote them).
 int stage_dist(const adkf_batch_t* b, const Workspace& w, bool with_query, hipStream_t st, int parts = 3) {
     if (b->flags & ADKF_BATCH_REUSE_DIST) return 0;
     const int T = b->T, ns = b->ns_max, nq = with_query ? b->nq_max : 0, d = b->d;
     if (!(parts & 2)) with_query = false;
     if (parts & 1) {
         if (!(parts & 4)) k_colmean<<<dim3(ceil_div(d, 64), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, T);
-        k_rownorm<<<dim3(ceil_div(ns, 4), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, w.nrm_s, T);
+        if (!(parts & 8)) k_rownorm<<<dim3(ceil_div(ns, 4), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, w.nrm_s, T);
     }
-    if (with_query) k_rownorm<<<dim3(ceil_div(nq, 4), T), 256, 0, st>>>(b->Z_q, b->n_q, nq, d, w.mean, w.nrm_q, T);
+    if (with_query && !(parts & 16)) k_rownorm<<<dim3(ceil_div(nq, 4), T), 256, 0, st>>>(b->Z_q, b->n_q, nq, d, w.mean, w.nrm_q, T);
     ProbDist p;
     p.mean = w.mean; p.d = d; p.vec = vec_ok(b, w);
     if (parts & 1) {
@@ -470,8 +471,8 @@ void ard_dz_support(ArdCtx& c, const float* W, float* out, const int32_t* n_over
 int ard_eval(ArdCtx& c, const float* x, float* f, float* g, int32_t* info3) {
     hipStream_t st = c.st;
     k_ard_params<<<dim3(ceil_div(c.d, 256), c.T), 256, 0, st>>>(c.v, x);
-    k_ard_scale<<<dim3(ceil_div(c.d, 256), c.ns, c.T), 256, 0, st>>>(c.v, c.b->Z_s, c.a.Zt_s, c.b->n_s, c.ns);
-    int rc = stage_dist(&c.bt, c.w, false, st, 1 | 4);
+    k_ard_scale_norm<<<dim3(ceil_div(c.ns, 4), c.T), 256, 0, st>>>(c.v, c.b->Z_s, c.a.Zt_s, c.b->n_s, c.ns, c.w.nrm_s);
+    int rc = stage_dist(&c.bt, c.w, false, st, 1 | 4 | 8);
     if (rc) return rc;
     InnerArgs ia = inner_args(&c.bt, c.w, c.a.phi3, info3);
     ia.f_out = c.a.f3; ia.g_out = c.a.g3;
@@ -586,8 +587,8 @@ int ard_outer(ArdCtx& c, const float* phi, int flags, float* f_out, int32_t* inf
     } else {
         hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)c.T, st);
     }
-    k_ard_scale<<<dim3(ceil_div(c.d, 256), c.nq, c.T), 256, 0, st>>>(c.v, c.b->Z_q, c.a.Zt_q, c.b->n_q, c.nq);
-    rc = stage_dist(&c.bt, c.w, true, st, 2 | 4);
+    k_ard_scale_norm<<<dim3(ceil_div(c.nq, 4), c.T), 256, 0, st>>>(c.v, c.b->Z_q, c.a.Zt_q, c.b->n_q, c.nq, c.w.nrm_q);
+    rc = stage_dist(&c.bt, c.w, true, st, 2 | 4 | 16);
     if (rc) return rc;
     if (!want_grads) return 0;
     adkf_batch_t bq = c.bt;

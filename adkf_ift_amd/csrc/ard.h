@@ -75,13 +75,22 @@ __global__ __launch_bounds__(256) void k_ard_params(ArdView a, const float* x) {
     }
 }
 
-// Zt = (Z - mu) / ell  (rows beyond n are zeroed);  grid: (ceil(d / 256), rows, T)
-__global__ __launch_bounds__(256) void k_ard_scale(ArdView a, const float* Z, float* Zt, const int32_t* n_arr, int ld) {
-    const int t = blockIdx.z, i = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= a.d) return;
+// Zt = (Z - mu) / ell (rows beyond n are zeroed) with the squared row norms of Zt alongside (what k_rownorm would compute
+// against a zero mean): one wave per row, grid (ceil(ld / 4), T).
+__global__ __launch_bounds__(256) void k_ard_scale_norm(ArdView a, const float* Z, float* Zt, const int32_t* n_arr, int ld, float* nrm) {
+    const int t = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= ld) return;
     const int n = n_arr ? n_arr[t] : ld;
-    const size_t o = ((size_t)t * ld + i) * a.d + k;
-    Zt[o] = i < n ? (Z[o] - a.mu[(size_t)t * a.d + k]) / a.ell[(size_t)t * a.d + k] : 0.f;
+    const size_t o = ((size_t)t * ld + i) * a.d;
+    const float *mu = a.mu + (size_t)t * a.d, *el = a.ell + (size_t)t * a.d;
+    float s = 0.f;
+    for (int k = lane; k < a.d; k += 64) {
+        const float v = i < n ? (Z[o + k] - mu[k]) / el[k] : 0.f;
+        Zt[o + k] = v;
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if (lane == 0) nrm[(size_t)t * ld + i] = s;
 }
 
 // out[k] = sum_i A_ik B_ik over the rows of one task (64 columns x 4 row groups; grid: ceil(d / 64) x T); optional second
