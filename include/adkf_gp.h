@@ -89,7 +89,8 @@ typedef struct adkf_batch {
 
 typedef struct adkf_fit_options {
     int32_t max_evals; /* hard cap on MLL value+gradient evaluations per task (SciPy maxfun) */
-    int32_t exact_evals; /* != 0: spend exactly max_evals evaluations (benchmark mode, deterministic work) */
+    int32_t exact_evals; /* != 0: spend exactly max_evals evaluations (benchmark mode, deterministic work): same stopping
+                          * rules, but a converged task re-evaluates at its optimum until the budget is used up */
     float gtol;        /* stop when max|grad| <= gtol          (SciPy L-BFGS-B pgtol, default 1e-5) */
     float ftol;        /* stop when rel. decrease <= ftol      (SciPy factr*eps: 2.22e-9 is the reference setting) */
     void* ev_start;    /* optional hipEvent_t recorded on `stream` immediately before the optimiser kernel */
