@@ -2,6 +2,7 @@
 // carving and the kernel pipeline of each entry point.  gfx950 only; no allocation, no synchronisation
 // (except adkf_check_info), everything enqueued on the caller's stream.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "../../include/adkf_gp.h"
 #include "ard.h"
@@ -268,7 +269,12 @@ void launch_ldl(const TaskView& tv, const adkf_batch_t* b, const Workspace& w, h
                                    (int)ldl_smem_bytes(REG_POINTS)) == hipSuccess;
     }();
     (void)attr_set;
-    LdlArgs la{tv, w.D2ss, w.D2qs, w.Ainv, b->y_s, w.C, w.vecs, LDL_THRESHOLD, b->T};
+    // ADKF_LDL_THRESHOLD (read once) moves the switch-over for experiments: 0 re-solves every task, a huge value none
+    static const float thresh = [] {
+        const char* e = getenv("ADKF_LDL_THRESHOLD");
+        return e ? (float)atof(e) : LDL_THRESHOLD;
+    }();
+    LdlArgs la{tv, w.D2ss, w.D2qs, w.Ainv, b->y_s, w.C, w.vecs, thresh, b->T};
     k_ldl_c<<<b->T, LDL_NT, smem, st>>>(la);
 }
 

@@ -10,19 +10,19 @@
 // emulation: f_out 2.6e-2 -> 2.3e-4, dL/dZ 3.5e-3 -> 5e-5).  Well-conditioned tasks - every benchmark configuration -
 // leave after reading n numbers: the test is  (outputscale + noise) * max_i (A^-1)_ii > threshold,  a lower bound of cond(A).
 //
-// One workgroup (512 threads) per task, everything in LDS (n <= 128):
+// One workgroup (576 threads) per task, everything in LDS (n <= 128):
 //   L   [n][n+1]   lower triangle: A, then its Schur complements column by column (right-looking, ONE barrier per pivot,
 //                  columns kept unscaled until the end so that no entry is read and written in the same step)
-//   R   [n][130]   up to 128 right-hand sides at a time (alpha's y rides as the first column of the first chunk); four lanes
-//                  of one wave share a column: LDS executes a wave's accesses in order, no barrier inside the substitutions
+//   R   [n][130]   up to 129 right-hand sides at a time (alpha's y rides as the first column of the first chunk); four or more
+//                  lanes of one wave share a column: LDS executes a wave's accesses in order, no barrier inside the substitutions
 #pragma once
 #include "problems.h"
 
 namespace adkf {
 
-constexpr int LDL_NT = 512;
-constexpr int LDL_RC = 128;        // right-hand sides per chunk
-constexpr int LDL_RLD = LDL_RC + 2;
+constexpr int LDL_NT = 576;        // eight waves share columns 0..127 of a chunk, the ninth takes column 128 by itself
+constexpr int LDL_RC = 129;        // right-hand sides per chunk: y + 128 query points go through in ONE pass
+constexpr int LDL_RLD = LDL_RC + 1;
 constexpr float LDL_THRESHOLD = 25.f;
 
 struct LdlArgs {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(LDL_NT) void k_ldl_c(LdlArgs a) {
     const int n = a.tv.ns(t), m = a.tv.nq(t), ld = a.tv.ns_ld, LD = ld + 1;
     if (n <= 0 || m <= 0) return;
     float* L = ldl_sm;
-    volatile float* R = ldl_sm + (size_t)ld * LD;
+    float* R = ldl_sm + (size_t)ld * LD;
     float* ipiv = ldl_sm + (size_t)ld * LD + (size_t)ld * LDL_RLD;
     float* red = ipiv + ld;
     const float* sc = a.tv.scal + (size_t)t * NSCAL;
@@ -84,7 +84,15 @@ __global__ __launch_bounds__(LDL_NT) void k_ldl_c(LdlArgs a) {
             const float ip = 1.f / L[k * LD + k];
             for (int i = k + 1 + tr; i < n; i += LDL_NT / 32) {
                 const float f = L[i * LD + k] * ip;
-                for (int j = k + 1 + tc; j <= i; j += 32) L[i * LD + j] -= f * L[j * LD + k];
+                int j = k + 1 + tc;
+                for (; j + 96 <= i; j += 128) {           // four independent entries in flight
+                    float c[4], v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { c[u] = L[(j + 32 * u) * LD + k]; v[u] = L[i * LD + j + 32 * u]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) L[i * LD + j + 32 * u] = fmaf(-f, c[u], v[u]);
+                }
+                for (; j <= i; j += 32) L[i * LD + j] -= f * L[j * LD + k];
             }
             __syncthreads();
         }
@@ -111,22 +119,53 @@ __global__ __launch_bounds__(LDL_NT) void k_ldl_c(LdlArgs a) {
             R[k * LDL_RLD + cc] = (g == 0) ? y[k] : os * kappa0(kind, Dqs[(size_t)(g - 1) * ld + k] * il2);
         }
         __syncthreads();
-        const int cc = tid >> 2, sub = tid & 3;   // four lanes of one wave per column
+        // lanes per column: 4 for a full chunk, up to a whole wave when few columns are left (the substitutions are n
+        // dependent steps whatever the width, so a narrow tail must not run on four lanes); the ninth wave serves column 128
+        int lpc, cc, sub;
+        if (tid >= 512) {
+            lpc = 64; cc = 128; sub = tid - 512;
+        } else {
+            const int cm = min(cols, 128);
+            lpc = 4;
+            while (lpc < 64 && cm * lpc * 2 <= 512) lpc *= 2;
+            cc = tid / lpc; sub = tid % lpc;
+            if (cc >= cm) cc = LDL_RC;        // idle
+        }
+        float* Rp = R;
         if (cc < cols) {
-            // forward: z = L^-1 b
+            // forward: z = L^-1 b.  Lanes of one column sit in one wave, which executes its LDS accesses in order: the
+            // compiler barrier keeps the z_k load behind the stores of the previous step, nothing else is needed.
             for (int k = 0; k < n - 1; ++k) {
-                const float zk = R[k * LDL_RLD + cc];
-                for (int i = k + 1 + sub; i < n; i += 4) R[i * LDL_RLD + cc] = R[i * LDL_RLD + cc] - L[i * LD + k] * zk;
+                asm volatile("" ::: "memory");
+                const float zk = Rp[k * LDL_RLD + cc];
+                int i = k + 1 + sub;
+                for (; i + 7 * lpc < n; i += 8 * lpc) {   // eight independent rows in flight
+                    float r[8], l[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { r[u] = Rp[(i + u * lpc) * LDL_RLD + cc]; l[u] = L[(i + u * lpc) * LD + k]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) Rp[(i + u * lpc) * LDL_RLD + cc] = fmaf(-l[u], zk, r[u]);
+                }
+                for (; i < n; i += lpc) Rp[i * LDL_RLD + cc] -= L[i * LD + k] * zk;
             }
+            asm volatile("" ::: "memory");
             // D^-1
-            for (int k = sub; k < n; k += 4) R[k * LDL_RLD + cc] = R[k * LDL_RLD + cc] * ipiv[k];
+            for (int k = sub; k < n; k += lpc) Rp[k * LDL_RLD + cc] *= ipiv[k];
             // backward: x = L^-T z
             for (int k = n - 2; k >= 0; --k) {
+                asm volatile("" ::: "memory");
                 float s = 0.f;
-                for (int i = k + 1 + sub; i < n; i += 4) s += L[i * LD + k] * R[i * LDL_RLD + cc];
-                s += __shfl_xor(s, 1, 64);
-                s += __shfl_xor(s, 2, 64);
-                if (sub == 0) R[k * LDL_RLD + cc] = R[k * LDL_RLD + cc] - s;
+                int i = k + 1 + sub;
+                for (; i + 7 * lpc < n; i += 8 * lpc) {
+                    float r[8], l[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { r[u] = Rp[(i + u * lpc) * LDL_RLD + cc]; l[u] = L[(i + u * lpc) * LD + k]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s = fmaf(l[u], r[u], s);
+                }
+                for (; i < n; i += lpc) s += L[i * LD + k] * Rp[i * LDL_RLD + cc];
+                for (int o = lpc >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                if (sub == 0) Rp[k * LDL_RLD + cc] -= s;
             }
         }
         __syncthreads();
