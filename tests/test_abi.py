@@ -69,3 +69,35 @@ def test_cpu_tensors_are_refused():
 
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         gp_ops.GPBatch(torch.zeros(1, 4, 2), torch.zeros(1, 4), torch.zeros(1, 4))
+
+
+def test_ctypes_signatures_agree_with_the_header(lib):
+    """Every ctypes prototype in adkf_ift_amd/_lib.py has the argument count AND the scalar classes (pointer / integer /
+    float / double) of the C declaration - a float passed where the header says double would be silently misread."""
+    import ctypes as C
+
+    from adkf_ift_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "adkf_gp.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    protos = dict(re.findall(r"\b(adkf_[a-z_]+)\s*\(([^)]*)\)\s*;", header))
+    assert set(protos) == set(_lib.SIGNATURES)
+
+    def c_class(decl):
+        decl = decl.strip()
+        if decl in ("void", ""):
+            return None
+        if "*" in decl:
+            return "ptr"
+        ty = decl.rsplit(" ", 1)[0].replace("const", "").strip()
+        return {"int32_t": "i32", "int": "i32", "int64_t": "i64", "size_t": "size", "float": "f32", "double": "f64"}[ty]
+
+    def py_class(t):
+        if t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and issubclass(t, C._Pointer)):
+            return "ptr"
+        return {C.c_int32: "i32", C.c_int: "i32", C.c_int64: "i64", C.c_size_t: "size", C.c_float: "f32", C.c_double: "f64"}[t]
+
+    for name, args in protos.items():
+        want = [c for c in (c_class(a) for a in args.split(",")) if c is not None]
+        got = [py_class(t) for t in _lib.SIGNATURES[name][1]]
+        assert want == got, (name, want, got)
