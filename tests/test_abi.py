@@ -101,3 +101,24 @@ def test_ctypes_signatures_agree_with_the_header(lib):
         want = [c for c in (c_class(a) for a in args.split(",")) if c is not None]
         got = [py_class(t) for t in _lib.SIGNATURES[name][1]]
         assert want == got, (name, want, got)
+
+
+def test_ctypes_structs_mirror_the_header():
+    """adkf_batch_t / adkf_fit_options_t: same field names, order and scalar classes as the ctypes.Structure mirrors."""
+    import ctypes as C
+
+    from adkf_ift_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "adkf_gp.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    for cname, mirror in (("adkf_batch", _lib.Batch), ("adkf_fit_options", _lib.FitOptions)):
+        body = re.search(r"typedef struct %s\s*\{(.*?)\}" % cname, header, flags=re.S).group(1)
+        fields = []
+        for decl in (d.strip() for d in body.split(";")):
+            if not decl:
+                continue
+            name = re.findall(r"[A-Za-z_0-9]+", decl)[-1]
+            kind = "ptr" if "*" in decl else {"int32_t": "i32", "float": "f32"}[decl.split()[0]]
+            fields.append((name, kind))
+        got = [(n, "ptr" if t is C.c_void_p else {C.c_int32: "i32", C.c_float: "f32"}[t]) for n, t in mirror._fields_]
+        assert fields == got, (cname, fields, got)
