@@ -133,39 +133,85 @@ __global__ __launch_bounds__(LDL_NT) void k_ldl_c(LdlArgs a) {
         }
         float* Rp = R;
         if (cc < cols) {
-            // forward: z = L^-1 b.  Lanes of one column sit in one wave, which executes its LDS accesses in order: the
-            // compiler barrier keeps the z_k load behind the stores of the previous step, nothing else is needed.
-            for (int k = 0; k < n - 1; ++k) {
+            // forward: z = L^-1 b, FOUR pivots per pass over the column (the substitutions are LDS-throughput-bound: per row
+            // and 4 pivots this reads R once, L four times and writes R once instead of 12 accesses).  Lanes of one column sit
+            // in one wave, which executes its LDS accesses in order: the compiler barriers keep each pass behind the stores of
+            // the previous one, nothing else is needed.
+            float* Rc = Rp + cc;
+            int k = 0;
+            for (; k + 4 <= n; k += 4) {
                 asm volatile("" ::: "memory");
-                const float zk = Rp[k * LDL_RLD + cc];
-                int i = k + 1 + sub;
-                for (; i + 7 * lpc < n; i += 8 * lpc) {   // eight independent rows in flight
-                    float r[8], l[8];
+                const float* L1 = L + (k + 1) * LD + k; const float* L2 = L + (k + 2) * LD + k; const float* L3 = L + (k + 3) * LD + k;
+                const float z0 = Rc[k * LDL_RLD];
+                const float z1 = Rc[(k + 1) * LDL_RLD] - L1[0] * z0;
+                const float z2 = Rc[(k + 2) * LDL_RLD] - L2[0] * z0 - L2[1] * z1;
+                const float z3 = Rc[(k + 3) * LDL_RLD] - L3[0] * z0 - L3[1] * z1 - L3[2] * z2;
+                asm volatile("" ::: "memory");
+                if (sub == 0) { Rc[(k + 1) * LDL_RLD] = z1; Rc[(k + 2) * LDL_RLD] = z2; Rc[(k + 3) * LDL_RLD] = z3; }
+                int i = k + 4 + sub;
+                for (; i + 3 * lpc < n; i += 4 * lpc) {   // four independent rows in flight
+                    float r[4], l[4][4];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { r[u] = Rp[(i + u * lpc) * LDL_RLD + cc]; l[u] = L[(i + u * lpc) * LD + k]; }
+                    for (int u = 0; u < 4; ++u) {
+                        r[u] = Rc[(i + u * lpc) * LDL_RLD];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) Rp[(i + u * lpc) * LDL_RLD + cc] = fmaf(-l[u], zk, r[u]);
+                        for (int q = 0; q < 4; ++q) l[u][q] = L[(i + u * lpc) * LD + k + q];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        Rc[(i + u * lpc) * LDL_RLD] = r[u] - (l[u][0] * z0 + l[u][1] * z1) - (l[u][2] * z2 + l[u][3] * z3);
                 }
-                for (; i < n; i += lpc) Rp[i * LDL_RLD + cc] -= L[i * LD + k] * zk;
+                for (; i < n; i += lpc) {
+                    const float* Li = L + i * LD + k;
+                    Rc[i * LDL_RLD] -= (Li[0] * z0 + Li[1] * z1) + (Li[2] * z2 + Li[3] * z3);
+                }
+            }
+            for (; k < n - 1; ++k) {                      // the last n mod 4 pivots
+                asm volatile("" ::: "memory");
+                const float zk = Rc[k * LDL_RLD];
+                for (int i = k + 1 + sub; i < n; i += lpc) Rc[i * LDL_RLD] -= L[i * LD + k] * zk;
             }
             asm volatile("" ::: "memory");
             // D^-1
-            for (int k = sub; k < n; k += lpc) Rp[k * LDL_RLD + cc] *= ipiv[k];
-            // backward: x = L^-T z
-            for (int k = n - 2; k >= 0; --k) {
+            for (int q = sub; q < n; q += lpc) Rc[q * LDL_RLD] *= ipiv[q];
+            // backward: x = L^-T z.  Blocks of four are aligned to the top; the n mod 4 bottom... top rows go one by one first.
+            const int nb = n & ~3;                        // rows [0, nb) in blocks of 4, rows [nb, n) singly
+            for (int q = n - 2; q >= nb && q >= 0; --q) {
                 asm volatile("" ::: "memory");
-                float s = 0.f;
-                int i = k + 1 + sub;
-                for (; i + 7 * lpc < n; i += 8 * lpc) {
-                    float r[8], l[8];
+                float sum = 0.f;
+                for (int i = q + 1 + sub; i < n; i += lpc) sum += L[i * LD + q] * Rc[i * LDL_RLD];
+                for (int o = lpc >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                if (sub == 0) Rc[q * LDL_RLD] -= sum;
+            }
+            for (int kb = nb - 4; kb >= 0; kb -= 4) {
+                asm volatile("" ::: "memory");
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int i = kb + 4 + sub;
+                for (; i + 3 * lpc < n; i += 4 * lpc) {
+                    float r[4], l[4][4];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { r[u] = Rp[(i + u * lpc) * LDL_RLD + cc]; l[u] = L[(i + u * lpc) * LD + k]; }
+                    for (int u = 0; u < 4; ++u) {
+                        r[u] = Rc[(i + u * lpc) * LDL_RLD];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) s = fmaf(l[u], r[u], s);
+                        for (int q = 0; q < 4; ++q) l[u][q] = L[(i + u * lpc) * LD + kb + q];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { s0 = fmaf(l[u][0], r[u], s0); s1 = fmaf(l[u][1], r[u], s1); s2 = fmaf(l[u][2], r[u], s2); s3 = fmaf(l[u][3], r[u], s3); }
                 }
-                for (; i < n; i += lpc) s += L[i * LD + k] * Rp[i * LDL_RLD + cc];
-                for (int o = lpc >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-                if (sub == 0) Rp[k * LDL_RLD + cc] -= s;
+                for (; i < n; i += lpc) {
+                    const float* Li = L + i * LD + kb; const float r = Rc[i * LDL_RLD];
+                    s0 = fmaf(Li[0], r, s0); s1 = fmaf(Li[1], r, s1); s2 = fmaf(Li[2], r, s2); s3 = fmaf(Li[3], r, s3);
+                }
+                for (int o = lpc >> 1; o > 0; o >>= 1) {
+                    s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); s3 += __shfl_xor(s3, o, 64);
+                }
+                const float* L1 = L + (kb + 1) * LD + kb; const float* L2 = L + (kb + 2) * LD + kb; const float* L3 = L + (kb + 3) * LD + kb;
+                const float x3 = Rc[(kb + 3) * LDL_RLD] - s3;
+                const float x2 = Rc[(kb + 2) * LDL_RLD] - s2 - L3[2] * x3;
+                const float x1 = Rc[(kb + 1) * LDL_RLD] - s1 - L2[1] * x2 - L3[1] * x3;
+                const float x0 = Rc[kb * LDL_RLD] - s0 - L1[0] * x1 - L2[0] * x2 - L3[0] * x3;
+                asm volatile("" ::: "memory");
+                if (sub == 0) { Rc[kb * LDL_RLD] = x0; Rc[(kb + 1) * LDL_RLD] = x1; Rc[(kb + 2) * LDL_RLD] = x2; Rc[(kb + 3) * LDL_RLD] = x3; }
             }
         }
         __syncthreads();
