@@ -15,6 +15,7 @@
 //                  columns kept unscaled until the end so that no entry is read and written in the same step)
 //   R   [n][130]   up to 129 right-hand sides at a time (alpha's y rides as the first column of the first chunk); four or more
 //                  lanes of one wave share a column: LDS executes a wave's accesses in order, no barrier inside the substitutions
+//                  (which go four pivots per pass over the column - they are LDS-throughput-bound - and keep up to 16 loads in flight)
 #pragma once
 #include "problems.h"
 
