@@ -178,6 +178,9 @@ class ClipAdam(torch.optim.Adam):
         todo = self._tensors()
         if not todo:
             return
+        for group in self.param_groups:
+            if group.get("amsgrad") or group.get("maximize"):
+                raise RuntimeError("ClipAdam.clip_step implements plain Adam (no amsgrad, no maximize)")
         dev = todo[0][1].device
         for _, p in todo:
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
