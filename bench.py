@@ -6,7 +6,16 @@ A "step" = one outer (meta) step over one meta-batch of synthetic tasks per GPU 
 GNN), per-task median-heuristic re-initialisation, inner fit with exactly I = 20 MLL value+gradient
 evaluations, predictive NLL + 3x3 Hessian + IFT mixed term -> dL/dZ, one backward through the feature map,
 (all-reduce of the outer gradient over ranks), clip, Adam step.  Inputs are resident in HBM before the clock
-starts.  One process per GPU; for N > 1 launch with torch.distributed.run (RCCL).
+starts.  One process per GPU.
+
+Launching.  ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N rank processes
+itself (plain child processes, one GPU each through LOCAL_RANK, rendezvous on 127.0.0.1) BEFORE anything touches the
+GPU, relays rank 0's JSON line and exits with the worst child status; the parent never initialises HIP and never
+re-execs.  Under ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` the ranks are already
+there (WORLD_SIZE is set) and each process is one rank; ``--gpus`` must then agree with WORLD_SIZE.
+
+Scaling modes.  Default: weak (``--tasks`` per GPU).  ``--global-tasks G``: strong (G tasks split over the ranks: the C4
+shape is ``--global-tasks 512 --gpus 8`` = 64 tasks per rank).
 
 Prints ONE JSON line on rank 0.
 """
@@ -16,6 +25,8 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,28 +34,102 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tasks", type=int, default=256, help="tasks per GPU per step (weak scaling)")
+    ap.add_argument("--global-tasks", type=int, default=0, help="strong scaling: this many tasks per step in total, split over the ranks")
     ap.add_argument("--n-support", type=int, default=128)
     ap.add_argument("--n-query", type=int, default=128)
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--inner-evals", type=int, default=20)
     ap.add_argument("--kernel", default="rbf", choices=["rbf", "matern"])
-    ap.add_argument("--converge", action="store_true", help="run the inner fit to convergence instead of a fixed I")
+    ap.add_argument("--converge", action="store_true", help="headline loop runs the inner fit to convergence instead of a fixed I")
+    ap.add_argument("--converge-steps", type=int, default=5, help="steps of the second, run-to-convergence timed loop (0: skip)")
     ap.add_argument("--graph", action="store_true", help="replay the GP section of the step from a captured HIP graph")
     ap.add_argument("--ard", action="store_true", help="ARD kernel (h = 2 + d inner parameters): device L-BFGS + HVP/CG; not the headline config")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / collective rehearsal without a GPU: ranks rendezvous (gloo), all-reduce a dummy gradient, "
+                         "time barriers and print a line with value null (tests/test_bench_launcher.py)")
+    return ap.parse_args(argv)
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Parent of a self-launched multi-GPU run.  Touches no GPU API (torch is not even imported here)."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+def metric_name(N: int, d: int) -> str:
+    return f"meta-tasks/sec (N_support={N}, d={d})"
+
+
+def dry_run(args, rank: int, world: int):
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group(os.environ.get("ADKF_BENCH_BACKEND", "gloo"))
+    T = args.global_tasks // world if args.global_tasks else args.tasks
+    g = torch.full((args.d, args.d), float(rank + 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1:
+            dist.all_reduce(g)
+            dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": metric_name(args.n_support, args.d), "value": None, "unit": "tasks/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3,
+                          "scaling": "strong" if args.global_tasks else "weak", "dry_run": True,
+                          "config": {"tasks_per_gpu": T, "parallelism": f"task-sharded dp{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or drop WORLD_SIZE and let bench.py start the ranks)")
+    if args.global_tasks and args.global_tasks % world:
+        raise SystemExit(f"--global-tasks {args.global_tasks} does not divide over {world} ranks")
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
     import torch
     import torch.distributed as dist
 
@@ -53,9 +138,6 @@ def main():
     from adkf_ift_amd.synthetic import LinearFeatureMap, make_tasks
     from adkf_ift_amd.trainer import ClipAdam, GraphedGPBackend, MetaStepConfig, meta_step
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the GP path has no CPU fallback")
@@ -77,22 +159,20 @@ def main():
     else:
         ge.build()
 
-    T, N, Nq, d, I = args.tasks, args.n_support, args.n_query, args.d, args.inner_evals
+    T = args.global_tasks // world if args.global_tasks else args.tasks
+    N, Nq, d, I = args.n_support, args.n_query, args.d, args.inner_evals
     tasks = make_tasks(T, N, d, N_q=Nq, first_task=rank * T)
     X_s, X_q, y_s, y_q = (a.to(dev) for a in (tasks.X_s, tasks.X_q, tasks.y_s, tasks.y_q))
     W = tasks.W.to(dev).clone().requires_grad_(True)
     opt = ClipAdam([W], lr=1e-4)  # fs_mol/adaptive_dkt_train.py --lr default; mean + clip + Adam in the library (2 launches)
-    cfg = MetaStepConfig(gp_kernel=args.kernel, inner_max_evals=(200 if args.converge else I),
-                         inner_exact_evals=not args.converge, clip_value=1.0, use_ard=args.ard)
-    inv_sqrt_d = 1.0 / math.sqrt(d)
+
+    def step_cfg(converge: bool) -> MetaStepConfig:
+        return MetaStepConfig(gp_kernel=args.kernel, inner_max_evals=(200 if converge else I),
+                              inner_exact_evals=not converge, clip_value=1.0, use_ard=args.ard)
+
+    cfg = step_cfg(args.converge)
     backend = GraphedGPBackend() if args.graph else None
-
     features = LinearFeatureMap(X_s, X_q, W)  # one GEMM for support+query rows; chunked-bmm backward
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b_ in ev:  # create the underlying hipEvents
-        a.record()
-        b_.record()
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -100,28 +180,48 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        meta_step(features, [W], opt, y_s, y_q, cfg, distributed=distributed, backend=backend)
-    sync()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        losses, phi = meta_step(features, [W], opt, y_s, y_q, cfg, distributed=distributed, fit_events=ev[k], backend=backend)
-    t_host = time.perf_counter() - t0   # when the host finished ENQUEUEING the K steps (== dt would mean host-bound)
-    sync()
-    dt = time.perf_counter() - t0
-    if distributed:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    fit_ms = sum(a.elapsed_time(b_) for a, b_ in ev) / len(ev)
+    def timed_loop(cfg_, steps, warmup, events=None):
+        for _ in range(warmup):
+            meta_step(features, [W], opt, y_s, y_q, cfg_, distributed=distributed, backend=backend)
+        sync()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            meta_step(features, [W], opt, y_s, y_q, cfg_, distributed=distributed, backend=backend,
+                      fit_events=events[k] if events else None)
+        t_host = time.perf_counter() - t0   # when the host finished ENQUEUEING the steps (== dt would mean host-bound)
+        sync()
+        dt = time.perf_counter() - t0
+        if distributed:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, t_host
+
+    # HIP events recorded by the library on the launch stream right around the inner-fit kernel (adkf_fit_options_t).
+    # Under --graph the captured launch carries no events, so the roofline object is omitted there.
+    ev = None
+    if not args.graph:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a, b_ in ev:  # create the underlying hipEvents
+            a.record()
+            b_.record()
+    dt, t_host = timed_loop(cfg, args.steps, args.warmup, ev)
+    fit_ms = sum(a.elapsed_time(b_) for a, b_ in ev) / len(ev) if ev else None
+
+    # ---- SURVEY 8d "also report run-to-convergence": a second, short timed loop with the fit run to its stopping rules ----
+    converged = None
+    if args.converge_steps > 0 and not args.converge and not args.ard:
+        cdt, _ = timed_loop(step_cfg(True), args.converge_steps, 2)
+        converged = {"tasks_per_s": T * world * args.converge_steps / cdt, "ms_per_step": cdt / args.converge_steps * 1e3,
+                     "steps": args.converge_steps}
 
     # ---- parity of the metric's second half ("logML rel-err") on a few tasks, outside the timed region ----
     parity = None
     if rank == 0 and not args.no_parity:
         from oracle import gp_oracle as O
         with torch.no_grad():
-            Zall = features()
-            Zs, Zq = Zall[0], Zall[1]
+            feats = features()
+            Zs, Zq = feats[0], feats[1]
         phi0, pri, _ = gp_ops.init_params(Zs)
         b = gp_ops.GPBatch(Zs, y_s, pri, args.kernel, Z_q=Zq, y_q=y_q)
         phi_f, f_in, gn, nev, info = gp_ops.fit(b, phi0, cfg.inner_max_evals, exact_evals=cfg.inner_exact_evals)
@@ -137,6 +237,10 @@ def main():
             e_dz = max(e_dz, float((out["dZ_s"][t].double().cpu() - ref).abs().max() / ref.abs().max()))
         parity = {"logml_rel_err": e_in, "outer_nll_rel_err": e_out, "ift_dZ_rel_err": e_dz,
                   "fit_max_grad": float(gn.max().item()), "fit_mean_evals": float(nev.float().mean().item())}
+        if converged is not None:
+            _, _, gn_c, nev_c, _ = gp_ops.fit(b, phi0, 200, exact_evals=False)
+            converged["mean_evals"] = float(nev_c.float().mean().item())
+            converged["fit_max_grad"] = float(gn_c.max().item())
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -152,37 +256,53 @@ def main():
         fl = roofline.flops_per_task(N, Nq, d, I)
         total_tasks = T * world * args.steps
         value = total_tasks / dt
-        fit_flops = fl["inner_fit"] * T            # algorithmic FLOPs of ONE launch of the dominant kernel
-        achieved = fit_flops / (fit_ms * 1e-3) / 1e12
-        # HBM bytes of that launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
-        # --pmc WRITE_SIZE in separate runs of this same command; KB -> bytes; the k_inner loads are dword-wide, for
-        # which the guide's x2 FETCH_SIZE correction is uncalibrated, so the raw counters are reported)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_final_k_inner_pmc.json")
-        if os.path.exists(pmc) and (T, N, Nq, d, I) == (256, 128, 128, 256, 20) and args.kernel == "rbf":
-            with open(pmc) as fh:
-                pm = json.load(fh)
-            traffic = (pm["FETCH_SIZE_KB_per_launch"] + pm["WRITE_SIZE_KB_per_launch"]) * 1024.0
         cfg_name = {(256, 128, 256): "C2", (64, 32, 64): "C1", (8, 1024, 512): "C5"}.get((T, N, d), "custom")
+        if args.global_tasks == 512 and (N, d) == (128, 256):
+            cfg_name = "C4"
         if args.ard:
             cfg_name += " with the ARD kernel (roofline FLOP model below is the non-ARD one: indicative only)"
-        fit_kernel = ("ARD inner fit (all launches between the two events)" if args.ard else "k_inner (in-kernel quasi-Newton fit: kernel build + register-resident sweep per evaluation)" if N <= 128 else
-                      "blocked inner fit (all launches between the two events: k_lg_build, k_lg_diag, panel/update MFMA GEMMs, "
-                      "k_lg_traces, k_lg_advance per evaluation)")
+        roof = None
+        if fit_ms is not None:
+            fit_flops = fl["inner_fit"] * T            # algorithmic FLOPs of ONE launch of the dominant kernel
+            achieved = fit_flops / (fit_ms * 1e-3) / 1e12
+            # HBM bytes of that launch: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of this same
+            # command (tools/profile_round.sh), committed under profiles/ with the commit they were taken at; FETCH_SIZE is
+            # doubled as MI355X_MICROARCH.md (HBM section) prescribes for 16-byte-per-lane streaming reads on gfx950.
+            traffic = traffic_src = None
+            pmc = os.path.join(ROOT, "profiles", "r02_k_inner_pmc.json")
+            if os.path.exists(pmc) and (T, N, Nq, d, I) == (256, 128, 128, 256, 20) and args.kernel == "rbf" and not args.ard:
+                with open(pmc) as fh:
+                    pm = json.load(fh)
+                traffic = (2.0 * pm["FETCH_SIZE_KB_per_launch"] + pm["WRITE_SIZE_KB_per_launch"]) * 1024.0
+                traffic_src = {"file": "profiles/r02_k_inner_pmc.json", "commit": pm.get("commit"),
+                               "correction": "2 x FETCH_SIZE + WRITE_SIZE"}
+            if args.ard:
+                fit_kernel, bound = "ARD inner fit (all launches between the two events)", "mfma"
+            elif N <= 128:
+                fit_kernel = "k_inner (in-kernel quasi-Newton fit: kernel build + register-resident sweep per evaluation)"
+                bound = "valu-fp32 (latency)"   # one workgroup per task, no MFMA: limited by the dependency chain of the sweep
+            else:
+                fit_kernel = ("blocked inner fit (all launches between the two events: k_lg_build, k_lg_diag, panel/update "
+                              "MFMA GEMMs, k_lg_traces, k_lg_advance per evaluation)")
+                bound = "mfma"
+            roof = {"kernel": fit_kernel, "bound": bound, "achieved": achieved, "peak": roofline.PEAK_FP32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / roofline.PEAK_FP32_TFLOPS, "traffic": traffic,
+                    "traffic_source": traffic_src, "flops_per_launch": fit_flops, "avg_launch_ms": fit_ms}
+        dz_exec = 2 * d * (N * N + 2 * N * Nq + Nq * Nq)   # what ProbDZ executes (K = N + Nq per output row)
         line = {
-            "metric": "meta-tasks/sec (N_support=128, d=256)", "value": value, "unit": "tasks/s", "n_gpus": world,
+            "metric": metric_name(N, d), "value": value, "unit": "tasks/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.global_tasks else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg_name}: {T} tasks/GPU/step, N_support={N}, N_query={Nq}, d={d}, kernel={args.kernel}, "
                                    f"inner fit = {'to convergence' if args.converge else f'exactly {I} MLL value+grad evals'}, "
                                    "IFT hypergradient, theta = W[d,d] linear feature map, Adam + clip 1.0",
-                       "tasks_per_gpu": T, "parallelism": f"task-sharded dp{world}"},
+                       "tasks_per_gpu": T, "global_tasks": T * world, "parallelism": f"task-sharded dp{world}"},
             "whole_path_tflops": value * fl["total"] / 1e12,
             "whole_path_frac_of_fp32_peak": value * fl["total"] / 1e12 / (roofline.PEAK_FP32_TFLOPS * world),
-            "roofline": {"kernel": fit_kernel,
-                         "bound": "mfma", "achieved": achieved, "peak": roofline.PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / roofline.PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "flops_per_launch": fit_flops, "avg_launch_ms": fit_ms},
+            # the frozen SURVEY 8d model prices the dZ GEMMs at 4d(N^2+N Nq+Nq^2); the kernels execute 2d(N+Nq)^2
+            "whole_path_frac_executed_flops": value * (fl["total"] - fl["dZ"] + dz_exec) / 1e12 / (roofline.PEAK_FP32_TFLOPS * world),
+            "roofline": roof,
+            "converged": converged,
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             "cpu_baseline": cpu_baseline,
             "parity": parity,
