@@ -473,12 +473,15 @@ class GraphFeatureExtractor(nn.Module):
         own[r + "first.bias"] = torch.cat(firsts_b)
         own[r + "max_combination.weight"] = get(r + "_max_pooler._combination_layer.weight")
         own[r + "combination_layer.weight"] = get(r + "_combination_layer.weight")
-        for k in ("final_norm_layer.weight", "final_norm_layer.bias"):
+        # output_norm = "batch": the running statistics are part of the checkpoint and decide what eval-mode features look
+        # like - they are copied too, and a batch-norm checkpoint without them is refused (not silently evaluated with 0 / 1)
+        for k in ("final_norm_layer.weight", "final_norm_layer.bias", "final_norm_layer.running_mean",
+                  "final_norm_layer.running_var", "final_norm_layer.num_batches_tracked"):
             if prefix + k in ref:
                 own[k] = get(k)
         missing, unexpected = self.load_state_dict(own, strict=False)
         unexpected = [k for k in unexpected]
-        missing = [k for k in missing if "num_batches_tracked" not in k and "running_" not in k]
+        missing = [k for k in missing if "num_batches_tracked" not in k]
         if missing or unexpected:
             raise KeyError(f"reference checkpoint does not match: missing {missing}, unexpected {unexpected}")
 
@@ -518,7 +521,8 @@ class GraphFeatureExtractor(nn.Module):
             out[f"{r}{pool}._combination_layer.weight"] = own[f"{r}{tag}_combination.weight"]
         out[r + "_max_pooler._combination_layer.weight"] = own[r + "max_combination.weight"]
         out[r + "_combination_layer.weight"] = own[r + "combination_layer.weight"]
-        for k in ("final_norm_layer.weight", "final_norm_layer.bias"):
+        for k in ("final_norm_layer.weight", "final_norm_layer.bias", "final_norm_layer.running_mean",
+                  "final_norm_layer.running_var", "final_norm_layer.num_batches_tracked"):
             if k in own:
                 out[k] = own[k]
         return {prefix + k: v for k, v in out.items()}

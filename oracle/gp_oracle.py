@@ -12,6 +12,13 @@ the published GPyTorch formulas the reference calls (gpytorch 1.6-1.8 era, impli
 ``environment.yml:9,19-22``), in float64 torch so that autograd supplies every
 derivative independently of the closed forms the HIP kernels implement.  What IS pinned:
 
+* the GP arithmetic that does not depend on GPyTorch's parametrisation - kernel matrices (RBF, Matern-5/2), the log
+  marginal likelihood, the exact posterior mean/covariance with likelihood noise - by scikit-learn's exact GP, and the
+  LogNormal prior density by torch.distributions (tests/test_oracle.py::test_oracle_against_independent_...).
+  Still memory-only after that: softplus parametrisation of noise / outputscale / lengthscale (A1),
+  the 1e-4 noise floor (A1), prior log-densities evaluated on the transformed values and added BEFORE the division by N
+  (A4), fresh raw_outputscale = 0 (A1), GPyTorch centring its kernel inputs (A3; immaterial for stationary kernels);
+
 * the hypergradient operator, by the reference's own ``cauchy_hypergradient`` /
   ``cauchy_hypergradient_jvp`` (torch-only files, imported by path inside this
   container when generating ``tests/golden``), and by the known answers of

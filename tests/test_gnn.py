@@ -83,3 +83,71 @@ def test_default_config_is_the_reference_cli_default():
     batch = random_graphs(5, seed=0)
     out = model(GraphBatch(batch.node_features.float(), batch.adjacency_lists, batch.node_to_graph, batch.num_graphs))
     assert out.shape == (5, 512) and torch.isfinite(out).all()
+
+
+def unit_gain_reference_state_dict(cfg, seed):
+    """GO.random_reference_state_dict rescaled to unit-gain layers (weights ~ 1/sqrt(fan_in), alpha ~ 0.3): keeps the
+    activations O(1) through ten layers at the reference's default width (hidden 128, 4 towers x 64, 3072-wide
+    aggregation), where N(0, 0.3^2) weights would overflow float32."""
+    sd = GO.random_reference_state_dict(cfg, seed=seed)
+    for k, v in sd.items():
+        if k.endswith(".weight") and v.dim() == 2 and "norm" not in k:
+            sd[k] = v / (0.3 * v.shape[1] ** 0.5)
+        if k.endswith("alpha"):
+            sd[k] = v * 0.4
+    return sd
+
+
+def grads_under_reference_names(model):
+    """d out / d parameters of ``model`` re-keyed by the REFERENCE's parameter names: the name mapping is a linear
+    re-stacking, so it applies to gradients unchanged (a scratch copy whose parameters hold the gradients is exported)."""
+    import copy
+    g = copy.deepcopy(model)
+    with torch.no_grad():
+        for q, p in zip(g.parameters(), model.parameters()):
+            q.copy_(p.grad if p.grad is not None else torch.zeros_like(p))
+    return g.reference_state_dict()
+
+
+def test_default_width_matches_reference_restatement_with_gradients():
+    """fs_mol/modules/gnn.py:401-515 at the CLI defaults (hidden 128, 4 towers x 64, 10 layers, BOOM 1024) and
+    fs_mol/modules/graph_readout.py:119-177 (12 heads x 64, all 11 states = 1408-wide nodes): forward AND parameter
+    gradients of the re-authored extractor against the naive restatement, float64."""
+    cfg = GraphFeatureExtractorConfig()
+    sd = {k: v.requires_grad_(True) for k, v in unit_gain_reference_state_dict(cfg, seed=2).items()}
+    batch = random_graphs(40, seed=11)
+    model = GraphFeatureExtractor(cfg).double()
+    model.load_reference_state_dict({k: v.detach() for k, v in sd.items()})
+    got = model(batch)
+    want = GO.graph_feature_extractor(batch, sd, cfg)
+    assert got.shape == (40, 512)
+    assert (got - want).abs().max().item() <= 1e-10 * want.abs().max().item()
+    w = torch.randn(want.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    (got * w).sum().backward()
+    (want * w).sum().backward()
+    mine = grads_under_reference_names(model)
+    scale = max(v.grad.abs().max().item() for v in sd.values() if v.grad is not None)
+    for k, v in sd.items():
+        if v.grad is None:
+            assert "mp_norm_layer" in k, k      # constructed but not applied in the reference forward (gnn.py:477-515)
+            continue
+        assert (mine[k] - v.grad).abs().max().item() <= 1e-9 * scale, k
+
+
+def test_batchnorm_running_statistics_round_trip():
+    cfg = small_cfg()
+    cfg.output_norm = "batch"
+    model = GraphFeatureExtractor(cfg).double()
+    model.train()
+    for s in (1, 2, 3):
+        model(random_graphs(6, seed=s))          # moves running_mean / running_var away from 0 / 1
+    ref = model.reference_state_dict()
+    assert "graph_feature_extractor.final_norm_layer.running_mean" in ref
+    other = GraphFeatureExtractor(cfg).double()
+    other.load_reference_state_dict(ref)
+    model.eval(), other.eval()
+    b = random_graphs(5, seed=9)
+    assert torch.equal(model(b), other(b))
+    del ref["graph_feature_extractor.final_norm_layer.running_var"]
+    with pytest.raises(KeyError):
+        GraphFeatureExtractor(cfg).double().load_reference_state_dict(ref)

@@ -1,0 +1,144 @@
+"""GPU: row a1 (GNN feature extractor) at the REFERENCE'S WIDTH against oracle/gnn_oracle.py, and BASELINE config C3
+(full default deep-kernel model, 16-shot molecular tasks) against the per-task float64 oracle loop.
+
+fs_mol/modules/gnn.py:401-515,530-556 (hidden 128, 4 towers x 64, 10 PNA layers, BOOM 1024) and
+fs_mol/modules/graph_readout.py:119-177 (12 heads x 64 over all 11 node states); head fs_mol/models/adaptive_dkt.py:50-65.
+The device side runs float32 with the fused HIP message / aggregation kernels (csrc/pna.h); the oracle side is the naive
+module-by-module restatement in float64 on the CPU, parameters under the reference's names."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def test_default_width_extractor_forward_and_gradients_vs_oracle(dev):
+    from adkf_ift_amd.gnn import GraphFeatureExtractor, GraphFeatureExtractorConfig
+    from oracle import gnn_oracle as GO
+    from test_gnn import grads_under_reference_names, random_graphs, unit_gain_reference_state_dict
+
+    cfg = GraphFeatureExtractorConfig()
+    sd = {k: v.requires_grad_(True) for k, v in unit_gain_reference_state_dict(cfg, seed=2).items()}
+    batch = random_graphs(40, seed=11)          # isolated nodes and a single-atom graph included
+    want = GO.graph_feature_extractor(batch, sd, cfg)
+    model = GraphFeatureExtractor(cfg)
+    model.load_reference_state_dict({k: v.detach().float() for k, v in sd.items()})
+    model = model.to(dev)
+    b32 = batch.to(dev)
+    b32.node_features = b32.node_features.float()
+    got = model(b32)
+    assert got.shape == (40, 512)
+    err = (got.double().cpu() - want).abs().max().item() / want.abs().max().item()
+    assert err <= 2e-5, err
+    w = torch.randn(want.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    (want * w).sum().backward()
+    (got * w.float().to(dev)).sum().backward()
+    mine = grads_under_reference_names(model)
+    scale = max(v.grad.abs().max().item() for v in sd.values() if v.grad is not None)
+    # Yardstick for "what float32 can do" on this network: the same extractor in float32 through plain PyTorch ops on the
+    # CPU.  The reference's std aggregation sqrt(relu(E[x^2] - E[x]^2) + 1e-7) (fs_mol/modules/gnn.py:231-240) has slope
+    # 1 / (2 sqrt(1e-7)) = 1581 at zero variance (every node with a single incoming message), so float32 rounding of the
+    # argument moves gradients by ~1e-3 of the largest entry whatever the implementation.
+    cpu32 = GraphFeatureExtractor(cfg)
+    cpu32.load_reference_state_dict({k: v.detach().float() for k, v in sd.items()})
+    c32 = batch.to("cpu")
+    c32.node_features = c32.node_features.float()
+    (cpu32(c32) * w.float()).sum().backward()
+    yard = grads_under_reference_names(cpu32)
+    e32 = max((yard[k].double() - v.grad).abs().max().item() / scale for k, v in sd.items() if v.grad is not None)
+    tol = max(2e-4, 2.0 * e32)
+    worst = 0.0
+    for k, v in sd.items():
+        if v.grad is None:
+            continue
+        e = (mine[k].double().cpu() - v.grad).abs().max().item() / scale
+        worst = max(worst, e)
+        assert e <= tol, (k, e, e32)
+    print("default-width extractor: forward rel err %.2e; worst parameter-gradient err %.2e of the largest entry "
+          "(float32 PyTorch on the CPU: %.2e)" % (err, worst, e32))
+
+
+def _molecules(n, seed):
+    from adkf_ift_amd.meta_batch import MoleculeFeatures
+    from test_gnn import random_graphs
+    g = torch.Generator().manual_seed(1000 + seed)
+    gb = random_graphs(n, seed=seed)
+    return MoleculeFeatures(gb.node_features.float(), gb.adjacency_lists, gb.node_to_graph, gb.num_graphs,
+                            torch.poisson(torch.full((n, 2048), 0.03), generator=g), torch.randn(n, 42, generator=g))
+
+
+def test_c3_default_model_meta_step_vs_per_task_oracle_loop(dev):
+    """BASELINE config 3: GNN + ECFP -> fc(2560 -> 2048 -> 2048) -> GP fit + IFT hypergradient, 2 tasks of 16 support +
+    32 query molecules, through ``model_meta_step`` (one extractor forward/backward for both tasks).
+    Expected: per task, oracle features (gnn_oracle + fc, float64) -> d f_out/dZ - v^T d^2 f_in/dphi dZ from the float64
+    autograd GP oracle AT THE DEVICE'S FITTED phi -> one backward through the oracle extractor; mean over tasks
+    (fs_mol/utils/adaptive_dkt_utils.py:361-407).  At the feature level that total derivative is exactly what the
+    reference's cauchy_hypergradient returns (pinned by the linmap fixtures); chaining it through the extractor is the
+    chain rule."""
+    from adkf_ift_amd.meta_batch import DKTBatch, collate_meta_batch, model_meta_step
+    from adkf_ift_amd.models import ADKTModel, ADKTModelConfig
+    from adkf_ift_amd.trainer import MetaStepConfig
+    from oracle import gnn_oracle as GO
+    from oracle import gp_oracle as O
+    from test_gnn import grads_under_reference_names, unit_gain_reference_state_dict
+
+    torch.manual_seed(0)
+    mcfg = ADKTModelConfig()                      # reference defaults
+    model = ADKTModel(mcfg)
+    gcfg = model.graph_feature_extractor.config
+    sd = unit_gain_reference_state_dict(gcfg, seed=5)
+    model.graph_feature_extractor.load_reference_state_dict({k: v.float() for k, v in sd.items()})
+    model = model.to(dev)
+    g = torch.Generator().manual_seed(3)
+    tasks = []
+    for t in range(2):
+        ns, nq = 16, 32
+        tasks.append(DKTBatch(_molecules(ns, 20 + 2 * t), torch.rand(ns, generator=g) > 0.5, torch.randn(ns, generator=g),
+                              _molecules(nq, 21 + 2 * t), torch.rand(nq, generator=g) > 0.5, torch.randn(nq, generator=g)))
+    mb = collate_meta_batch(tasks).to(dev)
+    cfg = MetaStepConfig(gp_kernel="matern", clip_value=None)
+    losses, phi = model_meta_step(model, None, mb, cfg, check=True)
+
+    # ---- oracle side (CPU, float64) ----
+    sd64 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fc = [p.detach().double().cpu().requires_grad_(True) for p in model.fc.parameters()]     # W1, b1, W2, b2
+
+    def features(part):
+        gb = part.graph()
+        gb.node_features = gb.node_features.double()
+        h = GO.graph_feature_extractor(gb, sd64, gcfg)
+        x = torch.cat([h, part.fingerprints.double()], dim=1)
+        return torch.relu(x @ fc[0].T + fc[1]) @ fc[2].T + fc[3]
+
+    T = len(tasks)
+    want_losses = []
+    for t, b in enumerate(tasks):
+        Zs, Zq = features(b.support_features), features(b.query_features)
+        ys, yq = (b.support_labels.double() - 0.5) * 2, (b.query_labels.double() - 0.5) * 2
+        _, pri = O.init_phi(Zs.detach(), False, True)
+        q = O.full_reference_quantities(Zs.detach(), ys, Zq.detach(), yq, phi[t].double().cpu(), pri, O.KERNEL_MATERN52)
+        want_losses.append(q["f_out"] / b.num_query_samples)
+        torch.autograd.backward([Zs, Zq], [torch.tensor(q["dZs_total"]) / T, torch.tensor(q["dZq_total"]) / T])
+    assert np.abs(losses.cpu().numpy() - np.array(want_losses)).max() <= 1e-4 * np.abs(want_losses).max()
+    mine = grads_under_reference_names(model.graph_feature_extractor)
+    scale = max(max(v.grad.abs().max().item() for v in sd64.values() if v.grad is not None), max(p.grad.abs().max().item() for p in fc))
+    worst = 0.0
+    for k, v in sd64.items():
+        if v.grad is None:
+            continue
+        e = (mine[k].double().cpu() - v.grad).abs().max().item() / scale
+        worst = max(worst, e)
+        assert e <= 5e-4, (k, e)
+    for p, r in zip(model.fc.parameters(), fc):
+        e = (p.grad.double().cpu() - r.grad).abs().max().item() / scale
+        worst = max(worst, e)
+        assert e <= 5e-4, e
+    print("C3 default model: worst theta.grad error %.2e of the largest entry" % worst)
