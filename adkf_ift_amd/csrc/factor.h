@@ -60,7 +60,7 @@ template <> struct SweepCfg<32, 256> { static constexpr int RB = 2, CB = 2; };
 template <> struct SweepCfg<16, 256> { static constexpr int RB = 1, CB = 1; };
 
 template <int NMAX, int NT>
-struct SweepSmem {
+struct SweepSmemBlk {
     static constexpr int B = SweepCfg<NMAX, NT>::CB;
     alignas(16) float cross[3][B][NMAX];  // C: the B pivot rows (with D - I at the pivot columns); 3 slots, see steps()
     alignas(16) float fvec[3][B][NMAX];   // F = D^-1 C
@@ -129,7 +129,8 @@ template <> struct InvSpd<4> {
 };
 
 template <int NMAX, int NT>
-struct Sweep {
+struct SweepBlk {
+    using Smem = SweepSmemBlk<NMAX, NT>;
     static constexpr int RB = SweepCfg<NMAX, NT>::RB, CB = SweepCfg<NMAX, NT>::CB, B = CB;
     static constexpr int NBC = NMAX / CB, NBR = NMAX / RB;
     static constexpr int G = RB / CB;          // row groups per thread
@@ -155,7 +156,7 @@ struct Sweep {
     // The owners of pivot block q = GI * NBR + bl (matrix rows q*B .. q*B+B-1 = local rows GI*CB.. of logical block
     // row bl) publish C and F for block step q into `slot`.  GI is a compile-time constant: static register indices.
     template <int GI>
-    __device__ static __forceinline__ void publish(float (&m)[RB][CB], int bl, int slot, SweepSmem<NMAX, NT>& sm) {
+    __device__ static __forceinline__ void publish(float (&m)[RB][CB], int bl, int slot, Smem& sm) {
         constexpr int RO = GI * CB;
         const int q = GI * NBR + bl;
         const int q_stamp = q - 1; (void)q_stamp;
@@ -229,7 +230,7 @@ struct Sweep {
 
     // rank-B update of local rows [R0, R1) of this thread's block from the vectors of block step `slot`
     template <int R0, int R1>
-    __device__ static __forceinline__ void apply_pivot(float (&m)[RB][CB], int slot, int a, SweepSmem<NMAX, NT>& sm) {
+    __device__ static __forceinline__ void apply_pivot(float (&m)[RB][CB], int slot, int a, Smem& sm) {
         const int j0 = bc() * CB;
         float fi[R1 - R0], cj[CB];
 #pragma unroll
@@ -242,14 +243,14 @@ struct Sweep {
             for (int c = 0; c < CB; ++c) m[r][c] = fmaf(-fi[r - R0], cj[c], m[r][c]);
     }
     template <int R0, int R1>
-    __device__ static __forceinline__ void apply_step(float (&m)[RB][CB], int slot, SweepSmem<NMAX, NT>& sm) {
+    __device__ static __forceinline__ void apply_step(float (&m)[RB][CB], int slot, Smem& sm) {
         if constexpr (R0 < R1) {
 #pragma unroll
             for (int a = 0; a < B; ++a) apply_pivot<R0, R1>(m, slot, a, sm);
         }
     }
     // (for the ablation harness tools/sweep_bench.hip)
-    __device__ static __forceinline__ void step(float (&m)[RB][CB], int q, SweepSmem<NMAX, NT>& sm) {
+    __device__ static __forceinline__ void step(float (&m)[RB][CB], int q, Smem& sm) {
         apply_step<0, RB>(m, q % 3, sm);
     }
 
@@ -258,7 +259,7 @@ struct Sweep {
     // those rows up to date, invert and publish - all at raised priority.  The rest of this wave's step-q update
     // happens one step later (see phase()).
     template <int NGI>
-    __device__ static __forceinline__ void chain(float (&m)[RB][CB], int nbl, int q, SweepSmem<NMAX, NT>& sm) {
+    __device__ static __forceinline__ void chain(float (&m)[RB][CB], int nbl, int q, Smem& sm) {
         constexpr int N0 = NGI * CB, N1 = NGI * CB + CB;
         const int q_stamp = q; (void)q_stamp;
         ADKF_TS(0);
@@ -273,7 +274,7 @@ struct Sweep {
 
     // All block steps whose pivot rows are local row group GI.
     template <int GI>
-    __device__ static __forceinline__ void phase(float (&m)[RB][CB], int nq, SweepSmem<NMAX, NT>& sm) {
+    __device__ static __forceinline__ void phase(float (&m)[RB][CB], int nq, Smem& sm) {
         if constexpr (GI < G) {
             const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
             for (int bl = 0; bl < NBR; ++bl) {
@@ -308,7 +309,7 @@ struct Sweep {
 
     // In: m = this thread's block of the SPD matrix (identity-padded beyond n).  Out: m = -(A^-1); the pivots are
     // left in sm.pivs[0..n) (finish() turns them into info and log-determinant).  All threads call.
-    __device__ static __forceinline__ void run(float (&m)[RB][CB], int n, SweepSmem<NMAX, NT>& sm) {
+    __device__ static __forceinline__ void run(float (&m)[RB][CB], int n, Smem& sm) {
         const int nq = (n + B - 1) / B;  // pivot blocks that contain a real row; sweeping identity padding is a no-op
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         if (wave == owner_wave(0)) publish<0>(m, 0, 0, sm);
@@ -323,7 +324,7 @@ struct Sweep {
     }
 
     // log-determinant and info from the pivots.  Contains barriers; all threads call; all get the same values.
-    __device__ static __forceinline__ int finish(int n, SweepSmem<NMAX, NT>& sm, float& logdet) {
+    __device__ static __forceinline__ int finish(int n, Smem& sm, float& logdet) {
         const int tid = threadIdx.x;
         float v[1] = {0.f};
         int bad = INT_MAX;
@@ -372,4 +373,16 @@ struct Sweep {
     }
 };
 
+// The names the kernels use.  128 points x 512 threads takes the wave-owned variant of factor_w.h (ADKF_SWEEP_W=0 keeps
+// the blocked one for A/B measurements); the smaller sizes use the blocked sweep above.
+template <int NMAX, int NT> struct SweepSmem : SweepSmemBlk<NMAX, NT> {};
+template <int NMAX, int NT> struct Sweep : SweepBlk<NMAX, NT> {};
+
 }  // namespace adkf
+
+#ifndef ADKF_SWEEP_W
+#define ADKF_SWEEP_W 1
+#endif
+#if ADKF_SWEEP_W
+#include "factor_w.h"
+#endif

@@ -112,9 +112,9 @@ struct InnerEval {
         const float il2 = 1.f / (ls * ls), gl = -2.f / ls;
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            __builtin_amdgcn_sched_barrier(0);   // one row of exponentials in flight at a time: keeps the pressure of this loop out of the sweep's allocation
 #pragma unroll
             for (int c = 0; c < CB; ++c) {
+                if (c % 4 == 0) __builtin_amdgcn_sched_barrier(0);   // four exponentials in flight at a time: keeps the pressure of this loop out of the sweep's allocation
                 const int i = SW::row(r), j = j0 + c;
                 float k1u = 0.f;
                 if (i < n && j < n) {
@@ -381,12 +381,17 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
     }
     if (a.vecs && tid < n) a.vecs[((size_t)t * NVEC + V_ALPHA) * a.vld + tid] = sm.vec_out[tid];
     if (a.Ainv) {
-        float* Ao = a.Ainv + (size_t)t * a.ld * a.ld;
+        // the output addresses are formed HERE from opaque copies: hoisted to the kernel's head (they are loop-invariant) the
+        // row offset was the one value (8 bytes) that spilled across the whole fit
+        int t_late = t, i_late = SW::row(0);
+        asm volatile("" : "+s"(t_late));
+        asm volatile("" : "+v"(i_late));
+        float* Ao = a.Ainv + (size_t)t_late * a.ld * a.ld;
 #pragma unroll
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int c = 0; c < CB; ++c) {
-                const int i = SW::row(r), j = j0 + c;
+                const int i = i_late + (SW::row(r) - SW::row(0)), j = j0 + c;   // (a compile-time offset in every layout)
                 if (i < n && j < n) Ao[(size_t)i * a.ld + j] = -m[r][c];
             }
     }

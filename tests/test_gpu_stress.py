@@ -42,8 +42,8 @@ def test_random_shapes_against_the_oracle(dev):
     from oracle import gp_oracle as O
 
     rng = np.random.default_rng(20260)
-    worst, worst32 = {}, {}
-    for case in range(int(os.environ.get("ADKF_STRESS_CASES", "12"))):
+    worst, worst32, failures = {}, {}, []
+    for case in range(int(os.environ.get("ADKF_STRESS_CASES", "60"))):
         N, Nq, d, kind, regression, n_s, n_q = _random_case(rng)
         if case < int(os.environ.get("ADKF_STRESS_FIRST", "0")):
             continue
@@ -82,18 +82,14 @@ def test_random_shapes_against_the_oracle(dev):
                    "g_out": out["g_phi"][t].cpu().numpy(), "v": out["v"][t].cpu().numpy(),
                    "dZs_total": out["dZ_s"][t, :n].cpu().numpy(), "dZq_total": out["dZ_q"][t, :m].cpu().numpy(),
                    "pred_mean": mean[t, :m].cpu().numpy(), "pred_var": var[t, :m].cpu().numpy()}
-            # Tolerance.  Well-conditioned tasks (cond(A), cond(Sigma_q) <= 100: every BASELINE configuration, noise 0.1 or
-            # high-dimensional features): 1e-4, or 4x the error of the SAME restatement run in float32 on the CPU where
-            # plain float32 cannot do better.  Ill-conditioned tasks (noise ~0.01 with clustered low-dimensional features,
-            # cond ~ 2e3): 2e-3 - the explicit fp32 inverses of the pipeline used to lose 2 % on f_out and 5-10 % on dL/dZ
-            # there; csrc/ldl.h re-solves C = K_qs A^-1 and alpha through an LDL^T factorisation for such tasks
-            # ("numerical envelope"); Sigma_q^-1 is still the explicit inverse of the sweep, whose error
-            # grows with cond(Sigma_q) (1.3e-3 on dL/dZ_q at cond 2.9e3), hence the linear factor beyond 1e3.
+            # Tolerance: 1e-4 (north star) on every output of every case - no allowance for ill-conditioning - or, where the
+            # SAME restatement run in float32 with Cholesky solves on the CPU (what the reference's GPyTorch path does) cannot
+            # do better, 4x that float32 error.  `slack` only accounts for outputs that are themselves sums of cancelling
+            # terms (f_out, grad_phi f_out, v): their error is measured against the size of the terms.
             noise, os_, ls = O.transform_phi(phi[t].double().cpu())
             A = O.kernel_matrix(zs.double(), zs.double(), os_, ls, kind) + noise * torch.eye(n, dtype=torch.float64)
             cond = max(float(torch.linalg.cond(A)), float(np.linalg.cond(q["pred_cov"])))
             well = cond <= 100.0
-            condH = max(1.0, float(np.linalg.cond(q["H"])) / 100.0)    # v = H^-1 g_out and the mixed term inherit it
             O.DT = torch.float32
             try:
                 q32 = O.full_reference_quantities(zs, ys[t, :n], zq, yq[t, :m], phi[t].cpu(), opri, kind)
@@ -116,16 +112,20 @@ def test_random_shapes_against_the_oracle(dev):
             for k, v in got.items():
                 e = _rel(v, q[k])
                 e32 = _rel(q32[k], q[k])
-                tol = max((TOL if well else 20.0 * TOL * max(1.0, cond / 1e3)) * slack.get(k, 1.0) * (condH if k in ("v", "dZs_total") else 1.0), 4.0 * e32)
+                tol = max(TOL * slack.get(k, 1.0), 4.0 * e32)
                 worst[k] = max(worst.get(k, 0.0), e / tol)
                 if e > 0.1 * TOL:
                     kk = ("well " if well else "ill ") + k
                     worst32[kk] = max(worst32.get(kk, 0.0), float("%.1e" % e))
-                assert e <= tol, (desc, t, k, e, e32, cond)
+                if e > tol:
+                    failures.append((case, t, k, float("%.2e" % e), float("%.2e" % e32), float("%.1e" % cond), n, m, d, kind))
             assert float(out["dZ_s"][t, n:].abs().max() if n < N else 0.0) == 0.0, desc
             assert float(out["dZ_q"][t, m:].abs().max() if m < Nq else 0.0) == 0.0, desc
     print("worst error / tolerance:", {k: float("%.2f" % v) for k, v in worst.items()})
     print("worst relative error by regime (where > 1e-5):", worst32)
+    for f_ in failures:
+        print("FAIL (case, task, output, err, fp32-autograd err, cond, n, m, d, kind):", f_)
+    assert not failures, failures[:5]
 
 
 @pytest.mark.parametrize("kernel, regression, exact", [("rbf", False, True), ("matern", True, True), ("matern", False, False)])
@@ -188,9 +188,12 @@ def test_ill_conditioned_regression_task_is_resolved_stably(dev):
     noise, os_, ls = O.transform_phi(phi[0].double().cpu())
     A = O.kernel_matrix(zs.double(), zs.double(), os_, ls, 0) + noise * torch.eye(n, dtype=torch.float64)
     assert float(torch.linalg.cond(A)) > 500.0          # the regime this test is about
-    assert abs(out["f_out"][0].item() - q["f_out"]) <= 5e-3 * abs(q["f_out"])
-    assert _rel(out["dZ_s"][0].cpu().numpy(), q["dZs_total"]) <= 1e-3
-    assert _rel(out["dZ_q"][0].cpu().numpy(), q["dZq_total"]) <= 1e-3
+    # f_out = 0.55 is a cancellation of terms of size 58, -114 and 57: the 1e-4 is on the terms
+    ld_q = float(np.linalg.slogdet(q["pred_cov"])[1])
+    terms = 0.5 * (abs(2.0 * q["f_out"] - ld_q - m * math.log(2.0 * math.pi)) + abs(ld_q) + m * math.log(2.0 * math.pi))
+    assert abs(out["f_out"][0].item() - q["f_out"]) <= 1e-4 * terms
+    assert _rel(out["dZ_s"][0].cpu().numpy(), q["dZs_total"]) <= 2e-4
+    assert _rel(out["dZ_q"][0].cpu().numpy(), q["dZq_total"]) <= 2e-4
     mean, var, _, _ = gp_ops.predict(b, phi)
-    assert _rel(mean[0].cpu().numpy(), q["pred_mean"]) <= 2e-4
-    assert _rel(var[0].cpu().numpy(), q["pred_var"]) <= 2e-4
+    assert _rel(mean[0].cpu().numpy(), q["pred_mean"]) <= 1e-4
+    assert _rel(var[0].cpu().numpy(), q["pred_var"]) <= 1e-4

@@ -7,9 +7,9 @@ using namespace adkf;
 
 template <int LEVEL>
 __global__ __launch_bounds__(512) void k_chain(const float* A, float* out, int reps) {
-    using SW = Sweep<128, 512>;
+    using SW = SweepBlk<128, 512>;
     constexpr int RB = 8, CB = 4, B = 4, NBC = 32;
-    __shared__ SweepSmem<128, 512> sm;
+    __shared__ SweepSmemBlk<128, 512> sm;
     const int i0 = SW::br() * RB, j0 = SW::bc() * CB;
     float m[RB][CB];
     for (int r = 0; r < RB; ++r) for (int c = 0; c < CB; ++c) m[r][c] = A[(i0 + r) * 128 + j0 + c];

@@ -35,6 +35,32 @@ def d2_gemm_form(X, Y, mu):
     return D
 
 
+def sweep_inverse(A):
+    """-(sweep of all indices) = A^-1 the way factor.h does it: Gauss-Jordan without pivoting, in A's dtype (unblocked:
+    the 4-pivot blocking of the device changes the order of a few operations, not the error class)."""
+    M = A.copy()
+    n = M.shape[0]
+    one = M.dtype.type(1)
+    for k in range(n):
+        d = M[k, k]
+        r = M[k, :] / d
+        c = M[:, k].copy()
+        M -= np.outer(c, r)
+        M[k, :] = r
+        M[:, k] = r
+        M[k, k] = -one / d
+    return -M
+
+
+def refine_inverse(S, X, steps=1):
+    """Mixed-precision refinement of an explicit inverse: residual R = I - S X accumulated in float64 from the float32
+    matrices, correction X += X R applied in float32."""
+    for _ in range(steps):
+        R = (np.eye(S.shape[0]) - S.astype(f64) @ X.astype(f64)).astype(f32)
+        X = X + X @ R
+    return X
+
+
 def pipeline(Zs, ys, Zq, yq, phi, pri, kind, cfg):
     """cfg: set of stage names computed in float64 (inputs are always the float32 D2 the device has)."""
     Zs32, Zq32 = Zs.astype(f32), Zq.astype(f32)
@@ -55,7 +81,9 @@ def pipeline(Zs, ys, Zq, yq, phi, pri, kind, cfg):
     u, k0, k1, k2 = kap(D2ss, "ainv")
     K = dt(s) * k0
     A = K + dt(noise) * np.eye(n, dtype=dt)
-    Ainv = np.linalg.inv(A)
+    Ainv = sweep_inverse(A) if "sweep" in cfg else np.linalg.inv(A)
+    if "refine_a" in cfg:
+        Ainv = refine_inverse(A, Ainv)
     Ainv = 0.5 * (Ainv + Ainv.T)
     alpha = (Ainv @ ys.astype(dt)) if "alpha_solve" not in cfg else np.linalg.solve(A.astype(f64), ys.astype(f64))
     # what the later float32 stages see
@@ -109,7 +137,9 @@ def pipeline(Zs, ys, Zq, yq, phi, pri, kind, cfg):
     Cs, Bs = (Cm if "c" in cfg or "c_solve" in cfg else Cm.astype(f32)).astype(dt), (dt(s) * C.kappa(cast(D2qs, "s") / dt(l) ** 2, kind)[0])
     S = dt(s) * kqq0 - Cs @ Bs.T + dt(noise) * np.eye(m, dtype=dt)
     S = 0.5 * (S + S.T)
-    Sinv = np.linalg.inv(S)
+    Sinv = sweep_inverse(S) if "sweep" in cfg else np.linalg.inv(S)
+    if "refine_s" in cfg:
+        Sinv = refine_inverse(S, Sinv)
     Sinv = 0.5 * (Sinv + Sinv.T)
     r = yq.astype(dt) - mu_q.astype(dt)
     e = np.linalg.solve(S.astype(f64), r.astype(f64)).astype(dt) if dt == f64 else Sinv @ r
@@ -157,6 +187,10 @@ def pipeline(Zs, ys, Zq, yq, phi, pri, kind, cfg):
 CONFIGS = {
     "fp32": set(),                                              # explicit float32 inverses everywhere (round-1 before ldl.h)
     "ldl": {"alpha_solve", "c_solve"},                          # round 1: C and alpha by a stable solve, the rest float32
+    "ldl+sweep": {"alpha_solve", "c_solve", "sweep"},           # the device as it is: C / alpha solved stably, S and A inverted by the sweep
+    "ldl+sweep+refS": {"alpha_solve", "c_solve", "sweep", "refine_s"},
+    "ldl+sweep+refSA": {"alpha_solve", "c_solve", "sweep", "refine_s", "refine_a"},
+    "sweep+refSA": {"sweep", "refine_s", "refine_a"},           # no LDL at all: refined explicit inverses only
     "outer64": {"alpha_solve", "c_solve", "c", "s"},            # + S, S^-1, e, f_out in float64 (rounded to float32 afterwards)
     "outer64+ainv": {"ainv", "c", "s"},                         # + A^-1 in float64 (rounded) for the Hessian / mixed term
     "outer64+ainv+hess": {"ainv", "c", "s", "hess"},            # + Hessian traces in float64

@@ -8,9 +8,9 @@ using namespace adkf;
 
 template <int NMAX, int NT, int VAR>
 __global__ __launch_bounds__(NT) void k_sweep(const float* A, float* out, int n, int reps) {
-    using SW = Sweep<NMAX, NT>;
+    using SW = SweepBlk<NMAX, NT>;
     constexpr int RB = SW::RB, CB = SW::CB;
-    __shared__ SweepSmem<NMAX, NT> sm;
+    __shared__ SweepSmemBlk<NMAX, NT> sm;
     const int j0 = SW::bc() * CB;
     const float* At = A + (size_t)blockIdx.x * n * n;
     float a[RB][CB], m[RB][CB];
