@@ -94,21 +94,20 @@ template <> struct Sweep<128, 512> {
         }
     }
 
-    // pivot `a` of the rank-4 update of `slot`, applied to every register row but GX (the row the chain already brought up to date)
-    template <int GX>
-    __device__ static __forceinline__ void apply_pivot_except(float (&m)[RB][CB], int slot, int a, Smem& sm) {
+    // pivot `a` of the rank-4 update of `slot`, applied to every register row but `gx` (the row the chain already brought up
+    // to date): the skipped row takes part with a zero factor, so the instruction stream has static register indices whatever
+    // gx is (a runtime choice between differently-shaped updates sent the whole block to scratch)
+    __device__ static __forceinline__ void apply_pivot_except(float (&m)[RB][CB], int slot, int a, int gx, Smem& sm) {
         const int j0 = bc() * CB, i0 = row(0);
         const float4 f4 = *reinterpret_cast<const float4*>(&sm.fvec[slot][a][i0]);
         const float4 c0 = *reinterpret_cast<const float4*>(&sm.cross[slot][a][j0]);
         const float4 c1 = *reinterpret_cast<const float4*>(&sm.cross[slot][a][j0 + 4]);
-        const float fi[4] = {f4.x, f4.y, f4.z, f4.w};
+        const float fi[4] = {gx == 0 ? 0.f : f4.x, gx == 1 ? 0.f : f4.y, gx == 2 ? 0.f : f4.z, gx == 3 ? 0.f : f4.w};
         const float cj[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            if (r == GX) continue;
+        for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int c = 0; c < CB; ++c) m[r][c] = fmaf(-fi[r], cj[c], m[r][c]);
-        }
     }
 
     // Row update of one Gauss-Jordan step inside every quad:  x += g * (x of quad lane P)  for the remaining columns of D and
@@ -217,14 +216,7 @@ template <> struct Sweep<128, 512> {
 
     __device__ static __forceinline__ void pay_one(float (&m)[RB][CB], Owed& o, Smem& sm) {
 #if !(ADKF_W_ABLATE & 8)
-        if (o.k < B) {
-            const int slot = o.s % Smem::NSLOT;
-            if (o.g == 0) apply_pivot_except<0>(m, slot, o.k, sm);
-            else if (o.g == 1) apply_pivot_except<1>(m, slot, o.k, sm);
-            else if (o.g == 2) apply_pivot_except<2>(m, slot, o.k, sm);
-            else apply_pivot_except<3>(m, slot, o.k, sm);
-            ++o.k;
-        }
+        if (o.k < B) { apply_pivot_except(m, o.s % Smem::NSLOT, o.k, o.g, sm); ++o.k; }
 #else
         o.k = B;
 #endif
