@@ -8,7 +8,7 @@
 #include "ard.h"
 #include "pna.h"
 #include "outer_step.h"
-#include "ldl.h"
+#include "refine64.h"
 
 using namespace adkf;
 
@@ -45,6 +45,7 @@ struct Workspace {
     float *lg_Dinv, *lg_C, *lg_F, *lg_logdet, *lg_part;
     int32_t *lg_info, *lg_med;  // lg_med: prefix[T], rank[T], hist[T, 256]
     FitShared* lg_fit;
+    double* w64; size_t w64_stride;   // float64 region of the ill-conditioned-task path (refine64.h); null beyond R64_MAXN points
     int vld, nt_oc, nt_ma;
     size_t bytes;
 };
@@ -88,6 +89,11 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
         w.lg_info = reinterpret_cast<int32_t*>(take(Tz));
         w.lg_med = reinterpret_cast<int32_t*>(take(Tz * 258));
         w.lg_fit = reinterpret_cast<FitShared*>(take(Tz * ((sizeof(FitShared) + 3) / 4)));
+    }
+    w.w64 = nullptr; w.w64_stride = 0;
+    if (w.vld <= R64_MAXN) {
+        w.w64_stride = refine64_doubles(ns, nq);
+        w.w64 = reinterpret_cast<double*>(take(2 * Tz * w.w64_stride));
     }
     w.bytes = off;
     return w;
@@ -259,23 +265,19 @@ int launch_inner(InnerArgs a, const Workspace& w, hipStream_t st) {
     return 0;
 }
 
-// After ProbC: tasks whose A is ill-conditioned get C = K_qs A^-1 and alpha = A^-1 y re-solved through an LDL^T
-// factorisation (ldl.h); everybody else leaves the kernel after one reduction.  Register-path sizes only.
-void launch_ldl(const TaskView& tv, const adkf_batch_t* b, const Workspace& w, hipStream_t st) {
-    if (b->ns_max > REG_POINTS) return;
-    const size_t smem = ldl_smem_bytes(b->ns_max);
-    static const bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ldl_c), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)ldl_smem_bytes(REG_POINTS)) == hipSuccess;
-    }();
-    (void)attr_set;
-    // ADKF_LDL_THRESHOLD (read once) moves the switch-over for experiments: 0 re-solves every task, a huge value none
+// Ill-conditioned tasks redo the factorisation-type stages in float64 (refine64.h); everybody else leaves the kernel after
+// reading two scalars.  level: 0 = inner quantities (A^-1, alpha, scalars), 1 = + C, mu (prediction), 2 = + S^-1, e, f_out.
+void launch_refine(const TaskView& tv, const adkf_batch_t* b, const Workspace& w, bool with_hessian, int level, float* f_out,
+                   int32_t* info, hipStream_t st, float* f_in = nullptr, float* g_in = nullptr, float* gnorm = nullptr) {
+    if (!w.w64) return;
+    // ADKF_R64_THRESHOLD (read once) moves the switch-over for experiments: 0 sends every task through float64, a huge value none
     static const float thresh = [] {
-        const char* e = getenv("ADKF_LDL_THRESHOLD");
-        return e ? (float)atof(e) : LDL_THRESHOLD;
+        const char* e = getenv("ADKF_R64_THRESHOLD");
+        return e ? (float)atof(e) : R64_THRESHOLD;
     }();
-    LdlArgs la{tv, w.D2ss, w.D2qs, w.Ainv, b->y_s, w.C, w.vecs, thresh, b->T};
-    k_ldl_c<<<b->T, LDL_NT, smem, st>>>(la);
+    Refine64Args ra{tv, w.D2ss, w.D2qs, w.D2qq, b->y_s, b->y_q, b->priors, w.Ainv, with_hessian ? w.P : nullptr, level >= 1 ? w.C : nullptr,
+                    level >= 2 ? w.S : nullptr, w.vecs, w.scal, f_out, info, f_in, g_in, gnorm, w.w64, w.w64_stride, thresh, b->T, with_hessian ? 1 : 0, level};
+    k_refine64<<<b->T, R64_NT, 0, st>>>(ra);
 }
 
 int launch_outer_factor(const OuterArgs& a, const Workspace& w, int nq, hipStream_t st) {
@@ -358,13 +360,13 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
     }
     ProbC pc; pc.tv = tv; pc.Ainv = w.Ainv; pc.D2qs = w.D2qs; pc.C = w.C;
     launch_gemm(pc, T, nq, ns, st);
-    launch_ldl(tv, b, w, st);
     ProbS ps; ps.tv = tv; ps.C = w.C; ps.D2qs = w.D2qs; ps.D2qq = w.D2qq; ps.S = w.S;
     launch_gemm(ps, T, nq, nq, st);
     // (reused inner stage: A^-1, alpha and the scalars of phi are in the workspace, info[] is written by the outer factor)
     OuterArgs oa{tv, w.C, w.S, b->y_s, b->y_q, w.vecs, w.scal, f_out, info, T, reuse_inner ? 1 : 0};
     rc = launch_outer_factor(oa, w, nq, st);
     if (rc) return rc;
+    launch_refine(tv, b, w, with_hessian, 2, f_out, info, st);
     ProbOC po; po.tv = tv; po.Sinv = w.S; po.C = w.C; po.D2qs = w.D2qs; po.OC = w.OC; po.Wqs = w.Wqs; po.part = w.part_oc; po.ntiles = w.nt_oc; po.dirscale = dirscale;
     launch_gemm(po, T, nq, ns, st);
     ProbMA pm; pm.tv = tv; pm.C = w.C; pm.OC = w.OC; pm.D2ss = w.D2ss; pm.Wss = w.Wss; pm.part = w.part_ma; pm.ntiles = w.nt_ma; pm.dirscale = dirscale;
@@ -565,12 +567,12 @@ int ard_fit(const adkf_batch_t* b, float* phi, const adkf_fit_options_t* opt, fl
 }
 
 // C = K_qs A^-1, predictive mean / variance (/ covariance) from the distances, A^-1 and scalars in the workspace
-int predict_core(const adkf_batch_t* b, const Workspace& w, float* mean, float* var, float* cov, hipStream_t st) {
+int predict_core(const adkf_batch_t* b, const Workspace& w, float* mean, float* var, float* cov, int32_t* info, hipStream_t st) {
     TaskView tv = make_tv(b, w, true);
     const int T = b->T;
     ProbC pc; pc.tv = tv; pc.Ainv = w.Ainv; pc.D2qs = w.D2qs; pc.C = w.C;
     launch_gemm(pc, T, b->nq_max, b->ns_max, st);
-    launch_ldl(tv, b, w, st);
+    launch_refine(tv, b, w, false, 1, nullptr, info, st);
     PredArgs pa{tv, w.C, w.D2qs, b->y_s, mean, var, w.scal, T};
     k_predict<<<grid_for(T, 1), 256, 0, st>>>(pa);
     if (cov) {
@@ -757,6 +759,7 @@ int adkf_mll_value_grad(const adkf_batch_t* b, const float* phi, float* f_in, fl
     ia.f_out = f_in; ia.g_out = g_phi;
     rc = launch_inner(ia, w, st);
     if (rc) return rc;
+    launch_refine(make_tv(b, w, false), b, w, false, 0, nullptr, info, st, f_in, g_phi, nullptr);
     if (dZ_s) {
         TaskView tv = make_tv(b, w, false);
         const int win_tiles = std::max(1, std::min(64, b->ns_max * b->ns_max / 2048));
@@ -789,7 +792,10 @@ int adkf_fit(const adkf_batch_t* b, float* phi, const adkf_fit_options_t* opt, f
     if (opt->ev_start && hipEventRecord(static_cast<hipEvent_t>(opt->ev_start), st) != hipSuccess) return ADKF_E_LAUNCH;
     rc = launch_inner(ia, w, st);
     if (opt->ev_stop && hipEventRecord(static_cast<hipEvent_t>(opt->ev_stop), st) != hipSuccess) return ADKF_E_LAUNCH;
-    return rc;
+    if (rc) return rc;
+    launch_refine(make_tv(b, w, false), b, w, false, 0, nullptr, info, st, f_final, nullptr, gnorm);   // ill-conditioned tasks: float64 value at phi*
+    LAUNCH_OK();
+    return 0;
 }
 
 int adkf_predict(const adkf_batch_t* b, const float* phi, float* mean, float* var, float* cov, int32_t* info, void* ws,
@@ -805,7 +811,7 @@ int adkf_predict(const adkf_batch_t* b, const float* phi, float* mean, float* va
         rc = ard_outer(c, phi, 0, nullptr, info, false);
         if (rc) return rc;
         adkf_batch_t bq = c.bt;
-        return predict_core(&bq, c.w, mean, var, cov, c.st);
+        return predict_core(&bq, c.w, mean, var, cov, info, c.st);
     }
     Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
@@ -819,7 +825,7 @@ int adkf_predict(const adkf_batch_t* b, const float* phi, float* mean, float* va
         rc = launch_inner(ia, w, st);
         if (rc) return rc;
     }
-    return predict_core(b, w, mean, var, cov, st);
+    return predict_core(b, w, mean, var, cov, info, st);
 }
 
 int adkf_outer_nll_value_grad(const adkf_batch_t* b, const float* phi, float* f_out, float* g_phi, float* dZ_s,

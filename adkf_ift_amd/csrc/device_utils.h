@@ -26,6 +26,7 @@ enum Scal : int {
     S_CN, S_CS, S_CL,                   // coefficients of B_v = cn I + cs K + cl G
     S_FOUT, S_LOGDETS,
     S_QQ_TR, S_QQ_K, S_QQ_L,            // reductions of the W_qq kernel: tr(Om), <Om,kappa>, <Om,dK/dl>
+    S_PIVR_A, S_PIVR_S,                 // pivot ratio max d_k / min d_k of the sweeps of A and Sigma_q (refine64.h)
     S_COUNT_ = 64
 };
 constexpr int NSCAL = 64;

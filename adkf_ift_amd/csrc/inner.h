@@ -311,6 +311,22 @@ __device__ __forceinline__ void fit_advance(FitShared& fs, const InnerArgs& a, f
     fs.phase = phase;
 }
 
+// max pivot / min pivot over pivs[0..n) (n <= 128: the first two waves hold them); +inf when a pivot is not positive.
+// Contains two barriers; all threads call; all get the value.
+template <int NT>
+__device__ __forceinline__ float pivot_ratio(const float* pivs, int n, float* red) {
+    const int tid = threadIdx.x;
+    float lo = INFINITY, hi = 0.f;
+    for (int k = tid; k < n; k += NT) { const float p = pivs[k]; lo = fminf(lo, p); hi = fmaxf(hi, p); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+    __syncthreads();
+    if ((tid & 63) == 0) { red[2 * (tid >> 6)] = lo; red[2 * (tid >> 6) + 1] = hi; }
+    __syncthreads();
+    for (int w = 0; w < NT / 64; ++w) { lo = fminf(lo, red[2 * w]); hi = fmaxf(hi, red[2 * w + 1]); }
+    return lo > 0.f ? hi / lo : INFINITY;
+}
+
 // The per-task scalars later stages (Hessian, outer NLL, mixed term) read back from the workspace.
 __device__ __forceinline__ void write_inner_scal(float* sc, const float* xe, float f, const float* g, const float* extra) {
     sc[S_NOISE] = softplus_f(xe[0]) + NOISE_LB; sc[S_OS] = softplus_f(xe[1]); sc[S_LS] = softplus_f(xe[2]);
@@ -378,6 +394,10 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
         if (a.gnorm_out) a.gnorm_out[t] = fmaxf(fabsf(g[0]), fmaxf(fabsf(g[1]), fabsf(g[2])));
         if (a.nevals_out) a.nevals_out[t] = evals;
         if (a.scal) write_inner_scal(a.scal + (size_t)t * NSCAL, xe, f, g, extra);
+    }
+    if (a.scal) {   // pivot ratio of the final sweep: the cheap condition estimate refine64.h flags tasks by
+        const float pr = pivot_ratio<NT>(sm.pivs, n, sm.red);
+        if (tid == 0) a.scal[(size_t)t * NSCAL + S_PIVR_A] = pr;
     }
     if (a.vecs && tid < n) a.vecs[((size_t)t * NVEC + V_ALPHA) * a.vld + tid] = sm.vec_out[tid];
     if (a.Ainv) {

@@ -320,6 +320,8 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
     SW::run(mm, m, sm);
     float logdet;
     const int info = SW::finish(m, sm, logdet);
+    const float pivr = pivot_ratio<NT>(sm.pivs, m, sm.red);
+    if (tid == 0) a.scal[(size_t)t * NSCAL + S_PIVR_S] = pivr;
     SW::solve(mm, sm.vec_in, sm.vec_out);  // e = S^-1 r
     float q[1] = {0.f};
     if (tid < m) {

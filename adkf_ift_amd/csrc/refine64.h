@@ -1,0 +1,346 @@
+// k_refine64: the float64 path of ILL-CONDITIONED tasks.
+//
+// The pipeline keeps A^-1 and Sigma_q^-1 as explicit float32 matrices (the sweep yields them for free and the closed
+// forms need every entry).  That is accurate to eps32 * cond: fine for every benchmark configuration (noise 0.1, or features
+// of dimension >= 64: pivot ratios below 10), wrong by 1e-3 .. 1e-2 on dL/dZ, grad_phi f_out and v for regression tasks
+// with noise ~0.01 on clustered low-dimensional features (cond 1e3 .. 5e3), where the reference - GPyTorch: Cholesky +
+// triangular solves, fs_mol/models/adaptive_dkt.py:183-191 - stays at 1e-5 .. 1e-4.  A CPU emulation of the precision
+// choices (tools/emulate_precision.py, 180 random tasks) shows what it takes to reach 1e-4 everywhere: A^-1, alpha, the
+// Hessian traces, C = K_qs A^-1, Sigma_q, Sigma_q^-1 and e COMPUTED in float64 and only then rounded to float32 for the
+// cotangent algebra (an explicit inverse ROUNDED to float32 is accurate entry by entry, which is what the element-wise
+// products with kappa' need; the float32 arithmetic that produced it was the problem).  Mixed-precision refinement of
+// the float32 inverses alone is not enough, nor is a float32 LDL^T re-solve of C and alpha (round 1's ldl.h, replaced by
+// this file).
+//
+// So: after the float32 stages have run for everybody, ONE workgroup per flagged task redoes, in float64 from the
+// float32 squared distances, everything between the kernel matrices and the cotangent stage
+//     A -> Cholesky -> A^-1, alpha, log|A| -> P = A^-1 G, beta, gamma, delta, the nine traces -> 3 x 3 Hessian
+//     C = K_qs A^-1, mu, r, S = K_qq - C K_sq + noise I -> Cholesky -> S^-1, e, log|S|, f_out, C^T e
+// and overwrites the float32 buffers the later kernels read.  A task is flagged when the pivot ratio max d_k / min d_k of
+// its sweep (a lower bound of the condition number; <= (s + noise) / noise) exceeds `thresh` for A or for Sigma_q; tasks on
+// the blocked path (> 128 points, no pivot ratio at hand) are flagged by (s + noise) / noise itself.  Everything lives in
+// a float64 region of the caller's workspace (L2-resident); plain loops - this is the slow path, it only has to be right.
+#pragma once
+#include "kernels.h"
+
+namespace adkf {
+
+constexpr int R64_NT = 512;
+constexpr int R64_MAXN = 256;          // float64 region is carved for batches up to this many points
+constexpr float R64_THRESHOLD = 30.f;
+
+struct Refine64Args {
+    TaskView tv;
+    const float *D2ss, *D2qs, *D2qq, *y_s, *y_q, *priors;
+    float *Ainv, *P, *C, *S;           // float32 buffers to overwrite (P, C, S may be null)
+    float* vecs; float* scal; float* f_out; int32_t* info;
+    float *f_in, *g_in, *gnorm;        // optional: the refined inner value / raw gradient / max |gradient| (adkf_fit, adkf_mll_value_grad)
+    double* w64; size_t w64_stride;    // [T][stride] doubles
+    float thresh; int T, want_hess, want_outer;   // want_outer: 0 = inner quantities only, 1 = + C and mu (prediction), 2 = + S, S^-1, e, f_out
+};
+
+inline size_t refine64_doubles(int ns, int nq) {
+    return 3 * (size_t)ns * ns + 2 * (size_t)nq * ns + 2 * (size_t)nq * nq + 8 * (size_t)(ns > nq ? ns : nq) + 64;
+}
+
+__device__ __forceinline__ void kappa3_d(int kind, double u, double& k0, double& k1, double& k2) {
+    if (kind == 0) { k0 = exp(-0.5 * u); k1 = -0.5 * k0; k2 = 0.25 * k0; }
+    else {
+        const double r = sqrt(u), e = exp(-2.23606797749979 * r);
+        k0 = (1.0 + 2.23606797749979 * r + (5.0 / 3.0) * u) * e;
+        k1 = -(5.0 / 6.0) * (1.0 + 2.23606797749979 * r) * e;
+        k2 = (25.0 / 12.0) * e;
+    }
+}
+
+// sum over the workgroup; every thread gets the total (two barriers)
+__device__ __forceinline__ double r64_sum(double v, double* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < R64_NT / 64; ++i) s += red[i];
+    return s;
+}
+
+// In-place Cholesky of the lower triangle of M (n x n, leading dimension ld); returns the first non-positive pivot
+// (1-based) or 0, log|M| through logdet.  Right-looking, the whole workgroup.
+__device__ int r64_cholesky(double* M, int n, int ld, double& logdet, double* red) {
+    const int tid = threadIdx.x;
+    int bad = 0;
+    double ld_acc = 0.0;
+    for (int k = 0; k < n; ++k) {
+        __syncthreads();
+        const double p = M[(size_t)k * ld + k];
+        if (!(p > 0.0)) { if (!bad) bad = k + 1; }
+        const double lkk = sqrt(p > 0.0 ? p : 1.0);
+        ld_acc += 2.0 * log(lkk);
+        __syncthreads();
+        for (int i = k + tid; i < n; i += R64_NT) M[(size_t)i * ld + k] = (i == k) ? lkk : M[(size_t)i * ld + k] / lkk;
+        __syncthreads();
+        const int rem = n - k - 1;
+        for (int e = tid; e < rem * rem; e += R64_NT) {
+            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
+            if (j <= i) M[(size_t)i * ld + j] -= M[(size_t)i * ld + k] * M[(size_t)j * ld + k];
+        }
+    }
+    __syncthreads();
+    (void)red;
+    logdet = ld_acc;
+    return bad;
+}
+
+// X = L^-1 (lower triangular) from the Cholesky factor in L; X and L distinct buffers.  One column per thread.
+__device__ void r64_tri_inverse(const double* L, double* X, int n, int ld) {
+    for (int j = threadIdx.x; j < n; j += R64_NT) {
+        for (int i = 0; i < j; ++i) X[(size_t)i * ld + j] = 0.0;
+        X[(size_t)j * ld + j] = 1.0 / L[(size_t)j * ld + j];
+        for (int i = j + 1; i < n; ++i) {
+            double s = 0.0;
+            for (int k = j; k < i; ++k) s += L[(size_t)i * ld + k] * X[(size_t)k * ld + j];
+            X[(size_t)i * ld + j] = -s / L[(size_t)i * ld + i];
+        }
+    }
+    __syncthreads();
+}
+
+// Out = X^T X for lower-triangular X (= the inverse of the factored matrix), full symmetric result
+__device__ void r64_xtx(const double* X, double* Out, int n, int ld) {
+    for (int e = threadIdx.x; e < n * n; e += R64_NT) {
+        const int i = e / n, j = e % n;
+        if (j > i) continue;
+        double s = 0.0;
+        for (int k = i; k < n; ++k) s += X[(size_t)k * ld + i] * X[(size_t)k * ld + j];
+        Out[(size_t)i * ld + j] = s;
+        Out[(size_t)j * ld + i] = s;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
+    __shared__ double red[R64_NT / 64];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    if (t >= a.T) return;
+    const int n = a.tv.ns(t), m = a.want_outer ? a.tv.nq(t) : 0, ld = a.tv.ns_ld, ldq = a.tv.nq_ld, vld = a.tv.vld;
+    if (n <= 0) return;
+    float* sc = a.scal + (size_t)t * NSCAL;
+    const double noise = sc[S_NOISE], os = sc[S_OS], ls = sc[S_LS], il2 = 1.0 / (ls * ls);
+    const int kind = a.tv.kind;
+    // ---- flagged?
+    const float bound = (float)((os + noise) / noise);
+    const float ra = ld <= 128 ? sc[S_PIVR_A] : bound;
+    const float rs = a.want_outer < 2 ? 0.f : (ldq <= 128 ? sc[S_PIVR_S] : bound);
+    if (!(ra > a.thresh || rs > a.thresh)) return;       // uniform over the workgroup
+
+    double* W = a.w64 + (size_t)t * a.w64_stride;
+    double* A1 = W;                                 // A -> L -> A^-1
+    double* A2 = A1 + (size_t)ld * ld;              // L^-1, then G
+    double* A3 = A2 + (size_t)ld * ld;              // P
+    double* B1 = A3 + (size_t)ld * ld;              // K_qs
+    double* B2 = B1 + (size_t)ldq * ld;             // C
+    double* S1 = B2 + (size_t)ldq * ld;             // S -> L_S -> S^-1
+    double* S2 = S1 + (size_t)ldq * ldq;            // L_S^-1
+    const int vmax = ld > ldq ? ld : ldq;
+    double* v_al = S2 + (size_t)ldq * ldq;          // alpha, beta, gamma, delta, r, e, mu, spare
+    double* v_be = v_al + vmax; double* v_ga = v_be + vmax; double* v_de = v_ga + vmax;
+    double* v_r = v_de + vmax; double* v_e = v_r + vmax; double* v_mu = v_e + vmax;
+    const float* D2 = a.D2ss + (size_t)t * ld * ld;
+    const float* ys = a.y_s + (size_t)t * ld;
+    float* vb = a.vecs + (size_t)t * NVEC * vld;
+
+    // ---- A, Cholesky, A^-1, alpha
+    for (int e = tid; e < n * n; e += R64_NT) {
+        const int i = e / n, j = e % n;
+        double k0, k1, k2; kappa3_d(kind, (double)D2[(size_t)i * ld + j] * il2, k0, k1, k2);
+        A1[(size_t)i * ld + j] = os * k0 + (i == j ? noise : 0.0);
+    }
+    double logdetA;
+    const int badA = r64_cholesky(A1, n, ld, logdetA, red);
+    r64_tri_inverse(A1, A2, n, ld);
+    r64_xtx(A2, A1, n, ld);
+    float* Ai32 = a.Ainv + (size_t)t * ld * ld;
+    for (int e = tid; e < n * n; e += R64_NT) { const int i = e / n, j = e % n; Ai32[(size_t)i * ld + j] = (float)A1[(size_t)i * ld + j]; }
+    for (int i = tid; i < n; i += R64_NT) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += A1[(size_t)i * ld + j] * (double)ys[j];
+        v_al[i] = s;
+        vb[V_ALPHA * vld + i] = (float)s;
+    }
+    __syncthreads();
+
+    // ---- inner scalars and the 3 x 3 Hessian (oracle/closed_form.py::inner_stage)
+    {
+        for (int e = tid; e < n * n; e += R64_NT) {   // G = dK/dl
+            const int i = e / n, j = e % n;
+            const double u = (double)D2[(size_t)i * ld + j] * il2;
+            double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
+            A2[(size_t)i * ld + j] = os * k1 * u * (-2.0 / ls);
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += R64_NT) {
+            double sb = 0.0, sg = 0.0;
+            for (int j = 0; j < n; ++j) { sb += A2[(size_t)i * ld + j] * v_al[j]; sg += A1[(size_t)i * ld + j] * v_al[j]; }
+            v_be[i] = sb; v_ga[i] = sg;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += R64_NT) {
+            double sd = 0.0;
+            for (int j = 0; j < n; ++j) sd += A1[(size_t)i * ld + j] * v_be[j];
+            v_de[i] = sd;
+        }
+        if (a.want_hess) {
+            for (int e = tid; e < n * n; e += R64_NT) {   // P = A^-1 G
+                const int i = e / n, j = e % n;
+                double s = 0.0;
+                for (int k = 0; k < n; ++k) s += A1[(size_t)i * ld + k] * A2[(size_t)k * ld + j];
+                A3[(size_t)i * ld + j] = s;
+            }
+        }
+        __syncthreads();
+        double trAinv = 0, trAinvG = 0, aGa = 0, trA2 = 0, trPA = 0, trPP = 0, trAinvKll = 0, aKlla = 0;
+        for (int e = tid; e < n * n; e += R64_NT) {
+            const int i = e / n, j = e % n;
+            const double ai = A1[(size_t)i * ld + j], g = A2[(size_t)i * ld + j];
+            if (i == j) trAinv += ai;
+            trAinvG += ai * g; aGa += v_al[i] * v_al[j] * g; trA2 += ai * ai;
+            if (a.want_hess) {
+                const double pij = A3[(size_t)i * ld + j], pji = A3[(size_t)j * ld + i];
+                const double u = (double)D2[(size_t)i * ld + j] * il2;
+                double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
+                const double Kll = os * (k2 * 4.0 * u * u + k1 * 6.0 * u) * il2;
+                trPA += pij * ai; trPP += pij * pji; trAinvKll += ai * Kll; aKlla += v_al[i] * v_al[j] * Kll;
+            }
+        }
+        double aa = 0, ya = 0, ag = 0, bg = 0, bd = 0, ab = 0;
+        for (int i = tid; i < n; i += R64_NT) {
+            aa += v_al[i] * v_al[i]; ya += (double)ys[i] * v_al[i]; ag += v_al[i] * v_ga[i]; bg += v_be[i] * v_ga[i];
+            bd += v_be[i] * v_de[i]; ab += v_al[i] * v_be[i];
+        }
+        trAinv = r64_sum(trAinv, red); trAinvG = r64_sum(trAinvG, red); aGa = r64_sum(aGa, red); trA2 = r64_sum(trA2, red);
+        trPA = r64_sum(trPA, red); trPP = r64_sum(trPP, red); trAinvKll = r64_sum(trAinvKll, red); aKlla = r64_sum(aKlla, red);
+        aa = r64_sum(aa, red); ya = r64_sum(ya, red); ag = r64_sum(ag, red); bg = r64_sum(bg, red); bd = r64_sum(bd, red); ab = r64_sum(ab, red);
+        for (int i = tid; i < n; i += R64_NT) { vb[V_BETA * vld + i] = (float)v_be[i]; vb[V_GAMMA * vld + i] = (float)v_ga[i]; vb[V_DELTA * vld + i] = (float)v_de[i]; }
+        if (a.want_hess && a.P) {
+            float* P32 = a.P + (size_t)t * ld * ld;
+            for (int e = tid; e < n * n; e += R64_NT) { const int i = e / n, j = e % n; P32[(size_t)i * ld + j] = (float)A3[(size_t)i * ld + j]; }
+        }
+        if (tid == 0) {
+            const float* pri = a.priors + t * 4;
+            const double fn = (double)n;
+            const double d1[3] = {sc[S_D1N], sc[S_D1S], sc[S_D1L]}, d2[3] = {sc[S_D2N], sc[S_D2S], sc[S_D2L]};
+            double lp = 0, dpn = 0, dpl = 0, d2pn = 0, d2pl = 0;
+            if (pri[1] > 0.f) {
+                const double lx = log(noise), s2 = (double)pri[1] * pri[1], z = (lx - pri[0]) / s2;
+                lp += -lx - log((double)pri[1]) - 0.5 * 1.8378770664093453 - 0.5 * (lx - pri[0]) * z;
+                dpn = (-1.0 - z) / noise; d2pn = (1.0 + z - 1.0 / s2) / (noise * noise);
+            }
+            if (pri[3] > 0.f) {
+                const double lx = log(ls), s2 = (double)pri[3] * pri[3], z = (lx - pri[2]) / s2;
+                lp += -lx - log((double)pri[3]) - 0.5 * 1.8378770664093453 - 0.5 * (lx - pri[2]) * z;
+                dpl = (-1.0 - z) / ls; d2pl = (1.0 + z - 1.0 / s2) / (ls * ls);
+            }
+            const double nll = 0.5 * ya + 0.5 * logdetA + 0.5 * fn * 1.8378770664093453;
+            const double gt0 = 0.5 * trAinv - 0.5 * aa - dpn;
+            const double gt1 = (0.5 * (fn - noise * trAinv) - 0.5 * (ya - noise * aa)) / os;
+            const double gt2 = 0.5 * trAinvG - 0.5 * aGa - dpl;
+            sc[S_FIN] = (float)((nll - lp) / fn);
+            sc[S_GIN0] = (float)(gt0 * d1[0] / fn); sc[S_GIN1] = (float)(gt1 * d1[1] / fn); sc[S_GIN2] = (float)(gt2 * d1[2] / fn);
+            if (a.f_in) a.f_in[t] = badA ? INFINITY : sc[S_FIN];
+            if (a.g_in) { a.g_in[t * 3 + 0] = sc[S_GIN0]; a.g_in[t * 3 + 1] = sc[S_GIN1]; a.g_in[t * 3 + 2] = sc[S_GIN2]; }
+            if (a.gnorm) a.gnorm[t] = fmaxf(fabsf(sc[S_GIN0]), fmaxf(fabsf(sc[S_GIN1]), fabsf(sc[S_GIN2])));
+            sc[S_LOGDET] = (float)logdetA; sc[S_TRAINV] = (float)trAinv; sc[S_AA] = (float)aa; sc[S_YA] = (float)ya;
+            sc[S_TRAINVG] = (float)trAinvG; sc[S_AGA] = (float)aGa; sc[S_GT0] = (float)gt0; sc[S_GT1] = (float)gt1; sc[S_GT2] = (float)gt2;
+            if (a.want_hess) {
+                double h[3][3];
+                h[0][0] = ag - 0.5 * trA2 - d2pn;
+                h[0][1] = ((aa - noise * ag) - 0.5 * (trAinv - noise * trA2)) / os;
+                h[0][2] = bg - 0.5 * trPA;
+                h[1][1] = ((ya - 2.0 * noise * aa + noise * noise * ag) - 0.5 * (fn - 2.0 * noise * trAinv + noise * noise * trA2)) / (os * os);
+                h[1][2] = ((ab - noise * bg) - 0.5 * (trAinvG - noise * trPA)) / os - (0.5 * aGa - 0.5 * trAinvG) / os;
+                h[2][2] = bd - 0.5 * aKlla - 0.5 * trPP + 0.5 * trAinvKll - d2pl;
+                h[1][0] = h[0][1]; h[2][0] = h[0][2]; h[2][1] = h[1][2];
+                const double gt[3] = {gt0, gt1, gt2};
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) sc[S_H0 + i * 3 + j] = (float)((h[i][j] * d1[i] * d1[j] + (i == j ? gt[i] * d2[i] : 0.0)) / fn);
+            }
+            if (badA && a.info[t] == 0) a.info[t] = badA;
+        }
+    }
+    __syncthreads();
+    if (m <= 0) return;
+
+    // ---- outer: C, mu, r, S, S^-1, e, f_out, C^T e   (oracle/closed_form.py::outer_stage)
+    const float* Dqs = a.D2qs + (size_t)t * ldq * ld;
+    const float* Dqq = a.D2qq + (size_t)t * ldq * ldq;
+    const float* yq = a.y_q + (size_t)t * ldq;
+    for (int e = tid; e < m * n; e += R64_NT) {
+        const int i = e / n, j = e % n;
+        double k0, k1, k2; kappa3_d(kind, (double)Dqs[(size_t)i * ld + j] * il2, k0, k1, k2);
+        B1[(size_t)i * ld + j] = os * k0;
+    }
+    __syncthreads();
+    for (int e = tid; e < m * n; e += R64_NT) {
+        const int i = e / n, j = e % n;
+        double s = 0.0;
+        for (int k = 0; k < n; ++k) s += B1[(size_t)i * ld + k] * A1[(size_t)k * ld + j];
+        B2[(size_t)i * ld + j] = s;
+    }
+    for (int i = tid; i < m; i += R64_NT) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += B1[(size_t)i * ld + j] * v_al[j];
+        v_mu[i] = s; v_r[i] = (double)yq[i] - s;
+    }
+    __syncthreads();
+    if (a.C) {
+        float* C32 = a.C + (size_t)t * ldq * ld;
+        for (int e = tid; e < m * n; e += R64_NT) { const int i = e / n, j = e % n; C32[(size_t)i * ld + j] = (float)B2[(size_t)i * ld + j]; }
+    }
+    if (a.want_outer < 2) {
+        for (int i = tid; i < m; i += R64_NT) vb[V_MU * vld + i] = (float)v_mu[i];
+        return;
+    }
+    for (int e = tid; e < m * m; e += R64_NT) {
+        const int i = e / m, j = e % m;
+        if (j > i) continue;
+        double k0, k1, k2; kappa3_d(kind, (double)Dqq[(size_t)i * ldq + j] * il2, k0, k1, k2);
+        double s = os * k0 + (i == j ? noise : 0.0);
+        for (int k = 0; k < n; ++k) s -= B2[(size_t)i * ld + k] * B1[(size_t)j * ld + k];
+        S1[(size_t)i * ldq + j] = s; S1[(size_t)j * ldq + i] = s;
+    }
+    double logdetS;
+    const int badS = r64_cholesky(S1, m, ldq, logdetS, red);
+    r64_tri_inverse(S1, S2, m, ldq);
+    r64_xtx(S2, S1, m, ldq);
+    if (a.S) {
+        float* S32 = a.S + (size_t)t * ldq * ldq;
+        for (int e = tid; e < m * m; e += R64_NT) { const int i = e / m, j = e % m; S32[(size_t)i * ldq + j] = (float)S1[(size_t)i * ldq + j]; }
+    }
+    for (int i = tid; i < m; i += R64_NT) {
+        double s = 0.0;
+        for (int j = 0; j < m; ++j) s += S1[(size_t)i * ldq + j] * v_r[j];
+        v_e[i] = s;
+    }
+    __syncthreads();
+    double q = 0.0;
+    for (int i = tid; i < m; i += R64_NT) {
+        q += v_r[i] * v_e[i];
+        vb[V_MU * vld + i] = (float)v_mu[i]; vb[V_R * vld + i] = (float)v_r[i]; vb[V_E * vld + i] = (float)v_e[i];
+    }
+    q = r64_sum(q, red);
+    for (int j = tid; j < n; j += R64_NT) {
+        double s = 0.0;
+        for (int i = 0; i < m; ++i) s += B2[(size_t)i * ld + j] * v_e[i];
+        vb[V_CTE * vld + j] = (float)s;
+    }
+    if (tid == 0) {
+        const double f = 0.5 * q + 0.5 * logdetS + 0.5 * (double)m * 1.8378770664093453;
+        sc[S_FOUT] = (float)f; sc[S_LOGDETS] = (float)logdetS;
+        if (a.f_out) a.f_out[t] = badS ? NAN : (float)f;
+        if (badS && a.info[t] == 0) a.info[t] = 100000 + badS;
+    }
+}
+
+}  // namespace adkf
