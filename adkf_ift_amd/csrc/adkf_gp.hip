@@ -265,6 +265,31 @@ int launch_inner(InnerArgs a, const Workspace& w, hipStream_t st) {
     return 0;
 }
 
+// (s + noise) max_i (A^-1)_ii above which C and alpha get one step of float32 iterative refinement (ADKF_REFINE32_THRESHOLD moves it)
+float refine32_threshold() {
+    static const float thresh = [] {
+        const char* e = getenv("ADKF_REFINE32_THRESHOLD");
+        return e ? (float)atof(e) : 3.f;
+    }();
+    return thresh;
+}
+
+void launch_alpha_refine(const TaskView& tv, const adkf_batch_t* b, const Workspace& w, hipStream_t st) {
+    AlphaRefineArgs aa{tv, w.Ainv, w.D2ss, b->y_s, w.vecs, refine32_threshold(), b->T};
+    k_alpha_refine<<<grid_for(b->T, 1), SMALL_NT, 0, st>>>(aa);
+}
+
+// C = K_qs A^-1 followed, for the tasks that need it, by one refinement step (R lives in w.OC, which ProbOC fills later)
+void launch_c(const TaskView& tv, const adkf_batch_t* b, const Workspace& w, hipStream_t st) {
+    const int T = b->T, ns = b->ns_max, nq = b->nq_max;
+    ProbC pc; pc.tv = tv; pc.Ainv = w.Ainv; pc.D2qs = w.D2qs; pc.C = w.C;
+    launch_gemm(pc, T, nq, ns, st);
+    ProbCres pr; pr.tv = tv; pr.C = w.C; pr.D2ss = w.D2ss; pr.D2qs = w.D2qs; pr.R = w.OC; pr.thresh = refine32_threshold();
+    launch_gemm(pr, T, nq, ns, st);
+    ProbCfix pf; pf.tv = tv; pf.R = w.OC; pf.Ainv = w.Ainv; pf.C = w.C; pf.thresh = refine32_threshold();
+    launch_gemm(pf, T, nq, ns, st);
+}
+
 // Ill-conditioned tasks redo the factorisation-type stages in float64 (refine64.h); everybody else leaves the kernel after
 // reading two scalars.  level: 0 = inner quantities (A^-1, alpha, scalars), 1 = + C, mu (prediction), 2 = + S^-1, e, f_out.
 void launch_refine(const TaskView& tv, const adkf_batch_t* b, const Workspace& w, bool with_hessian, int level, float* f_out,
@@ -339,6 +364,7 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         if (rc) return rc;
     }
     TaskView tv = make_tv(b, w, true);
+    launch_alpha_refine(tv, b, w, st);
     const int tms = ceil_div(ns, GT), tmq = ceil_div(nq, GT);
     const float dirscale = (flags & ADKF_IGNORE_DIRECT_GRAD) ? 0.f : 1.f;
     const float corrscale = (with_hessian && !(flags & ADKF_IGNORE_GRAD_CORRECTION)) ? 1.f : 0.f;
@@ -358,8 +384,7 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
             k_hess<<<grid_for(T, 1), SMALL_NT, 0, st>>>(ha);
         }
     }
-    ProbC pc; pc.tv = tv; pc.Ainv = w.Ainv; pc.D2qs = w.D2qs; pc.C = w.C;
-    launch_gemm(pc, T, nq, ns, st);
+    launch_c(tv, b, w, st);
     ProbS ps; ps.tv = tv; ps.C = w.C; ps.D2qs = w.D2qs; ps.D2qq = w.D2qq; ps.S = w.S;
     launch_gemm(ps, T, nq, nq, st);
     // (reused inner stage: A^-1, alpha and the scalars of phi are in the workspace, info[] is written by the outer factor)
@@ -570,8 +595,8 @@ int ard_fit(const adkf_batch_t* b, float* phi, const adkf_fit_options_t* opt, fl
 int predict_core(const adkf_batch_t* b, const Workspace& w, float* mean, float* var, float* cov, int32_t* info, hipStream_t st) {
     TaskView tv = make_tv(b, w, true);
     const int T = b->T;
-    ProbC pc; pc.tv = tv; pc.Ainv = w.Ainv; pc.D2qs = w.D2qs; pc.C = w.C;
-    launch_gemm(pc, T, b->nq_max, b->ns_max, st);
+    launch_alpha_refine(tv, b, w, st);
+    launch_c(tv, b, w, st);
     launch_refine(tv, b, w, false, 1, nullptr, info, st);
     PredArgs pa{tv, w.C, w.D2qs, b->y_s, mean, var, w.scal, T};
     k_predict<<<grid_for(T, 1), 256, 0, st>>>(pa);

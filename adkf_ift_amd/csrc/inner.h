@@ -395,9 +395,26 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
         if (a.nevals_out) a.nevals_out[t] = evals;
         if (a.scal) write_inner_scal(a.scal + (size_t)t * NSCAL, xe, f, g, extra);
     }
-    if (a.scal) {   // pivot ratio of the final sweep: the cheap condition estimate refine64.h flags tasks by
+    if (a.scal) {   // pivot ratio of the final sweep and the largest diagonal entry of A^-1: the cheap condition estimates by
+                    // which refine64.h / ProbCres pick the tasks that need more than the explicit float32 inverse
         const float pr = pivot_ratio<NT>(sm.pivs, n, sm.red);
-        if (tid == 0) a.scal[(size_t)t * NSCAL + S_PIVR_A] = pr;
+        float dmax = 0.f;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+                if (SW::row(r) == j0 + c && SW::row(r) < n) dmax = fmaxf(dmax, -m[r][c]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64));
+        __syncthreads();
+        if ((tid & 63) == 0) sm.red[tid >> 6] = dmax;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < NT / 64; ++w) dmax = fmaxf(dmax, sm.red[w]);
+            float* sc = a.scal + (size_t)t * NSCAL;
+            sc[S_PIVR_A] = pr;
+            sc[S_CONDA] = (sc[S_OS] + sc[S_NOISE]) * dmax;
+        }
     }
     if (a.vecs && tid < n) a.vecs[((size_t)t * NVEC + V_ALPHA) * a.vld + tid] = sm.vec_out[tid];
     if (a.Ainv) {

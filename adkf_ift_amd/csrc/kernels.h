@@ -267,6 +267,38 @@ __global__ __launch_bounds__(SMALL_NT) void k_hess(HessArgs a) {
     if (tid == 0) hess_assemble(sc, a.priors + t * 4, n, acc);
 }
 
+// ---- alpha += A^-1 (y - A alpha): the same refinement step as ProbCres / ProbCfix for the one right-hand side y ------------
+struct AlphaRefineArgs { TaskView tv; const float* Ainv; const float* D2ss; const float* y_s; float* vecs; float thresh; int T; };
+
+__global__ __launch_bounds__(SMALL_NT) void k_alpha_refine(AlphaRefineArgs a) {
+    constexpr int NT = SMALL_NT, NW = NT / 64;
+    __shared__ float res[256];
+    int t, tile;
+    if (!task_tile(a.T, 1, t, tile)) return;
+    const int n = a.tv.ns(t), ld = a.tv.ns_ld, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* sc = a.tv.scal + (size_t)t * NSCAL;
+    if (ld > 256 || (ld <= 128 && !(sc[S_CONDA] > a.thresh))) return;     // (uniform; beyond 256 points the blocked path keeps its alpha)
+    const float os = sc[S_OS], noise = sc[S_NOISE], il2 = 1.f / (sc[S_LS] * sc[S_LS]);
+    const float* Ai = a.Ainv + (size_t)t * ld * ld;
+    const float* D2 = a.D2ss + (size_t)t * ld * ld;
+    const float* y = a.y_s + (size_t)t * ld;
+    float* al = a.vecs + ((size_t)t * NVEC + V_ALPHA) * a.tv.vld;
+    const int kind = a.tv.kind;
+    for (int i = wv; i < n; i += NW) {     // residual, wave per row
+        float s = 0.f;
+        for (int j = lane; j < n; j += 64) s += (os * kappa0(kind, D2[(size_t)i * ld + j] * il2) + (i == j ? noise : 0.f)) * al[j];
+        s = wave_sum(s);
+        if (lane == 0) res[i] = y[i] - s;
+    }
+    __syncthreads();
+    for (int i = wv; i < n; i += NW) {
+        float s = 0.f;
+        for (int j = lane; j < n; j += 64) s += Ai[(size_t)i * ld + j] * res[j];
+        s = wave_sum(s);
+        if (lane == 0) al[i] += s;
+    }
+}
+
 // ---- Stage D core: mu = C y, r = y_q - mu, factor S, e = S^-1 r, f_out, Cte = C^T e --------------------
 struct OuterArgs { TaskView tv; const float* C; float* S; const float* y_s; const float* y_q; float* vecs; float* scal; float* f_out; int32_t* info; int T;
                    int reset_info; };  // reset_info: info[] holds nothing yet (the inner stage was reused): write, do not merge

@@ -128,6 +128,20 @@ def pipeline(Zs, ys, Zq, yq, phi, pri, kind, cfg):
     B = dt(s) * kqs0
     if "c_solve" in cfg:
         Cm = np.linalg.solve(A.astype(f64), B.astype(f64).T).T
+    elif "c_refine32" in cfg:
+        # one step of iterative refinement in WORKING precision with the explicit inverse as the solver (Skeel: backward stable)
+        A32, Ai32_, B32 = A.astype(f32), Ainv32, B.astype(f32)
+        C0 = B32 @ Ai32_
+        for _ in range(int("c_refine32x2" in cfg) + 1):
+            R = B32 - C0 @ A32
+            C0 = C0 + R @ Ai32_
+        Cm = C0
+        a0 = Ai32_ @ ys.astype(f32)
+        for _ in range(int("c_refine32x2" in cfg) + 1):
+            ra = ys.astype(f32) - A32 @ a0
+            a0 = a0 + Ai32_ @ ra
+        alpha = a0
+        alpha32 = a0
     else:
         Cm = B @ (Ainv.astype(dt) if ("ainv" in cfg and dt == f64) else Ainv32.astype(dt))
     al_c = alpha.astype(dt) if dt == f64 and ("ainv" in cfg or "alpha_solve" in cfg) else alpha32.astype(dt)
@@ -187,6 +201,8 @@ def pipeline(Zs, ys, Zq, yq, phi, pri, kind, cfg):
 CONFIGS = {
     "fp32": set(),                                              # explicit float32 inverses everywhere (round-1 before ldl.h)
     "ldl": {"alpha_solve", "c_solve"},                          # round 1: C and alpha by a stable solve, the rest float32
+    "refC32+sweep": {"c_refine32", "sweep"},                     # C and alpha by ONE float32 refinement step on top of the explicit inverse
+    "refC32x2+sweep": {"c_refine32", "c_refine32x2", "sweep"},
     "ldl+sweep": {"alpha_solve", "c_solve", "sweep"},           # the device as it is: C / alpha solved stably, S and A inverted by the sweep
     "ldl+sweep+refS": {"alpha_solve", "c_solve", "sweep", "refine_s"},
     "ldl+sweep+refSA": {"alpha_solve", "c_solve", "sweep", "refine_s", "refine_a"},
