@@ -115,9 +115,9 @@ def test_adkt_model_modes_and_fused_hypergradient(dev, kernel, numeric):
     assert abs(val.item() - ref_val.item()) <= 1e-4 * abs(ref_val.item())
     hscale = max(b.grad.abs().max().item() for b in po64)
     for a, b in zip(po, po64):
-        assert (a.grad.double().cpu() - b.grad).abs().max() <= 1e-3 * max(b.grad.abs().max().item(), hscale), (a.shape,)
+        assert (a.grad.double().cpu() - b.grad).abs().max() <= 2e-4 * max(b.grad.abs().max().item(), hscale), (a.shape,)
     for a, b in zip(pi, pi64):
-        assert (a.grad.double().cpu() - b.grad).abs().max() <= 1e-3 * max(b.grad.abs().max().item(), 1e-2)
+        assert (a.grad.double().cpu() - b.grad).abs().max() <= 2e-4 * max(b.grad.abs().max().item(), 1e-2)
     # first-order flag
     cauchy_hypergradient(f_outer, f_inner, po, pi, dev, ignore_grad_correction=True)
     for a, b in zip(po, g_ref[: len(po)]):
@@ -133,7 +133,7 @@ def test_adkt_model_modes_and_fused_hypergradient(dev, kernel, numeric):
     assert (post.covariance_matrix.double().cpu() - cov).abs().max() <= 1e-4 * cov.abs().max()
     yq = batch.query_numeric_labels if numeric else (batch.query_labels.float() - 0.5) * 2
     lp = post.log_prob(yq)
-    assert abs(lp.item() + O.f_outer(Zs.double().cpu(), ys.double().cpu(), Zq.double().cpu(), yq.double().cpu(), phi, kind).item()) <= 1e-3 * abs(lp.item())
+    assert abs(lp.item() + O.f_outer(Zs.double().cpu(), ys.double().cpu(), Zq.double().cpu(), yq.double().cpu(), phi, kind).item()) <= 2e-4 * abs(lp.item())
 
 
 def test_dkl_model_surface(dev):
@@ -287,7 +287,7 @@ def test_moleculenet_adkf_model_fused_hypergradient(dev):
     assert abs(val.item() - ref_val.item()) <= 1e-4 * abs(ref_val.item())
     scale = max(q.grad.abs().max().item() for q in p64)
     for p, q in zip(po, p64):
-        assert (p.grad.double().cpu() - q.grad).abs().max().item() <= 1e-3 * scale
+        assert (p.grad.double().cpu() - q.grad).abs().max().item() <= 2e-4 * scale
     model.eval()
     probs, labels = model.forward_query_loader(s_data, [q_data], s_label=s_data.y)
     assert probs.shape == (32,) and labels.shape == (32,) and ((probs > 0) & (probs < 1)).all()
