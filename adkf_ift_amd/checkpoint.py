@@ -41,12 +41,38 @@ class _Bag:
             self.__dict__.update(state)
 
 
+# Globals a checkpoint written by ``ADKTModelTrainer.save_model`` legitimately refers to.  Everything under ``fs_mol.``
+# (the reference's config dataclasses and enums, not importable here) becomes an attribute bag; any OTHER global is refused:
+# a pickle is a program, and this loader exists to read files that come from elsewhere.
+_ALLOWED_GLOBALS = {
+    ("collections", "OrderedDict"), ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "dict"), ("builtins", "list"),
+    ("builtins", "tuple"), ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"), ("builtins", "str"),
+    ("builtins", "complex"), ("builtins", "slice"), ("builtins", "range"), ("builtins", "bytearray"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._utils", "_rebuild_qtensor"),
+    ("torch._utils", "_rebuild_device_tensor_from_numpy"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch.serialization", "_get_layout"), ("torch", "Size"), ("torch", "device"), ("torch", "dtype"),
+    ("torch.nn.parameter", "Parameter"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+}
+
+
 class _TolerantUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        try:
+        if (module, name) in _ALLOWED_GLOBALS:
             return super().find_class(module, name)
-        except (ImportError, AttributeError):
-            return type(name, (_Bag,), {"__module__": module})
+        if module == "torch" and (name.endswith("Storage") or name in ("float32", "float64", "float16", "bfloat16", "int64",
+                                                                       "int32", "int16", "int8", "uint8", "bool")):
+            return super().find_class(module, name)      # torch.FloatStorage & co., dtype singletons
+        if module == "torch.storage" and name in ("TypedStorage", "UntypedStorage", "_load_from_bytes"):
+            if name == "_load_from_bytes":
+                raise pickle.UnpicklingError("refusing torch.storage._load_from_bytes (nested pickle) in a checkpoint")
+            return super().find_class(module, name)
+        if module.split(".")[0] in ("fs_mol", "MoleculeNet", "chem_lib", "dpu_utils") or module in ("pathlib", "enum"):
+            return type(name, (_Bag,), {"__module__": module})     # the reference's own classes: kept as attribute bags
+        raise pickle.UnpicklingError(f"checkpoint refers to the global {module}.{name}, which a reference checkpoint has no "
+                                     f"reason to contain; refusing to import it")
 
 
 _tolerant_pickle = types.SimpleNamespace(Unpickler=_TolerantUnpickler, load=lambda f, **kw: _TolerantUnpickler(f, **kw).load(),

@@ -130,6 +130,10 @@ __global__ __launch_bounds__(NT) void k_median(const float* D2ss, const int32_t*
     const int n = n_s ? n_s[t] : ld;
     const uint32_t* D = reinterpret_cast<const uint32_t*>(D2ss + (size_t)t * ld * ld);
     const int tid = threadIdx.x;
+    if (n <= 0 || n > ld) {   // an empty (or corrupt) task: no candidates, and no division by n below
+        if (tid == 0) { l0[t] = 0.f; if (init.phi) init_params_task(init, t, 0.f); }
+        return;
+    }
     uint32_t v[EPT];
     int cnt = 0;
 #pragma unroll

@@ -21,8 +21,6 @@ REUSE_DIST = 1
 REUSE_INNER = 2
 ARD = 4
 
-_workspaces = {}
-
 
 def kernel_id(kernel) -> int:
     if isinstance(kernel, int):
@@ -77,10 +75,35 @@ class GPBatch:
         self.y_q = _f32(self.y_q, "y_q")
         if self.Z_s.dim() != 3:
             raise ValueError("Z_s must be [T, N, d]")
-        for name in ("n_s", "n_q"):
+        T, N, d = self.Z_s.shape
+        # The library trusts the sizes of adkf_batch_t: every tensor is checked against them HERE (a [T, 3] phi on an ARD
+        # batch, or labels of another meta-batch, would otherwise be read and written out of bounds on the device).
+        if tuple(self.y_s.shape) != (T, N):
+            raise ValueError(f"y_s must be [T, N] = [{T}, {N}], got {tuple(self.y_s.shape)}")
+        if tuple(self.priors.shape) != (T, 4):
+            raise ValueError(f"priors must be [T, 4] = [{T}, 4], got {tuple(self.priors.shape)}")
+        if (self.Z_q is None) != (self.y_q is None) and self.Z_q is None:
+            raise ValueError("y_q given without Z_q")
+        if self.Z_q is not None:
+            if self.Z_q.dim() != 3 or self.Z_q.shape[0] != T or self.Z_q.shape[2] != d:
+                raise ValueError(f"Z_q must be [T, N_q, d] = [{T}, N_q, {d}], got {tuple(self.Z_q.shape)}")
+            if self.y_q is not None and tuple(self.y_q.shape) != tuple(self.Z_q.shape[:2]):
+                raise ValueError(f"y_q must be [T, N_q] = {tuple(self.Z_q.shape[:2])}, got {tuple(self.y_q.shape)}")
+        for name, limit in (("n_s", N), ("n_q", self.nq)):
             v = getattr(self, name)
             if v is not None:
-                setattr(self, name, v.to(device=self.Z_s.device, dtype=torch.int32).contiguous())
+                if v.numel() != T:
+                    raise ValueError(f"{name} must have T = {T} entries, got {v.numel()}")
+                if not v.is_cuda:     # host-side sizes can be range-checked without a device synchronisation
+                    lo, hi = int(v.min()), int(v.max())
+                    if lo < (1 if name == "n_s" else 0) or hi > limit:
+                        raise ValueError(f"{name} out of range: [{lo}, {hi}] for a padded size of {limit}")
+                setattr(self, name, v.to(device=self.Z_s.device, dtype=torch.int32).contiguous().view(T))
+        for name in ("y_s", "priors", "Z_q", "y_q"):
+            v = getattr(self, name)
+            if v is not None and v.device != self.Z_s.device:
+                raise ValueError(f"{name} lives on {v.device}, Z_s on {self.Z_s.device}: one batch, one device")
+        self._ws = None
 
     @property
     def T(self):
@@ -115,14 +138,24 @@ class GPBatch:
         return b
 
     def workspace(self) -> Tuple[torch.Tensor, int]:
+        """The caller-owned workspace of THIS batch.  It belongs to the batch object (not to a per-stream cache) because
+        the REUSE_DIST / REUSE_INNER promises refer to what earlier calls on this batch left in it; torch's caching allocator
+        makes the per-batch allocation cheap."""
         lib = _lib.load()
         need = (lib.adkf_workspace_bytes_ard if self.ard else lib.adkf_workspace_bytes)(self.T, self.ns, self.nq, self.d)
-        key = (self.device.index, torch.cuda.current_stream(self.device).cuda_stream)
-        ws = _workspaces.get(key)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-            _workspaces[key] = ws
-        return ws, need
+        if self._ws is None or self._ws.numel() < need:
+            if self._ws is not None and (self.flags & (REUSE_DIST | REUSE_INNER)):
+                raise RuntimeError("the workspace of this batch would have to grow while REUSE flags are set: the data they refer to would be lost")
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws, need
+
+    def check_phi(self, phi: torch.Tensor, name: str = "phi") -> torch.Tensor:
+        phi = _f32(phi, name)
+        if tuple(phi.shape) != (self.T, self.h):
+            raise ValueError(f"{name} must be [T, h] = [{self.T}, {self.h}] for this batch, got {tuple(phi.shape)}")
+        if phi.device != self.device:
+            raise ValueError(f"{name} lives on {phi.device}, the batch on {self.device}")
+        return phi
 
 
 def _stream(dev) -> C.c_void_p:
@@ -187,7 +220,7 @@ def init_params_batch(b: GPBatch, use_numeric_labels: bool = False, use_lengthsc
 
 def mll_value_grad(b: GPBatch, phi: torch.Tensor, want_grad_phi=True, want_dZ=False):
     lib = _lib.load()
-    phi = _f32(phi, "phi")
+    phi = b.check_phi(phi)
     f = _new(b, b.T)
     g = _new(b, b.T, b.h) if want_grad_phi else None
     dZ = _new(b, b.T, b.ns, b.d) if want_dZ else None
@@ -204,7 +237,7 @@ def fit(b: GPBatch, phi0: torch.Tensor, max_evals: int = 200, gtol: float = 1e-5
     """Batched inner optimisation; returns (phi*, f_final, gnorm, n_evals, info).  ``events`` = a pair of
     already-created timing events recorded right around the optimiser kernel (bench.py's roofline clock)."""
     lib = _lib.load()
-    phi = _f32(phi0, "phi0").clone()
+    phi = b.check_phi(phi0, "phi0").clone()
     f, gn = _new(b, b.T), _new(b, b.T)
     ne, info = _new(b, b.T, dtype=torch.int32), _new(b, b.T, dtype=torch.int32)
     opt = FitOptions(int(max_evals), int(exact_evals), float(gtol), float(ftol),
@@ -218,7 +251,7 @@ def fit(b: GPBatch, phi0: torch.Tensor, max_evals: int = 200, gtol: float = 1e-5
 
 def predict(b: GPBatch, phi: torch.Tensor, want_var=True, want_cov=False):
     lib = _lib.load()
-    phi = _f32(phi, "phi")
+    phi = b.check_phi(phi)
     mean = _new(b, b.T, b.nq)
     var = _new(b, b.T, b.nq) if want_var else None
     cov = _new(b, b.T, b.nq, b.nq) if want_cov else None
@@ -232,7 +265,7 @@ def predict(b: GPBatch, phi: torch.Tensor, want_var=True, want_cov=False):
 
 def outer_nll_value_grad(b: GPBatch, phi: torch.Tensor, want_grads=True):
     lib = _lib.load()
-    phi = _f32(phi, "phi")
+    phi = b.check_phi(phi)
     f = _new(b, b.T)
     g = _new(b, b.T, b.h) if want_grads else None
     dZs = _new(b, b.T, b.ns, b.d) if want_grads else None
@@ -251,7 +284,7 @@ def ift_hypergrad(b: GPBatch, phi: torch.Tensor, ignore_grad_correction=False, i
     ``out_dZ = (dZ_s, dZ_q)``: optional preallocated contiguous float32 outputs (e.g. two halves of one buffer).
     ARD batches: H is None (never formed), ``cg_iters`` reports the conjugate-gradient iterations per task."""
     lib = _lib.load()
-    phi = _f32(phi, "phi")
+    phi = b.check_phi(phi)
     flags = (_lib.IGNORE_GRAD_CORRECTION if ignore_grad_correction else 0) | (_lib.IGNORE_DIRECT_GRAD if ignore_direct_grad else 0)
     if out_dZ is not None:
         dZ_s, dZ_q = out_dZ

@@ -141,9 +141,28 @@ def shard_tasks_by_nodes(tasks: Sequence[DKTBatch], world: int, rank: int) -> Li
     return [i for i in range(len(tasks)) if owner[i] == rank]
 
 
+def _batch_coupled(model) -> Optional[str]:
+    """Why ONE forward over all molecules of all tasks would NOT equal the reference's per-task support / query forwards."""
+    gfe = getattr(model, "graph_feature_extractor", None)
+    if gfe is None or not model.training:
+        return None
+    if gfe.config.output_norm == "batch":
+        return "output_norm='batch' (train-mode BatchNorm statistics would be pooled over tasks and over support + query sets)"
+    if gfe.config.gnn_config.dropout_rate > 0.0:
+        return "dropout_rate > 0 (one mask draw per molecule set in the reference, fs_mol/modules/gnn.py:497-513)"
+    return None
+
+
 def meta_features(model, mb: MetaBatch):
     """ONE forward of the deep-kernel feature extractor for the whole meta-batch ->
-    ``Z_s [T, Ns_max, d]``, ``Z_q [T, Nq_max, d]`` (padded rows are zero and receive zero gradient)."""
+    ``Z_s [T, Ns_max, d]``, ``Z_q [T, Nq_max, d]`` (padded rows are zero and receive zero gradient).
+    Exact only when molecules do not interact inside the extractor: a model whose extractor couples the molecules of a
+    forward pass in train mode (BatchNorm output norm, dropout) is refused - the reference runs separate support and query
+    forwards per task (fs_mol/models/adaptive_dkt.py:141-160) and pooling would silently change the features."""
+    why = _batch_coupled(model)
+    if why is not None:
+        raise NotImplementedError("meta_features: the batched extractor forward is not equivalent to the reference's per-task "
+                                  "forwards with " + why + "; use the per-task path (ADKTModel.forward + cauchy_hypergradient)")
     F = model._features(mb.molecules)  # [G_total, d]
     Z_s = F[mb.s_index] * mb.s_mask.unsqueeze(-1).to(F.dtype)
     Z_q = F[mb.q_index] * mb.q_mask.unsqueeze(-1).to(F.dtype)

@@ -9,8 +9,8 @@ Mirrors (names, arguments, modes, return conventions):
 The GP is no longer a GPyTorch module, so the three raw parameters keep their GPyTorch names
 (``gp_likelihood.noise_covar.raw_noise``, ``gp_model.covar_module.raw_outputscale``,
 ``gp_model.covar_module.base_kernel.raw_lengthscale``; shapes [1], [], [1,1]) and ``gp_params()`` returns them in
-that order, which is what checkpoints and the trainers of the reference rely on.  ARD (``use_ard``) is not yet
-supported by the HIP path and raises.
+that order, which is what checkpoints and the trainers of the reference rely on.  ARD (``use_ard``: ``raw_lengthscale``
+of shape [1, d]) runs on the HVP + conjugate-gradient path of the library (csrc/ard.h).
 """
 from __future__ import annotations
 

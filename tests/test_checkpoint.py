@@ -88,3 +88,21 @@ def test_reference_checkpoint_round_trip(tmp_path):
     model2, ck2 = CK.load_reference_checkpoint(path2)
     assert ck2["epoch"] == 8 and "optimizer_state_dict" in ck2
     assert torch.equal(model2.graph_feature_extractor(batch), got)
+
+
+def test_loader_refuses_globals_a_checkpoint_has_no_reason_to_contain(tmp_path):
+    """A pickle is a program: the tolerant loader maps the reference's own classes to attribute bags and allows the torch
+    / numpy / collections reconstruction helpers, nothing else (an ``os.system`` reduce must not run)."""
+    import os
+    import pickle
+
+    import pytest
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > /dev/null",))
+
+    path = str(tmp_path / "evil.pt")
+    torch.save({"model_config": Evil(), "model_state_dict": {}}, path)
+    with pytest.raises(pickle.UnpicklingError):
+        CK.load_reference_checkpoint(path)

@@ -73,3 +73,28 @@ def test_shards_balance_by_node_count():
         naive = [sum(cost[r * per:(r + 1) * per]) for r in range(world)]
         assert max(loads) <= max(naive)
     assert len({len(s) for s in [shard_tasks_by_nodes(tasks, 2, r) for r in range(2)]}) > 1   # task counts DO differ
+
+
+def test_batched_forward_refuses_models_that_couple_molecules():
+    """BatchNorm (train mode) or dropout make one forward over all tasks differ from the reference's per-task forwards:
+    meta_features must refuse instead of silently pooling statistics."""
+    import pytest
+    from adkf_ift_amd.models import _DeepKernelBase
+
+    tasks = [random_task(4, 4, 1), random_task(4, 4, 2)]
+    mb = collate_meta_batch(tasks)
+    for mutate in ("batch", "dropout"):
+        cfg = small_model()
+        m = type("FeatOnly", (_DeepKernelBase,), {})()
+        torch.nn.Module.__init__(m)
+        m.config = cfg
+        m._build_features(cfg)
+        if mutate == "batch":
+            m.graph_feature_extractor.config.output_norm = "batch"
+        else:
+            m.graph_feature_extractor.config.gnn_config.dropout_rate = 0.1
+        m.train()
+        with pytest.raises(NotImplementedError):
+            meta_features(m, mb)
+        m.eval()
+        meta_features(m, mb)      # eval mode: running statistics / no dropout - molecules do not interact
