@@ -383,8 +383,6 @@ template <int NMAX, int NT> struct Sweep : SweepBlk<NMAX, NT> {};
 #ifndef ADKF_SWEEP_W
 #define ADKF_SWEEP_W 1
 #endif
-#if ADKF_SWEEP_W == 2
-#include "factor_w8.h"   // eight pivots per barrier
-#elif ADKF_SWEEP_W
-#include "factor_w.h"    // four pivots per barrier
+#if ADKF_SWEEP_W
+#include "factor_w.h"
 #endif

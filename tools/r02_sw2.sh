@@ -1,2 +1,2 @@
-timeout -k 10 120 tools/sweepw_bench 256 2>&1 | tail -12
-timeout -k 10 120 tools/sweepw_bench_stamp 256 2>&1 | grep -A9 "stamps of"
+timeout -k 10 120 tools/sweepw_bench 256 2>&1 | tail -10
+for v in 24 31; do echo "== ablate $v"; timeout -k 10 120 tools/sweepw_abl_$v 256 2>&1 | grep "wave-owned: "; done
