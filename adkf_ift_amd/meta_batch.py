@@ -60,6 +60,46 @@ class DKTBatch:
                         self.query_features.to(device), self.query_labels.to(device), self.query_numeric_labels.to(device))
 
 
+def _as_tensor(x, dtype=None) -> torch.Tensor:
+    t = x if isinstance(x, torch.Tensor) else torch.as_tensor(x)      # numpy arrays, lists, tensors alike
+    return t if dtype is None else t.to(dtype)
+
+
+def molecule_features_from_fsmol(part) -> MoleculeFeatures:
+    """The reference's ``MoleculeDKTFeatures`` (fs_mol/data/dkt.py:25-29, an ``FSMolBatch`` of NUMPY arrays,
+    fs_mol/data/fsmol_batcher.py:22-54: ``node_features [V, 32] float``, ``adjacency_lists`` = one ``[E_t, 2]`` integer array
+    per edge type, ``node_to_graph [V]``, ``num_graphs``; plus ``fingerprints [G, 2048]``, ``descriptors [G, 42]``) or its
+    ``torchify``-ed twin (fs_mol/utils/torch_utils.py:7-28) -> ``MoleculeFeatures``.  Duck-typed: nothing of the reference is
+    imported; ``edge_features`` / ``num_nodes`` / ``num_edges`` are ignored, as the reference's GNN ignores them
+    (fs_mol/modules/graph_feature_extractor.py:76-98)."""
+    adj = [_as_tensor(a, torch.long).reshape(-1, 2) for a in part.adjacency_lists]
+    nodes = _as_tensor(part.node_features, torch.float32)
+    n2g = _as_tensor(part.node_to_graph, torch.long)
+    G = int(part.num_graphs)
+    if nodes.dim() != 2 or n2g.shape[0] != nodes.shape[0]:
+        raise ValueError(f"node_features {tuple(nodes.shape)} and node_to_graph {tuple(n2g.shape)} do not describe the same nodes")
+    if n2g.numel() and (int(n2g.min()) < 0 or int(n2g.max()) >= G):
+        raise ValueError("node_to_graph refers to a graph outside [0, num_graphs)")
+    for a in adj:
+        if a.numel() and (int(a.min()) < 0 or int(a.max()) >= nodes.shape[0]):
+            raise ValueError("an adjacency list refers to a node outside [0, V)")
+    fp = _as_tensor(part.fingerprints, torch.float32)       # count fingerprints: integers in the reference's files
+    ds = _as_tensor(part.descriptors, torch.float32)
+    if fp.shape[0] != G or ds.shape[0] != G:
+        raise ValueError(f"fingerprints / descriptors have {fp.shape[0]} / {ds.shape[0]} rows for {G} graphs")
+    return MoleculeFeatures(nodes, adj, n2g, G, fp, ds)
+
+
+def dkt_batch_from_fsmol(batch) -> DKTBatch:
+    """The reference's ``DKTBatch`` (fs_mol/data/dkt.py:32-46; numpy or torchified) -> this package's ``DKTBatch``: what
+    ``ADKTModel.forward`` and ``collate_meta_batch`` consume.  Labels keep the reference's conventions (bool activity labels,
+    numeric labels already log-standardised by ``task_sample_to_dkt_task_sample``, fs_mol/data/dkt.py:86-97)."""
+    return DKTBatch(molecule_features_from_fsmol(batch.support_features), _as_tensor(batch.support_labels).bool(),
+                    _as_tensor(batch.support_numeric_labels, torch.float32),
+                    molecule_features_from_fsmol(batch.query_features), _as_tensor(batch.query_labels).bool(),
+                    _as_tensor(batch.query_numeric_labels, torch.float32))
+
+
 def _concat_molecules(parts: Sequence[MoleculeFeatures]) -> MoleculeFeatures:
     g = concat_graph_batches([p.graph() for p in parts])
     return MoleculeFeatures(g.node_features, g.adjacency_lists, g.node_to_graph, g.num_graphs,

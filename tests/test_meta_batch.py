@@ -98,3 +98,61 @@ def test_batched_forward_refuses_models_that_couple_molecules():
             meta_features(m, mb)
         m.eval()
         meta_features(m, mb)      # eval mode: running statistics / no dropout - molecules do not interact
+
+
+def test_ingests_the_reference_numpy_batch_objects():
+    """f3: ``DKTBatch`` / ``MoleculeDKTFeatures`` as the reference's batcher emits them (frozen dataclasses of numpy arrays,
+    fs_mol/data/dkt.py:25-46, fs_mol/data/fsmol_batcher.py:22-54) go through ``dkt_batch_from_fsmol`` into the meta-batch
+    collation.  The classes below restate only the FIELD LAYOUT of the reference's dataclasses."""
+    from dataclasses import dataclass
+    from typing import List
+
+    import numpy as np
+    import pytest
+    from adkf_ift_amd.meta_batch import dkt_batch_from_fsmol
+
+    @dataclass(frozen=True)
+    class RefMolecules:                      # FSMolBatch + the two MoleculeDKTFeatures fields
+        num_graphs: int
+        num_nodes: int
+        num_edges: int
+        node_features: np.ndarray
+        adjacency_lists: List[np.ndarray]
+        edge_features: List[np.ndarray]
+        node_to_graph: np.ndarray
+        fingerprints: np.ndarray
+        descriptors: np.ndarray
+
+    @dataclass(frozen=True)
+    class RefDKTBatch:
+        support_features: RefMolecules
+        support_labels: np.ndarray
+        support_numeric_labels: np.ndarray
+        query_features: RefMolecules
+        query_labels: np.ndarray
+        query_numeric_labels: np.ndarray
+
+    rng = np.random.default_rng(0)
+
+    def ref_part(n, seed):
+        gb = random_graphs(n, seed=seed)
+        adj = [a.numpy().astype(np.int32) for a in gb.adjacency_lists]          # the reference stores int32 pairs
+        return RefMolecules(n, gb.node_features.shape[0], sum(a.shape[0] for a in adj), gb.node_features.numpy().astype(np.float32), adj,
+                            [np.zeros((a.shape[0], 0), np.float32) for a in adj], gb.node_to_graph.numpy().astype(np.int64),
+                            rng.poisson(0.05, (n, 2048)).astype(np.int32), rng.normal(size=(n, 42)).astype(np.float32))
+
+    ref = RefDKTBatch(ref_part(6, 1), rng.random(6) > 0.5, rng.normal(size=6), ref_part(9, 2), rng.random(9) > 0.5, rng.normal(size=9))
+    b = dkt_batch_from_fsmol(ref)
+    assert b.num_support_samples == 6 and b.num_query_samples == 9
+    assert b.support_features.node_features.dtype == torch.float32 and b.support_features.adjacency_lists[0].dtype == torch.long
+    assert b.support_features.fingerprints.dtype == torch.float32 and b.support_labels.dtype == torch.bool
+    assert torch.equal(b.query_features.node_to_graph, torch.as_tensor(ref.query_features.node_to_graph))
+    # the torch-side batch built directly from the same graphs gives the same meta-batch
+    mb = collate_meta_batch([b, b])
+    assert mb.molecules.num_graphs == 30 and mb.n_s.tolist() == [6, 6] and mb.n_q.tolist() == [9, 9]
+    assert torch.equal(mb.molecules.fingerprints[:6], torch.as_tensor(ref.support_features.fingerprints).float())
+    # malformed input is refused, not silently indexed out of range on the device
+    bad = RefMolecules(**{**ref.support_features.__dict__, "node_to_graph": ref.support_features.node_to_graph + 10})
+    with pytest.raises(ValueError):
+        dkt_batch_from_fsmol(RefDKTBatch(bad, ref.support_labels, ref.support_numeric_labels, ref.query_features, ref.query_labels,
+                                         ref.query_numeric_labels))
