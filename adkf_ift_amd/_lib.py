@@ -56,9 +56,6 @@ SIGNATURES = {
                                      C.c_void_p]),
     "adkf_check_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "adkf_workspace_bytes_ard": (C.c_size_t, [C.c_int32] * 4),
-    "adkf_dense_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    "adkf_dense_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "adkf_msg_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int64, C.c_void_p, C.c_void_p]),
     "adkf_msg_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,

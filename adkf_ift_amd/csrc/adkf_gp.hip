@@ -9,7 +9,6 @@
 #include "pna.h"
 #include "outer_step.h"
 #include "refine64.h"
-#include "dense.h"
 
 using namespace adkf;
 
@@ -926,50 +925,6 @@ int adkf_msg_backward(const float* x, const int64_t* src, const int64_t* tgt, co
     ProbMsgBwdW pw; pw.m = m; pw.nsplit = ceil_div(E, m.chunk);
     launch_gemm(pw, H * pw.nsplit, 2 * in, out, st);
     k_msg_dbias<<<dim3(ceil_div(H * out, 64), ceil_div(E, DB_ROWS)), 256, 0, st>>>(m, db);
-    LAUNCH_OK();
-    return 0;
-}
-
-int adkf_dense_forward(const float* X, const float* W, const float* bias, int32_t M, int32_t N, int32_t K, int32_t act, float* Y,
-                       void* stream) {
-    (void)hipGetLastError();
-    if (!X || !W || !Y || M < 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return ADKF_E_BADARG;
-    if (M == 0) return 0;
-    ProbDenseFwd p{X, W, bias, Y, M, N, K, act, (K % 4 == 0) && aligned16(X) && aligned16(W)};
-    const int panels = ceil_div(M, GT), tn = ceil_div(N, GT);
-    k_bgemm<ProbDenseFwd><<<((panels + 7) / 8) * 8 * tn, 256, 0, static_cast<hipStream_t>(stream)>>>(p, panels, 1, tn);
-    LAUNCH_OK();
-    return 0;
-}
-
-int adkf_dense_backward(const float* X, const float* W, const float* Yact, const float* dY, int32_t M, int32_t N, int32_t K, int32_t act,
-                        float* dX, int32_t accumulate_dX, float* dW, float* db, void* stream) {
-    (void)hipGetLastError();
-    if (!X || !W || !dY || M < 0 || N <= 0 || K <= 0 || act < 0 || act > 2 || (act && !Yact)) return ADKF_E_BADARG;
-    if (M == 0) return 0;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool al = aligned16(X) && aligned16(W) && aligned16(dY) && (!Yact || aligned16(Yact));
-    if (dX) {
-        ProbDenseBwdX p{dY, Yact, W, dX, M, N, K, act, accumulate_dX, al && (N % 4 == 0) && (K % 4 == 0)};
-        const int panels = ceil_div(M, GT), tn = ceil_div(K, GT);
-        k_bgemm<ProbDenseBwdX><<<((panels + 7) / 8) * 8 * tn, 256, 0, st>>>(p, panels, 1, tn);
-    }
-    if (dW) {
-        // rows per chunk: enough chunks to fill the chip (>= ~1024 tiles), at least 256 rows each
-        const int panels = ceil_div(N, GT), tn = ceil_div(K, GT);
-        int nsplit = ceil_div(1024, panels * tn);
-        const int max_split = ceil_div(M, 256);
-        nsplit = nsplit < 1 ? 1 : (nsplit > max_split ? max_split : nsplit);
-        const int chunk = ceil_div(ceil_div(M, nsplit), 4) * 4;
-        nsplit = ceil_div(M, chunk);
-        ProbDenseBwdW p{dY, Yact, X, dW, M, N, K, act, chunk, panels, al && (N % 4 == 0) && (K % 4 == 0)};
-        const int T = nsplit * panels;
-        k_bgemm<ProbDenseBwdW><<<((T + 7) / 8) * 8 * tn, 256, 0, st>>>(p, T, 1, tn);
-    }
-    if (db) {
-        DenseDbArgs a{dY, Yact, db, M, N, act};
-        k_dense_dbias<<<dim3(ceil_div(N, 64), ceil_div(M, 256)), 256, 0, st>>>(a);
-    }
     LAUNCH_OK();
     return 0;
 }

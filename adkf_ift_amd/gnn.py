@@ -30,8 +30,6 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import dense
-
 SMALL_NUMBER = 1e-7
 NUM_NODE_FEATURES = 32   # fs_mol/data/fsmol_dataset.py:21
 NUM_EDGE_TYPES = 3       # fs_mol/data/fsmol_dataset.py:22
@@ -304,9 +302,7 @@ class BOOMLayer(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):
-        # both products on the library's fp32 MFMA GEMM, the leaky-ReLU fused into the first epilogue (dense.py)
-        h = dense.linear(x, self.linear1.weight, self.linear1.bias, dense.ACT_LEAKY)
-        return dense.linear(self.dropout(h), self.linear2.weight, self.linear2.bias)
+        return self.linear2(self.dropout(F.leaky_relu(self.linear1(x))))
 
 
 class GNNBlock(nn.Module):
@@ -333,7 +329,7 @@ class GNNBlock(nn.Module):
             # per-node combination, instead of writing and re-reading the [V, H 12m] (3072-wide) concatenation
             H, q, hid = self.mp.H, 4 * self.mp.msg, self.config.hidden_dim
             w = self.msg_out_projection.weight.view(hid, H, 3, q).permute(2, 0, 1, 3).reshape(3 * hid, H * q)
-            p = dense.linear(self.mp(x, plan, scale=False), w)
+            p = F.linear(self.mp(x, plan, scale=False), w)
             new = p[:, :hid] + plan.amplify.to(x.dtype) * p[:, hid:2 * hid] + plan.attenuate.to(x.dtype) * p[:, 2 * hid:] \
                 + self.msg_out_projection.bias
             new = self.dropout_layer(new)
@@ -395,22 +391,20 @@ class CombinedGraphReadout(nn.Module):
 
     def forward(self, node_embeddings: torch.Tensor, node_to_graph_id: torch.Tensor, num_graphs: int) -> torch.Tensor:
         V, hid = node_embeddings.shape[0], self.nh * self.hd
-        h = dense.linear(node_embeddings, self.first.weight, self.first.bias, dense.ACT_RELU)
+        h = F.relu(self.first(node_embeddings))
         h_ms, h_mv, h_ss, h_sv = h.split(hid, dim=1)
-        lin = lambda mod, t: dense.linear(t.contiguous(), mod.weight, mod.bias)
-        w_mean = _segment_softmax(lin(self.mean_score_out, h_ms), node_to_graph_id, num_graphs)      # [V, heads]
-        w_sum = torch.sigmoid(lin(self.sum_score_out, h_ss))
-        v_mean = lin(self.mean_value_out, h_mv).view(V, self.nh, self.hd)
-        v_sum = lin(self.sum_value_out, h_sv).view(V, self.nh, self.hd)
+        w_mean = _segment_softmax(self.mean_score_out(h_ms), node_to_graph_id, num_graphs)      # [V, heads]
+        w_sum = torch.sigmoid(self.sum_score_out(h_ss))
+        v_mean = self.mean_value_out(h_mv).view(V, self.nh, self.hd)
+        v_sum = self.sum_value_out(h_sv).view(V, self.nh, self.hd)
         zeros = node_embeddings.new_zeros(num_graphs, hid)
         g_mean = zeros.index_add(0, node_to_graph_id, (w_mean.unsqueeze(-1) * v_mean).reshape(V, hid))
         g_sum = zeros.index_add(0, node_to_graph_id, (w_sum.unsqueeze(-1) * v_sum).reshape(V, hid))
         idx = node_to_graph_id.view(-1, 1).expand_as(node_embeddings)
         g_max = node_embeddings.new_zeros(num_graphs, node_embeddings.shape[1]).scatter_reduce_(
             0, idx, node_embeddings, reduce="amax", include_self=False)
-        raw = torch.cat((dense.linear(g_mean, self.mean_combination.weight), dense.linear(g_sum, self.sum_combination.weight),
-                         dense.linear(g_max, self.max_combination.weight)), dim=1)
-        return dense.linear(F.relu(raw), self.combination_layer.weight)
+        raw = torch.cat((self.mean_combination(g_mean), self.sum_combination(g_sum), self.max_combination(g_max)), dim=1)
+        return self.combination_layer(F.relu(raw))
 
 
 class GraphFeatureExtractor(nn.Module):
@@ -435,7 +429,7 @@ class GraphFeatureExtractor(nn.Module):
 
     def forward(self, batch) -> torch.Tensor:
         """``batch`` = anything with node_features, adjacency_lists, node_to_graph, num_graphs (FSMolBatch layout)."""
-        states = self.gnn(dense.linear(batch.node_features, self.init_node_proj.weight), list(batch.adjacency_lists))
+        states = self.gnn(self.init_node_proj(batch.node_features), list(batch.adjacency_lists))
         node_repr = torch.cat(states, dim=-1) if self.config.readout_config.use_all_states else states[-1]
         out = self.readout(node_repr, batch.node_to_graph, batch.num_graphs)
         if self.final_norm_layer is not None:

@@ -284,9 +284,8 @@ class _DeepKernelBase(nn.Module):
         if "pc-descs" in uf:
             feats.append(part.descriptors)
         flat = torch.cat(feats, dim=1)
-        if self.use_fc:   # Linear - ReLU - Linear (adaptive_dkt.py:61-65) on the library's fp32 MFMA GEMM, ReLU fused
-            from . import dense
-            flat = dense.linear(dense.linear(flat, self.fc[0].weight, self.fc[0].bias, dense.ACT_RELU), self.fc[2].weight, self.fc[2].bias)
+        if self.use_fc:
+            flat = self.fc(flat)
         if self.normalizing_features:
             flat = F.normalize(flat, p=2, dim=1)
         return flat

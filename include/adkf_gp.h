@@ -177,18 +177,6 @@ int adkf_msg_backward(const float* x, const int64_t* src, const int64_t* tgt, co
                       const float* d_msgs, int32_t E, int32_t H, int32_t in, int32_t out, int64_t e_off, float* dx,
                       float* dW, float* db, void* stream);
 
-/* a1 / a2 (every nn.Linear of the deep-kernel feature extractor: the BOOM layer and the message-output projection of
- * GNNBlock.forward, fs_mol/modules/gnn.py:497-513; the read-out MLPs, fs_mol/modules/graph_readout.py:119-177; the fc head,
- * fs_mol/models/adaptive_dkt.py:61-65, 141-160 - torch.nn.functional.linear there) on the fp32 MFMA:
- *   adkf_dense_forward   Y [M, N] = act(X [M, K] W[N, K]^T + bias [N] or NULL);  act: 0 none, 1 relu, 2 leaky_relu(0.01)
- *   adkf_dense_backward  with G = dY . act'(Y) (Yact = the activated forward output, NULL when act == 0):
- *                        dX [M, K] = G W (accumulate_dX != 0: +=), dW [N, K] += G^T X, db [N] += colsum(G); any of dX / dW /
- *                        db may be NULL; dW and db are accumulated ATOMICALLY (initialise them).  All row-major, contiguous. */
-int adkf_dense_forward(const float* X, const float* W, const float* bias, int32_t M, int32_t N, int32_t K, int32_t act, float* Y,
-                       void* stream);
-int adkf_dense_backward(const float* X, const float* W, const float* Yact, const float* dY, int32_t M, int32_t N, int32_t K,
-                        int32_t act, float* dX, int32_t accumulate_dX, float* dW, float* db, void* stream);
-
 /* a1 (aggregation inside RelationalMultiAggrMP._aggregate_messages, fs_mol/modules/gnn.py:197-265; torch_scatter's
  * scatter_sum / scatter_mean / scatter_max there): SUM | MEAN | STD | MAX of the incoming messages of every target
  * node in one pass.  msgs [E, H, 3m] post-ReLU messages (per tower: sum-part | mean/std-part | max-part), perm [E] the
