@@ -426,12 +426,12 @@ __device__ __forceinline__ void solve_v_task(const SolveArgs& a, int t) {
     const int n = a.tv.ns(t), lane = threadIdx.x;
     __shared__ float sh[8];
     if (lane == 0) {
-        float oc0 = 0.f, oc1 = 0.f, ma0 = 0.f, ma1 = 0.f, ma2 = 0.f;
+        double oc0 = 0.0, oc1 = 0.0, ma0 = 0.0, ma1 = 0.0, ma2 = 0.0;   // (the three pieces of each component nearly cancel: summed in float64)
         for (int q = 0; q < a.nt_oc; ++q) { oc0 += a.part_oc[((size_t)t * a.nt_oc + q) * 4 + 0]; oc1 += a.part_oc[((size_t)t * a.nt_oc + q) * 4 + 1]; }
         for (int q = 0; q < a.nt_ma; ++q) { const float* p = a.part_ma + ((size_t)t * a.nt_ma + q) * 4; ma0 += p[0]; ma1 += p[1]; ma2 += p[2]; }
-        const float g_noise = sc[S_QQ_TR] + ma0;
-        const float g_s = ma1 + oc0 + sc[S_QQ_K];
-        const float g_l = ma2 + oc1 + sc[S_QQ_L];
+        const float g_noise = (float)((double)sc[S_QQ_TR] + ma0);
+        const float g_s = (float)(ma1 + oc0 + (double)sc[S_QQ_K]);
+        const float g_l = (float)(ma2 + oc1 + (double)sc[S_QQ_L]);
         float g[3] = {g_noise * sc[S_D1N], g_s * sc[S_D1S], g_l * sc[S_D1L]};
         sc[S_GOUT0] = g[0]; sc[S_GOUT1] = g[1]; sc[S_GOUT2] = g[2];
         if (a.g_phi_out) { a.g_phi_out[t * 3 + 0] = g[0]; a.g_phi_out[t * 3 + 1] = g[1]; a.g_phi_out[t * 3 + 2] = g[2]; }
@@ -439,16 +439,18 @@ __device__ __forceinline__ void solve_v_task(const SolveArgs& a, int t) {
         if (a.with_hessian && !(a.flags & 1)) {
             // 3x3 Gaussian elimination with partial pivoting (the reference: torch.linalg.solve,
             // fs_mol/utils/cauchy_hypergradient.py:136)
-            float Mx[3][4];
+            double Mx[3][4];   // 3 x 3 elimination in float64 (free; cond(H) reaches 1e2 .. 1e3)
             for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Mx[i][j] = sc[S_H0 + i * 3 + j]; Mx[i][3] = g[i]; }
             for (int c = 0; c < 3; ++c) {
                 int pv = c;
-                for (int r = c + 1; r < 3; ++r) if (fabsf(Mx[r][c]) > fabsf(Mx[pv][c])) pv = r;
-                if (pv != c) for (int j = 0; j < 4; ++j) { const float tmp = Mx[c][j]; Mx[c][j] = Mx[pv][j]; Mx[pv][j] = tmp; }
-                const float ip = 1.f / Mx[c][c];
-                for (int r = c + 1; r < 3; ++r) { const float f = Mx[r][c] * ip; for (int j = c; j < 4; ++j) Mx[r][j] -= f * Mx[c][j]; }
+                for (int r = c + 1; r < 3; ++r) if (fabs(Mx[r][c]) > fabs(Mx[pv][c])) pv = r;
+                if (pv != c) for (int j = 0; j < 4; ++j) { const double tmp = Mx[c][j]; Mx[c][j] = Mx[pv][j]; Mx[pv][j] = tmp; }
+                const double ip = 1.0 / Mx[c][c];
+                for (int r = c + 1; r < 3; ++r) { const double f = Mx[r][c] * ip; for (int j = c; j < 4; ++j) Mx[r][j] -= f * Mx[c][j]; }
             }
-            for (int c = 2; c >= 0; --c) { float s = Mx[c][3]; for (int j = c + 1; j < 3; ++j) s -= Mx[c][j] * v[j]; v[c] = s / Mx[c][c]; }
+            double vd[3] = {0.0, 0.0, 0.0};
+            for (int c = 2; c >= 0; --c) { double s = Mx[c][3]; for (int j = c + 1; j < 3; ++j) s -= Mx[c][j] * vd[j]; vd[c] = s / Mx[c][c]; }
+            for (int c = 0; c < 3; ++c) v[c] = (float)vd[c];
         }
         sc[S_V0] = v[0]; sc[S_V1] = v[1]; sc[S_V2] = v[2];
         const float cn = v[0] * sc[S_D1N], cs = v[1] * sc[S_D1S] / sc[S_OS], cl = v[2] * sc[S_D1L];
