@@ -150,16 +150,27 @@ int stage_dist(const adkf_batch_t* b, const Workspace& w, bool with_query, hipSt
     if (with_query && !(parts & 16)) k_rownorm<<<dim3(ceil_div(nq, 4), T), 256, 0, st>>>(b->Z_q, b->n_q, nq, d, w.mean, w.nrm_q, T);
     ProbDist p;
     p.mean = w.mean; p.d = d; p.vec = vec_ok(b, w);
+    ProbDistMulti pm;
+    pm.vec = p.vec; pm.end0 = pm.end1 = 0; pm.tn0 = pm.tn1 = pm.tn2 = 1;
+    int nblk = 0, total = 0;
+    auto add = [&](const ProbDist& q, int M, int N) {
+        const int tn = ceil_div(N, GT), tiles = ceil_div(M, GT) * tn;
+        if (nblk == 0) { pm.s0 = q; pm.tn0 = tn; pm.end0 = pm.end1 = total + tiles; pm.s1 = pm.s2 = q; }
+        else if (nblk == 1) { pm.s1 = q; pm.tn1 = tn; pm.end1 = total + tiles; pm.s2 = q; }
+        else { pm.s2 = q; pm.tn2 = tn; }
+        total += tiles; ++nblk;
+    };
     if (parts & 1) {
         p.X = b->Z_s; p.Y = b->Z_s; p.nx = w.nrm_s; p.ny = w.nrm_s; p.n_x = b->n_s; p.n_y = b->n_s; p.x_ld = ns; p.y_ld = ns; p.symmetric = true; p.D2 = w.D2ss;
-        launch_gemm(p, T, ns, ns, st);
+        add(p, ns, ns);
     }
     if (with_query) {
         p.X = b->Z_q; p.Y = b->Z_s; p.nx = w.nrm_q; p.ny = w.nrm_s; p.n_x = b->n_q; p.n_y = b->n_s; p.x_ld = nq; p.y_ld = ns; p.symmetric = false; p.D2 = w.D2qs;
-        launch_gemm(p, T, nq, ns, st);
+        add(p, nq, ns);
         p.X = b->Z_q; p.Y = b->Z_q; p.nx = w.nrm_q; p.ny = w.nrm_q; p.n_x = b->n_q; p.n_y = b->n_q; p.x_ld = nq; p.y_ld = nq; p.symmetric = true; p.D2 = w.D2qq;
-        launch_gemm(p, T, nq, nq, st);
+        add(p, nq, nq);
     }
+    if (nblk > 0) k_bgemm<ProbDistMulti, GT><<<grid_for(T, total), 256, 0, st>>>(pm, T, 1, total);
     LAUNCH_OK();
     return 0;
 }
@@ -706,8 +717,8 @@ static int median_core(const adkf_batch_t* b, const Workspace& w, float* l0, con
     int rc = stage_dist(b, w, has_query(b), st);
     if (rc) return rc;
     *fused = b->ns_max <= 256;
-    if (b->ns_max <= 128) k_median<512, 32><<<grid_for(b->T, 1), 512, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T, init);
-    else if (b->ns_max <= 256) k_median<1024, 64><<<grid_for(b->T, 1), 1024, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T, init);
+    if (b->ns_max <= 128) k_median<512, 16><<<grid_for(b->T, 1), 512, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T, init);
+    else if (b->ns_max <= 256) k_median<1024, 32><<<grid_for(b->T, 1), 1024, 0, st>>>(w.D2ss, b->n_s, b->ns_max, l0, b->T, init);
     else {
         LgMedian lm{w.D2ss, b->n_s, b->ns_max, l0, b->T, reinterpret_cast<uint32_t*>(w.lg_med), w.lg_med + b->T, w.lg_med + 2 * (size_t)b->T};
         hipMemsetAsync(lm.hist, 0, sizeof(int) * 256 * (size_t)b->T, st);

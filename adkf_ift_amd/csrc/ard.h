@@ -56,8 +56,7 @@ __device__ __forceinline__ float bsum256(float v, float* red) {
     return a[0];
 }
 __device__ __forceinline__ float bmax256(float v, float* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = wave_max(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();

@@ -89,16 +89,43 @@ __device__ __forceinline__ float kappa0(int kind, float u) {
 // ---------------------------------------------------------------------------------------------------
 // reductions: wave shuffles first, one LDS hop across waves (deterministic order)
 // ---------------------------------------------------------------------------------------------------
+// Cross-lane moves inside a row of 16 lanes ride the VALU's DPP path (a few cycles) instead of the LDS crossbar
+// (ds_bpermute: ~100+ cycles each, and __shfl_xor always compiles to it): xor-1 and xor-2 inside the quad, then the two
+// mirrors.  After the four steps every lane holds its row's total; the four row totals are read as scalars.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
+// Every lane of the wave must be active (the callers reduce in wave-uniform control flow); all lanes get the total.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f<DPP_XOR1>(v);
+    v += dpp_f<DPP_XOR2>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    v += dpp_f<DPP_MIRROR>(v);
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_i<DPP_XOR1>(v);
+    v += dpp_i<DPP_XOR2>(v);
+    v += dpp_i<DPP_HALF_MIRROR>(v);
+    v += dpp_i<DPP_MIRROR>(v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
+    const int b = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
+}
+__device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }
 
 // Sums K values over the whole block; every thread gets the totals.  `red` needs K * (NT/64) floats.
 // Contains two barriers; safe to call repeatedly with the same scratch.

@@ -315,8 +315,14 @@ template <> struct Sweep<128, 512> {
             sr[r] = acc;
         }
         // the 16 column blocks of a row sit in lanes a, a + 4, .., a + 60
+        // (inside a row of 16 lanes: two DPP rotations by 4 and 8; across the four rows: two shuffles)
 #pragma unroll
-        for (int o = 4; o < 64; o <<= 1)
+        for (int r = 0; r < RB; ++r) {
+            sr[r] += dpp_f<0x124>(sr[r]);   // row_ror:4
+            sr[r] += dpp_f<0x128>(sr[r]);   // row_ror:8
+        }
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1)
 #pragma unroll
             for (int r = 0; r < RB; ++r) sr[r] += __shfl_xor(sr[r], o, 64);
         if (bc() == 0) *reinterpret_cast<float4*>(out + row(0)) = make_float4(sr[0], sr[1], sr[2], sr[3]);

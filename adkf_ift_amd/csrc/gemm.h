@@ -27,6 +27,8 @@
 //                                                  epilogue still runs, with acc = 0)
 //   __device__ bool  active(int m0, int n0)      : OPTIONAL - false: the tile at (m0, n0) is not computed at all (e.g. the
 //                                                  lower tiles of a symmetric result, written by their mirror images)
+//   __device__ void  select(int& tile, int& tiles_n) : OPTIONAL - called before setup(): picks one of several sub-problems
+//                                                  from the flat tile index and rewrites it to that sub-problem's own
 //   __device__ void  epi4(int i0, int j, const float (&acc)[4], float* red) : OPTIONAL - four consecutive rows of one
 //                                                  column at once (what one lane holds after the MFMA), all in range
 #pragma once
@@ -43,12 +45,26 @@ constexpr int LD_MN = GK + 2; // [mn][k] layout, K-contiguous operands
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef ADKF_GEMM_ABLATE   // diagnostics (tools/gemm_bench.hip): 1 no fragment reads, 2 no barriers, 4 no operand loads after the first chunk, 8 no epilogue
+#define ADKF_GEMM_ABLATE 0
+#endif
+#if (ADKF_GEMM_ABLATE & 2)
+#define ADKF_GEMM_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ADKF_GEMM_SYNC() __syncthreads()
+#endif
+
 template <class P, class = void> struct has_skip : std::false_type {};
 template <class P> struct has_skip<P, std::void_t<decltype(&P::skip)>> : std::true_type {};
 template <class P, class = void> struct has_active : std::false_type {};
 template <class P> struct has_active<P, std::void_t<decltype(&P::active)>> : std::true_type {};
+template <class P, class = void> struct has_select : std::false_type {};
+template <class P> struct has_select<P, std::void_t<decltype(&P::select)>> : std::true_type {};
 template <class P, class = void> struct has_epi4 : std::false_type {};
 template <class P> struct has_epi4<P, std::void_t<decltype(&P::epi4)>> : std::true_type {};
+
+template <class P, class = void> struct has_raw : std::false_type {};
+template <class P> struct has_raw<P, std::void_t<decltype(P::A_NRAW)>> : std::true_type {};
 
 template <int TM> struct GemmCfg {
     static constexpr int GPT = TM * GK / 256;   // operand elements staged per thread per chunk
@@ -104,12 +120,56 @@ __device__ __forceinline__ void gemm_stage(float* S, const float (&reg)[GemmCfg<
     }
 }
 
+// Two-phase operand path (problems with A_NRAW / B_NRAW): x_raw() only ISSUES the 16-byte loads of a group into registers,
+// x_fin() turns them into the four operand entries (exp, scaling, centring ...).  The main loop issues the raw loads of
+// chunk c+1 before the MFMAs of chunk c and runs x_fin() after them, while staging, so no wave waits for memory in front
+// of its matrix instructions.  Used only for tiles that lie fully inside the task with K a multiple of the chunk (no
+// per-lane range checks, hence no divergent branches around the loads); every other tile takes the checked path below.
+template <class P, bool IS_A, int TM>
+__device__ __forceinline__ void gemm_group(int ps, int base, int k0, int& g, int& gk) {
+    using C = GemmCfg<TM>;
+    constexpr bool KC = IS_A ? P::A_KCONTIG : P::B_KCONTIG;
+    const int tid = threadIdx.x;
+    if (KC) { g = base + (tid >> 3) + ps * 32; gk = k0 + (tid & 7) * 4; }
+    else { g = base + (tid % C::MNQ) * 4; gk = k0 + (tid / C::MNQ) + ps * C::KSTEP; }
+}
+
+template <class P, bool IS_A, int TM, int NR>
+__device__ __forceinline__ void gemm_fetch_raw(const P& p, float4 (&raw)[GemmCfg<TM>::GPT / 4][NR], int base, int k0) {
+#pragma unroll
+    for (int ps = 0; ps < GemmCfg<TM>::GPT / 4; ++ps) {
+        int g, gk;
+        gemm_group<P, IS_A, TM>(ps, base, k0, g, gk);
+        if constexpr (IS_A) p.a_raw(g, gk, raw[ps]); else p.b_raw(gk, g, raw[ps]);
+    }
+}
+
+template <class P, bool IS_A, int TM, int NR>
+__device__ __forceinline__ void gemm_stage_raw(const P& p, float* S, const float4 (&raw)[GemmCfg<TM>::GPT / 4][NR], int base, int k0) {
+    using C = GemmCfg<TM>;
+    constexpr bool KC = IS_A ? P::A_KCONTIG : P::B_KCONTIG;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int ps = 0; ps < C::GPT / 4; ++ps) {
+        int g, gk;
+        gemm_group<P, IS_A, TM>(ps, base, k0, g, gk);
+        float v[4];
+        if constexpr (IS_A) p.a_fin(g, gk, raw[ps], v); else p.b_fin(gk, g, raw[ps], v);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            if (KC) S[((tid >> 3) + ps * 32) * LD_MN + (tid & 7) * 4 + x] = v[x];
+            else S[((tid / C::MNQ) + ps * C::KSTEP) * C::LD_K + (tid % C::MNQ) * 4 + x] = v[x];
+        }
+    }
+}
+
 template <class P, int TM = GT>
 __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tiles_n) {
     using C = GemmCfg<TM>;
     constexpr int MI = C::MI, LD_K = C::LD_K, GPT = C::GPT, WT = TM / 2;
     int task, tile;
     if (!task_tile(T, tiles_m * tiles_n, task, tile)) return;
+    if constexpr (has_select<P>::value) p.select(tile, tiles_n);   // several sub-problems in one launch (tiles_m = 1, tiles_n = all tiles)
     if (!p.setup(task)) return;
     const int M = p.M(), N = p.N();
     int K = p.K();
@@ -150,20 +210,14 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
     if constexpr (has_skip<P>::value) {
         if (p.skip(m0, n0)) K = 0;
     }
-    float ra[GPT], rb[GPT];
-    gemm_fetch<P, true, TM>(p, ra, m0, 0, M, K);
-    gemm_fetch<P, false, TM>(p, rb, n0, 0, N, K);
-    for (int k0 = 0; k0 < K; k0 += GK) {
-        gemm_stage<P::A_KCONTIG, TM>(As, ra);
-        gemm_stage<P::B_KCONTIG, TM>(Bs, rb);
-        __syncthreads();
-        if (k0 + GK < K) {  // next chunk's loads fly while this chunk is multiplied
-            gemm_fetch<P, true, TM>(p, ra, m0, k0 + GK, M, K);
-            gemm_fetch<P, false, TM>(p, rb, n0, k0 + GK, N, K);
-        }
+    auto multiply_chunk = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < GK / 4; ++s) {
             float af[MI], bf[MI];
+#if (ADKF_GEMM_ABLATE & 1)   // tools/gemm_bench.hip: no fragment reads
+#pragma unroll
+            for (int i = 0; i < MI; ++i) { af[i] = (float)(lane + s + i); bf[i] = (float)(lane - s - i); }
+#else
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int r = wr * WT + i * 16 + fi;
@@ -174,13 +228,52 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
                 const int c = wc * WT + j * 16 + fi;
                 bf[j] = P::B_KCONTIG ? Bs[c * LD_MN + 4 * s + fk] : Bs[(4 * s + fk) * LD_K + c];
             }
+#endif
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < MI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+    };
+    bool fast = false;
+#ifndef ADKF_GEMM_NO_RAW   // diagnostics: -DADKF_GEMM_NO_RAW sends every tile through the checked path (tools/ab_lib.py)
+    if constexpr (has_raw<P>::value) {
+        fast = p.vec && m0 + TM <= M && n0 + TM <= N && K > 0 && (K % GK) == 0 && p.raw_ok();
+        if (fast) {
+            float4 qa[GPT / 4][P::A_NRAW], qb[GPT / 4][P::B_NRAW];
+            gemm_fetch_raw<P, true, TM, P::A_NRAW>(p, qa, m0, 0);
+            gemm_fetch_raw<P, false, TM, P::B_NRAW>(p, qb, n0, 0);
+            for (int k0 = 0; k0 < K; k0 += GK) {
+                gemm_stage_raw<P, true, TM, P::A_NRAW>(p, As, qa, m0, k0);
+                gemm_stage_raw<P, false, TM, P::B_NRAW>(p, Bs, qb, n0, k0);
+                ADKF_GEMM_SYNC();
+                if (k0 + GK < K && !(ADKF_GEMM_ABLATE & 4)) {
+                    gemm_fetch_raw<P, true, TM, P::A_NRAW>(p, qa, m0, k0 + GK);
+                    gemm_fetch_raw<P, false, TM, P::B_NRAW>(p, qb, n0, k0 + GK);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // the loads above are in flight before the first MFMA issues
+                multiply_chunk();
+                ADKF_GEMM_SYNC();
+            }
+        }
+    }
+#endif
+    if (!fast) {
+        float ra[GPT], rb[GPT];
+        gemm_fetch<P, true, TM>(p, ra, m0, 0, M, K);
+        gemm_fetch<P, false, TM>(p, rb, n0, 0, N, K);
+        for (int k0 = 0; k0 < K; k0 += GK) {
+            gemm_stage<P::A_KCONTIG, TM>(As, ra);
+            gemm_stage<P::B_KCONTIG, TM>(Bs, rb);
+            __syncthreads();
+            if (k0 + GK < K) {  // next chunk's loads fly while this chunk is multiplied
+                gemm_fetch<P, true, TM>(p, ra, m0, k0 + GK, M, K);
+                gemm_fetch<P, false, TM>(p, rb, n0, k0 + GK, N, K);
+            }
+            multiply_chunk();
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg ----
@@ -193,6 +286,9 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
         for (int j = 0; j < MI; ++j) {
             const int gi0 = m0 + wr * WT + i * 16 + fk * 4;
             const int gj = n0 + wc * WT + j * 16 + fi;
+#if (ADKF_GEMM_ABLATE & 8)   // no epilogue (the accumulators stay alive through a store that never happens)
+            if (acc[i][j][0] != 123.456f) continue;
+#endif
             if constexpr (has_epi4<P>::value) {
                 if (gi0 + 3 < M && gj < N) {
                     const float v4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};

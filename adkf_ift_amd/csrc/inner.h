@@ -318,8 +318,7 @@ __device__ __forceinline__ float pivot_ratio(const float* pivs, int n, float* re
     const int tid = threadIdx.x;
     float lo = INFINITY, hi = 0.f;
     for (int k = tid; k < n; k += NT) { const float p = pivs[k]; lo = fminf(lo, p); hi = fmaxf(hi, p); }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+    lo = wave_min(lo); hi = wave_max(hi);
     __syncthreads();
     if ((tid & 63) == 0) { red[2 * (tid >> 6)] = lo; red[2 * (tid >> 6) + 1] = hi; }
     __syncthreads();
@@ -404,8 +403,7 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
 #pragma unroll
             for (int c = 0; c < CB; ++c)
                 if (SW::row(r) == j0 + c && SW::row(r) < n) dmax = fmaxf(dmax, -m[r][c]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64));
+        dmax = wave_max(dmax);
         __syncthreads();
         if ((tid & 63) == 0) sm.red[tid >> 6] = dmax;
         __syncthreads();

@@ -58,20 +58,16 @@ struct ProbDist {
     __device__ int M() const { return mx; } __device__ int N() const { return my; } __device__ int K() const { return d; }
     __device__ float a(int i, int k) const { return Xi[(size_t)i * d + k] - mu[k]; }
     __device__ float b(int k, int j) const { return Yi[(size_t)j * d + k] - mu[k]; }
-    __device__ void a4(int i, int k, float (&v)[4]) const {
-        float m4[4];
-        ld4(Xi + (size_t)i * d + k, v);
-        ld4(mu + k, m4);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) v[x] -= m4[x];
+    static constexpr int A_NRAW = 2, B_NRAW = 2;   // two-phase operand path (gemm.h): loads, then the centring
+    __device__ bool raw_ok() const { return true; }
+    __device__ void a_raw(int i, int k, float4 (&r)[2]) const { r[0] = ldq(Xi + (size_t)i * d + k); r[1] = ldq(mu + k); }
+    __device__ void b_raw(int k, int j, float4 (&r)[2]) const { r[0] = ldq(Yi + (size_t)j * d + k); r[1] = ldq(mu + k); }
+    __device__ void a_fin(int, int, const float4 (&r)[2], float (&v)[4]) const {
+        v[0] = r[0].x - r[1].x; v[1] = r[0].y - r[1].y; v[2] = r[0].z - r[1].z; v[3] = r[0].w - r[1].w;
     }
-    __device__ void b4(int k, int j, float (&v)[4]) const {
-        float m4[4];
-        ld4(Yi + (size_t)j * d + k, v);
-        ld4(mu + k, m4);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) v[x] -= m4[x];
-    }
+    __device__ void b_fin(int k, int j, const float4 (&r)[2], float (&v)[4]) const { a_fin(j, k, r, v); }
+    __device__ void a4(int i, int k, float (&v)[4]) const { float4 r[2]; a_raw(i, k, r); a_fin(i, k, r, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const { float4 r[2]; b_raw(k, j, r); b_fin(k, j, r, v); }
     // symmetric (X == Y): only the tiles on or above the diagonal are computed; they also write their mirror image, so
     // the result is EXACTLY symmetric
     __device__ bool active(int m0, int n0) const { return !symmetric || m0 <= n0; }
@@ -98,6 +94,38 @@ struct ProbDist {
     __device__ void store_red(int, const float*) const {}
 };
 
+// Up to three distance blocks (support-support, query-support, query-query) in ONE launch: each block alone is 3-4 tiles
+// per task, which fills the chip for less than one round of resident workgroups and leaves launch, setup, first-fetch
+// and epilogue latency uncovered (three launches: 3 x 33 us at C2; one launch of all ten tiles per task: see DESIGN.md).
+// gemm.h's optional select() hook maps the flat tile index to (block, tile within the block).
+struct ProbDistMulti {
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
+    static constexpr int NRED = 0;
+    ProbDist s0, s1, s2; int end0, end1, tn0, tn1, tn2;   // tiles [0, end0) -> s0, [end0, end1) -> s1, the rest -> s2
+    ProbDist q; bool vec;
+    __device__ void select(int& tile, int& tiles_n) {
+        if (tile < end0) { q = s0; tiles_n = tn0; }
+        else if (tile < end1) { q = s1; tiles_n = tn1; tile -= end0; }
+        else { q = s2; tiles_n = tn2; tile -= end1; }
+    }
+    __device__ bool setup(int t) { return q.setup(t); }
+    __device__ int M() const { return q.M(); } __device__ int N() const { return q.N(); } __device__ int K() const { return q.K(); }
+    __device__ float a(int i, int k) const { return q.a(i, k); }
+    __device__ float b(int k, int j) const { return q.b(k, j); }
+    __device__ void a4(int i, int k, float (&v)[4]) const { q.a4(i, k, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const { q.b4(k, j, v); }
+    static constexpr int A_NRAW = 2, B_NRAW = 2;
+    __device__ bool raw_ok() const { return true; }
+    __device__ void a_raw(int i, int k, float4 (&r)[2]) const { q.a_raw(i, k, r); }
+    __device__ void b_raw(int k, int j, float4 (&r)[2]) const { q.b_raw(k, j, r); }
+    __device__ void a_fin(int i, int k, const float4 (&r)[2], float (&v)[4]) const { q.a_fin(i, k, r, v); }
+    __device__ void b_fin(int k, int j, const float4 (&r)[2], float (&v)[4]) const { q.b_fin(k, j, r, v); }
+    __device__ bool active(int m0, int n0) const { return q.active(m0, n0); }
+    __device__ void epi(int i, int j, float acc, float* red) const { q.epi(i, j, acc, red); }
+    __device__ void epi4(int i0, int j, const float (&acc)[4], float* red) const { q.epi4(i0, j, acc, red); }
+    __device__ void store_red(int, const float*) const {}
+};
+
 // ---- a4: fresh phi and priors ---------------------------------------------------------------------------
 struct InitArgs { int numeric, use_ls_prior; float* phi; float* priors; };   // phi == null: nothing to initialise
 
@@ -120,39 +148,59 @@ __global__ void k_init_params(const float* l0, int T, InitArgs a) {
 
 // ---- K10: median heuristic.  Exact lower median of the positive strict-upper-triangle entries by a
 // 31-step radix select on the float bit patterns (positive floats order like their bits). ---------------
-// One workgroup per task; the (at most 128 x 128) candidates are loaded ONCE into registers (32 per lane), every
-// radix step is then 32 compares + a wave/LDS count reduction, no memory traffic.
-template <int NT, int EPT>  // NT * EPT >= ld * ld: <512, 32> up to 128 points, <1024, 64> up to 256
+// One workgroup per task; the candidates are loaded ONCE into registers, every radix step is then one compare per held
+// value whose wave-wide count is the population count of the compare mask (a scalar instruction, no lane shuffles) and ONE
+// barrier for the cross-wave sum (partials alternate between two LDS rows).  Only the strict upper triangle is held:
+// rows i and n-1-i are folded into one row of n-1 candidates, so ceil(n/2) (n-1) slots cover all n (n-1) / 2 pairs.
+template <int NT, int EPT>  // NT * EPT >= ceil(ld / 2) * (ld - 1): <512, 16> up to 128 points, <1024, 32> up to 256
 __global__ __launch_bounds__(NT) void k_median(const float* D2ss, const int32_t* n_s, int ld, float* l0, int T, InitArgs init) {
-    __shared__ int red[NT / 64];
+    constexpr int NW = NT / 64;
+    __shared__ int red[2][NW];
     int t, tile;
     if (!task_tile(T, 1, t, tile)) return;
     const int n = n_s ? n_s[t] : ld;
     const uint32_t* D = reinterpret_cast<const uint32_t*>(D2ss + (size_t)t * ld * ld);
-    const int tid = threadIdx.x;
-    if (n <= 0 || n > ld) {   // an empty (or corrupt) task: no candidates, and no division by n below
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (n <= 1 || n > ld) {   // an empty, single-point (or corrupt) task: no candidates
         if (tid == 0) { l0[t] = 0.f; if (init.phi) init_params_task(init, t, 0.f); }
         return;
     }
+    const int nm1 = n - 1, slots = ((n + 1) >> 1) * nm1;
     uint32_t v[EPT];
-    int cnt = 0;
+    int nonzero = 0;   // wave-uniform
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
         const int e = r * NT + tid;
-        const int i = e / n, j = e - i * n;
-        v[r] = (e < n * n && j > i) ? D[(size_t)i * ld + j] : 0u;  // entries are clamped >= 0: 0 marks "not a candidate"
-        cnt += (v[r] != 0u);
+        uint32_t val = 0u;   // entries are clamped >= 0: 0 marks "not a candidate"
+        if (e < slots) {
+            const int fr = e / nm1, c = e - fr * nm1, top = nm1 - fr;   // row fr holds `top` candidates, row n-1-fr holds fr
+            const int i = c < top ? fr : top, j = c < top ? fr + 1 + c : top + 1 + (c - top);
+            if (c < top || top != fr) val = D[(size_t)i * ld + j];       // odd n: the middle row is folded onto itself
+        }
+        v[r] = val;
+        nonzero += __popcll(__ballot(val != 0u));
     }
-    const int total = block_sum_i<NT>(cnt, red);
+    const int zeros = EPT * 64 - nonzero;
+    if (lane == 0) red[0][wv] = nonzero;
+    __syncthreads();
+    int total = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) total += red[0][i];
     if (total == 0) { if (tid == 0) { l0[t] = 0.f; if (init.phi) init_params_task(init, t, 0.f); } return; }
     int rank = (total - 1) / 2;  // torch.median: lower median
     uint32_t prefix = 0;
-    for (int bit = 30; bit >= 0; --bit) {
+    int buf = 1;
+    for (int bit = 30; bit >= 0; --bit, buf ^= 1) {
         const uint32_t hi_mask = ~((1u << bit) - 1u);  // bits >= bit
         int c0 = 0;
 #pragma unroll
-        for (int r = 0; r < EPT; ++r) c0 += (v[r] != 0u && (v[r] & hi_mask) == prefix);  // prefix matches, this bit = 0
-        c0 = block_sum_i<NT>(c0, red);
+        for (int r = 0; r < EPT; ++r) c0 += __popcll(__ballot((v[r] & hi_mask) == prefix));  // prefix matches, this bit = 0
+        if (prefix == 0u) c0 -= zeros;   // the non-candidates match the all-zero prefix
+        if (lane == 0) red[buf][wv] = c0;
+        __syncthreads();   // one barrier per step: row `buf` was last read two steps ago, before the previous barrier
+        c0 = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) c0 += red[buf][i];
         if (rank >= c0) { rank -= c0; prefix |= (1u << bit); }
     }
     if (tid == 0) {
@@ -161,6 +209,13 @@ __global__ __launch_bounds__(NT) void k_median(const float* D2ss, const int32_t*
         if (init.phi) init_params_task(init, t, l);   // a4 in the same launch
     }
 }
+
+#if ADKF_STAMP_SMALL   // tools/small_bench.hip: s_memtime of the phases of the per-task kernels (workgroup 3, thread 0)
+__device__ unsigned long long g_small_stamps[16];
+#define ADKF_SST(k_) do { if (blockIdx.x == 3 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_small_stamps[k_] = t_; } } while (0)
+#else
+#define ADKF_SST(k_) do {} while (0)
+#endif
 
 // ---- Stage C: beta = G alpha, gamma = Ainv alpha, delta = Ainv beta, traces, 3x3 Hessian ------------------
 // (oracle/closed_form.py::inner_stage, want_hessian branch)
@@ -208,28 +263,33 @@ __global__ __launch_bounds__(SMALL_NT) void k_hess(HessArgs a) {
     float* ga = a.vecs + ((size_t)t * NVEC + V_GAMMA) * a.tv.vld;
     float* de = a.vecs + ((size_t)t * NVEC + V_DELTA) * a.tv.vld;
     const int kind = a.tv.kind;
+    ADKF_SST(0);
     // wave per row: beta_i = sum_j G_ij alpha_j ; gamma_i = sum_j Ainv_ij alpha_j
-    // (four rows in flight per wave in both mat-vec passes: a row at a time is a chain of L2 round trips)
-    for (int i0 = wv; i0 < n; i0 += 4 * NW) {
-        float sb[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
+    // (RF rows in flight per wave in both mat-vec passes: a row at a time is a chain of L2 round trips; RF = 8 makes each
+    // pass ONE round of loads at 128 points)
+    constexpr int RF = 8;
+    for (int i0 = wv; i0 < n; i0 += RF * NW) {
+        float sb[RF], sg[RF];
+#pragma unroll
+        for (int q = 0; q < RF; ++q) { sb[q] = 0.f; sg[q] = 0.f; }
         for (int j = lane; j < n; j += 64) {
             const float aj = al[j];
-            float d2v[4], av[4];
+            float d2v[RF], av[RF];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < RF; ++q) {
                 const int i = i0 + q * NW;
                 d2v[q] = i < n ? D2[(size_t)i * ld + j] : 0.f;
                 av[q] = i < n ? Ai[(size_t)i * ld + j] : 0.f;
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < RF; ++q) {
                 float k0, k1, k2; const float u = d2v[q] * il2; kappa3(kind, u, k0, k1, k2);
                 sb[q] += os * k1 * u * (-2.f / ls) * aj;
                 sg[q] += av[q] * aj;
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < RF; ++q) {
             const int i = i0 + q * NW;
             const float b_ = wave_sum(sb[q]), g_ = wave_sum(sg[q]);
             if (lane == 0 && i < n) { be[i] = b_; ga[i] = g_; }
@@ -237,18 +297,21 @@ __global__ __launch_bounds__(SMALL_NT) void k_hess(HessArgs a) {
     }
     __threadfence_block();
     __syncthreads();
-    for (int i0 = wv; i0 < n; i0 += 4 * NW) {
-        float sd[4] = {0.f, 0.f, 0.f, 0.f};
+    ADKF_SST(1);
+    for (int i0 = wv; i0 < n; i0 += RF * NW) {
+        float sd[RF];
+#pragma unroll
+        for (int q = 0; q < RF; ++q) sd[q] = 0.f;
         for (int j = lane; j < n; j += 64) {
             const float bj = be[j];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < RF; ++q) {
                 const int i = i0 + q * NW;
                 if (i < n) sd[q] += Ai[(size_t)i * ld + j] * bj;
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < RF; ++q) {
             const int i = i0 + q * NW;
             const float d_ = wave_sum(sd[q]);
             if (lane == 0 && i < n) de[i] = d_;
@@ -256,18 +319,32 @@ __global__ __launch_bounds__(SMALL_NT) void k_hess(HessArgs a) {
     }
     __threadfence_block();
     __syncthreads();
+    ADKF_SST(2);
     // elementwise traces
     float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // trA2, trPA, trPP, trAinvKll, aKlla, ag, bg, bd, ab
-    for (int e = tid; e < n * n; e += NT) {
-        const int i = e / n, j = e - i * n;
-        const float ai = Ai[(size_t)i * ld + j], pij = Pi[(size_t)i * ld + j], pji = Pi[(size_t)j * ld + i];
-        float k0, k1, k2; const float u = D2[(size_t)i * ld + j] * il2; kappa3(kind, u, k0, k1, k2);
-        const float Kll = os * (k2 * 4.f * u * u + k1 * 6.f * u) * il2;
-        acc[0] += ai * ai; acc[1] += pij * ai; acc[2] += pij * pji; acc[3] += ai * Kll; acc[4] += al[i] * al[j] * Kll;
+    // four elements per thread per trip: their sixteen loads (one of them, P^T, strided) go out together
+    for (int e0 = tid; e0 < n * n; e0 += 4 * NT) {
+        float ai[4], pij[4], pji[4], d2v[4], aa[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * NT;
+            const bool in = e < n * n;
+            const int i = in ? e / n : 0, j = in ? e - i * n : 0;
+            ai[q] = in ? Ai[(size_t)i * ld + j] : 0.f; pij[q] = in ? Pi[(size_t)i * ld + j] : 0.f; pji[q] = in ? Pi[(size_t)j * ld + i] : 0.f;
+            d2v[q] = in ? D2[(size_t)i * ld + j] : 0.f; aa[q] = in ? al[i] * al[j] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float k0, k1, k2; const float u = d2v[q] * il2; kappa3(kind, u, k0, k1, k2);
+            const float Kll = os * (k2 * 4.f * u * u + k1 * 6.f * u) * il2;
+            acc[0] += ai[q] * ai[q]; acc[1] += pij[q] * ai[q]; acc[2] += pij[q] * pji[q]; acc[3] += ai[q] * Kll; acc[4] += aa[q] * Kll;
+        }
     }
     if (tid < n) { acc[5] = al[tid] * ga[tid]; acc[6] = be[tid] * ga[tid]; acc[7] = be[tid] * de[tid]; acc[8] = al[tid] * be[tid]; }
     for (int i = tid + NT; i < n; i += NT) { acc[5] += al[i] * ga[i]; acc[6] += be[i] * ga[i]; acc[7] += be[i] * de[i]; acc[8] += al[i] * be[i]; }
+    ADKF_SST(3);
     block_sum<9, NT>(acc, red);
+    ADKF_SST(4);
     if (tid == 0) hess_assemble(sc, a.priors + t * 4, n, acc);
 }
 
@@ -324,26 +401,8 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
     const int j0 = SW::bc() * CB;
     if (tid < NMAX) sm.vec_in[tid] = 0.f;
     __syncthreads();
-    // residual r = y_q - C y_s  (wave per row)
-    // (four rows in flight per wave: the loop is a chain of L2 round trips otherwise - 17 us at 128 x 128, measured)
-    for (int i0 = wv; i0 < m; i0 += 4 * NW) {
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int j = lane; j < n; j += 64) {
-            const float yj = ys[j];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * NW;
-                if (i < m) s[u] += Ci[(size_t)i * a.tv.ns_ld + j] * yj;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * NW;
-            const float t_ = wave_sum(s[u]);
-            if (lane == 0 && i < m) { vbase[V_MU * a.tv.vld + i] = t_; sm.vec_in[i] = yq[i] - t_; }
-        }
-    }
-    // this thread's block of S (exactly symmetric by construction), identity-padded
+    // this thread's block of S (exactly symmetric by construction), identity-padded: the loads are issued first and
+    // land while the residual below is formed
     float mm[RB][CB];
 #pragma unroll
     for (int r = 0; r < RB; ++r)
@@ -352,6 +411,28 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
             const int i = SW::row(r), j = j0 + c;
             mm[r][c] = (i < m && j < m) ? Si[(size_t)i * a.tv.nq_ld + j] : (i == j ? 1.f : 0.f);   // ProbS mirrors its tiles
         }
+    // residual r = y_q - C y_s  (wave per row; ALL of a wave's rows in flight at once: a row at a time is a chain of L2
+    // round trips - 17 us at 128 x 128, measured; four at a time left four trips)
+    {
+        constexpr int RW = NMAX / NW;   // rows per wave
+        float s[RW];
+#pragma unroll
+        for (int u = 0; u < RW; ++u) s[u] = 0.f;
+        for (int j = lane; j < n; j += 64) {
+            const float yj = ys[j];
+#pragma unroll
+            for (int u = 0; u < RW; ++u) {
+                const int i = wv + u * NW;
+                if (i < m) s[u] += Ci[(size_t)i * a.tv.ns_ld + j] * yj;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RW; ++u) {
+            const int i = wv + u * NW;
+            const float t_ = wave_sum(s[u]);
+            if (lane == 0 && i < m) { vbase[V_MU * a.tv.vld + i] = t_; sm.vec_in[i] = yq[i] - t_; }
+        }
+    }
     __syncthreads();
     SW::run(mm, m, sm);
     float logdet;
@@ -374,16 +455,41 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
             const int i = SW::row(r), j = j0 + c;
             if (i < m && j < m) Si[(size_t)i * a.tv.nq_ld + j] = -mm[r][c];
         }
-    // Cte_j = sum_i C_ij e_i  (thread per column: coalesced)
-    for (int j = tid; j < n; j += NT) {
-        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // eight loads in flight
-        int i = 0;
-        for (; i + 8 <= m; i += 8) {
+    // Cte_j = sum_i C_ij e_i  (thread per column: coalesced; the rows are split over PARTS thread groups so that every
+    // thread works and a column is PARTS short chains of loads instead of one long one: 12 -> 4 dependent round trips
+    // at 128 x 128)
+    {
+        constexpr int PARTS = NMAX >= 64 ? NT / NMAX : 1, COLS = NT / PARTS;
+        static_assert(PARTS == 1 || sizeof(sm.cross) >= sizeof(float) * NT, "the partial sums reuse the sweep's LDS slots");
+        float* part_s = &sm.cross[0][0][0];
+        const int jl = tid % COLS, part = tid / COLS;
+        const int per = (m + PARTS - 1) / PARTS, i_lo = part * per, i_hi = min(m, i_lo + per);
+        for (int jb = 0; jb < n; jb += COLS) {   // n is the SUPPORT count: it may exceed NMAX (which follows the query count)
+            const int j = jb + jl;
+            float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // eight loads in flight
+            if (j < n) {
+                int i = i_lo;
+                for (; i + 8 <= i_hi; i += 8) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s8[u] += Ci[(size_t)(i + u) * a.tv.ns_ld + j] * sm.vec_out[i + u];
+                    for (int u = 0; u < 8; ++u) s8[u] += Ci[(size_t)(i + u) * a.tv.ns_ld + j] * sm.vec_out[i + u];
+                }
+                for (; i < i_hi; ++i) s8[0] += Ci[(size_t)i * a.tv.ns_ld + j] * sm.vec_out[i];
+            }
+            const float part_sum = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+            if (PARTS == 1) {
+                if (j < n) vbase[V_CTE * a.tv.vld + j] = part_sum;
+            } else {
+                __syncthreads();
+                part_s[tid] = part_sum;
+                __syncthreads();
+                if (part == 0 && j < n) {
+                    float c = 0.f;
+#pragma unroll
+                    for (int q2 = 0; q2 < PARTS; ++q2) c += part_s[q2 * COLS + jl];
+                    vbase[V_CTE * a.tv.vld + j] = c;
+                }
+            }
         }
-        for (; i < m; ++i) s8[0] += Ci[(size_t)i * a.tv.ns_ld + j] * sm.vec_out[i];
-        vbase[V_CTE * a.tv.vld + j] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     }
     if (tid == 0) {
         const float f = 0.5f * q[0] + 0.5f * logdet + 0.5f * (float)m * LOG_2PI;
@@ -493,14 +599,27 @@ __global__ __launch_bounds__(SMALL_NT) void k_wqq(WqqArgs a) {
     float* Wo = a.Wqq + (size_t)t * ld * ld;
     const float* ev = a.tv.vec_ptr(t, V_E);
     float acc[3] = {0.f, 0.f, 0.f};
-    for (int e = tid; e < m * m; e += NT) {
-        const int i = e / m, j = e - i * m;
-        const float om = 0.5f * (Si[(size_t)i * ld + j] - ev[i] * ev[j]);
-        float k0, k1, k2; const float u = D2[(size_t)i * ld + j] * il2; kappa3(a.tv.kind, u, k0, k1, k2);
-        Wo[(size_t)i * ld + j] = a.dirscale * om * os * k1 * il2;
-        if (i == j) acc[0] += om;
-        acc[1] += om * k0;
-        acc[2] += om * os * k1 * u * (-2.f / ls);
+    for (int e0 = tid; e0 < m * m; e0 += 4 * NT) {   // four elements per trip: their loads go out together
+        float sv[4], dv[4], ee[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * NT;
+            const bool in = e < m * m;
+            const int i = in ? e / m : 0, j = in ? e - i * m : 0;
+            sv[q] = in ? Si[(size_t)i * ld + j] : 0.f; dv[q] = in ? D2[(size_t)i * ld + j] : 0.f; ee[q] = in ? ev[i] * ev[j] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * NT;
+            if (e >= m * m) break;
+            const int i = e / m, j = e - i * m;
+            const float om = 0.5f * (sv[q] - ee[q]);
+            float k0, k1, k2; const float u = dv[q] * il2; kappa3(a.tv.kind, u, k0, k1, k2);
+            Wo[(size_t)i * ld + j] = a.dirscale * om * os * k1 * il2;
+            if (i == j) acc[0] += om;
+            acc[1] += om * k0;
+            acc[2] += om * os * k1 * u * (-2.f / ls);
+        }
     }
     block_sum<3, NT>(acc, red);
     if (tid == 0) { sc[S_QQ_TR] = acc[0]; sc[S_QQ_K] = acc[1]; sc[S_QQ_L] = acc[2]; }
@@ -527,33 +646,61 @@ __global__ __launch_bounds__(SMALL_NT) void k_rowsums(RowsumArgs a) {
     // column sums of W_qs: every wave sums its share of the rows for all columns (coalesced), partials meet in LDS
     constexpr int CMAX = 128;  // larger sets take k_lg_colsum / k_lg_rowsums (large.h)
     __shared__ float cpart[NW][CMAX];
+    // (every pass keeps RF rows per wave in flight: a row at a time is a chain of L2 round trips, 27 us at 128 points)
+    constexpr int RF = 8;
     if (m > 0) {
         for (int j = lane; j < n; j += 64) {
             float s = 0.f;
-            for (int i = wv; i < m; i += NW) s += Wqs[(size_t)i * a.tv.ns_ld + j];
+            for (int i0 = wv; i0 < m; i0 += RF * NW) {
+                float v[RF];
+#pragma unroll
+                for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; v[q] = i < m ? Wqs[(size_t)i * a.tv.ns_ld + j] : 0.f; }
+#pragma unroll
+                for (int q = 0; q < RF; ++q) s += v[q];
+            }
             cpart[wv][j] = s;
         }
     }
     __syncthreads();
-    for (int i = wv; i < n; i += NW) {
-        float s = 0.f;
-#pragma unroll 4
-        for (int j = lane; j < n; j += 64) s += Wss[(size_t)i * a.tv.ns_ld + j];
-        s = wave_sum(s);
-        if (lane == 0) {
-            float cs = 0.f;
-            if (m > 0)
-                for (int w = 0; w < NW; ++w) cs += cpart[w][i];
-            vb[V_RS_SS * a.tv.vld + i] = 4.f * s + 2.f * cs;
+    for (int i0 = wv; i0 < n; i0 += RF * NW) {
+        float s[RF];
+#pragma unroll
+        for (int q = 0; q < RF; ++q) s[q] = 0.f;
+        for (int j = lane; j < n; j += 64) {
+#pragma unroll
+            for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; if (i < n) s[q] += Wss[(size_t)i * a.tv.ns_ld + j]; }
+        }
+#pragma unroll
+        for (int q = 0; q < RF; ++q) {
+            const int i = i0 + q * NW;
+            const float t_ = wave_sum(s[q]);
+            if (lane == 0 && i < n) {
+                float cs = 0.f;
+                if (m > 0)
+                    for (int w = 0; w < NW; ++w) cs += cpart[w][i];
+                vb[V_RS_SS * a.tv.vld + i] = 4.f * t_ + 2.f * cs;
+            }
         }
     }
     if (m > 0) {
-        for (int i = wv; i < m; i += NW) {
-            float s1 = 0.f, s2 = 0.f;
-            for (int j = lane; j < n; j += 64) s1 += Wqs[(size_t)i * a.tv.ns_ld + j];
-            for (int j = lane; j < m; j += 64) s2 += Wqq[(size_t)i * a.tv.nq_ld + j];
-            s1 = wave_sum(s1); s2 = wave_sum(s2);
-            if (lane == 0) vb[V_RS_QS * a.tv.vld + i] = 2.f * s1 + 4.f * s2;
+        for (int i0 = wv; i0 < m; i0 += RF * NW) {
+            float s1[RF], s2[RF];
+#pragma unroll
+            for (int q = 0; q < RF; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+            for (int j = lane; j < n; j += 64) {
+#pragma unroll
+                for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; if (i < m) s1[q] += Wqs[(size_t)i * a.tv.ns_ld + j]; }
+            }
+            for (int j = lane; j < m; j += 64) {
+#pragma unroll
+                for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; if (i < m) s2[q] += Wqq[(size_t)i * a.tv.nq_ld + j]; }
+            }
+#pragma unroll
+            for (int q = 0; q < RF; ++q) {
+                const int i = i0 + q * NW;
+                const float t1 = wave_sum(s1[q]), t2 = wave_sum(s2[q]);
+                if (lane == 0 && i < m) vb[V_RS_QS * a.tv.vld + i] = 2.f * t1 + 4.f * t2;
+            }
         }
     }
 }

@@ -29,6 +29,9 @@ __device__ __forceinline__ void ld4(const float* p, float (&v)[4]) {
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
 }
 
+__device__ __forceinline__ float4 ldq(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void unq(const float4& t, float (&v)[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+
 // ---- G1: P = Ainv * G,   G = dK_ss/dl = s kappa'(u) (-2u/l) ------------------------------------------
 struct ProbP {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
@@ -45,12 +48,18 @@ struct ProbP {
     __device__ float gfun(float d2) const { float k0, k1, k2; const float u = d2 * il2; kappa3(tv.kind, u, k0, k1, k2); return os * k1 * u * (-2.f / ls); }
     __device__ float a(int i, int k) const { return Ai[(size_t)i * tv.ns_ld + k]; }
     __device__ float b(int k, int j) const { return gfun(D2[(size_t)j * tv.ns_ld + k]); }  // G symmetric: row j, contiguous in k
-    __device__ void a4(int i, int k, float (&v)[4]) const { ld4(Ai + (size_t)i * tv.ns_ld + k, v); }
-    __device__ void b4(int k, int j, float (&v)[4]) const {
-        ld4(D2 + (size_t)j * tv.ns_ld + k, v);
+    static constexpr int A_NRAW = 1, B_NRAW = 1;   // two-phase operand path (gemm.h): loads, then arithmetic
+    __device__ bool raw_ok() const { return true; }
+    __device__ void a_raw(int i, int k, float4 (&r)[1]) const { r[0] = ldq(Ai + (size_t)i * tv.ns_ld + k); }
+    __device__ void a_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
+    __device__ void b_raw(int k, int j, float4 (&r)[1]) const { r[0] = ldq(D2 + (size_t)j * tv.ns_ld + k); }
+    __device__ void b_fin(int, int, const float4 (&r)[1], float (&v)[4]) const {
+        unq(r[0], v);
 #pragma unroll
         for (int x = 0; x < 4; ++x) v[x] = gfun(v[x]);
     }
+    __device__ void a4(int i, int k, float (&v)[4]) const { float4 r[1]; a_raw(i, k, r); a_fin(i, k, r, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const { float4 r[1]; b_raw(k, j, r); b_fin(k, j, r, v); }
     __device__ void epi(int i, int j, float acc, float*) const { Po[(size_t)i * tv.ns_ld + j] = acc; }
     __device__ void store_red(int, const float*) const {}
 };
@@ -70,12 +79,18 @@ struct ProbC {
     __device__ int M() const { return m; } __device__ int N() const { return n; } __device__ int K() const { return n; }
     __device__ float a(int i, int k) const { return os * kappa0(tv.kind, D2[(size_t)i * tv.ns_ld + k] * il2); }
     __device__ float b(int k, int j) const { return Ai[(size_t)j * tv.ns_ld + k]; }
-    __device__ void a4(int i, int k, float (&v)[4]) const {
-        ld4(D2 + (size_t)i * tv.ns_ld + k, v);
+    static constexpr int A_NRAW = 1, B_NRAW = 1;
+    __device__ bool raw_ok() const { return true; }
+    __device__ void a_raw(int i, int k, float4 (&r)[1]) const { r[0] = ldq(D2 + (size_t)i * tv.ns_ld + k); }
+    __device__ void a_fin(int, int, const float4 (&r)[1], float (&v)[4]) const {
+        unq(r[0], v);
 #pragma unroll
         for (int x = 0; x < 4; ++x) v[x] = os * kappa0(tv.kind, v[x] * il2);
     }
-    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(Ai + (size_t)j * tv.ns_ld + k, v); }
+    __device__ void b_raw(int k, int j, float4 (&r)[1]) const { r[0] = ldq(Ai + (size_t)j * tv.ns_ld + k); }
+    __device__ void b_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
+    __device__ void a4(int i, int k, float (&v)[4]) const { float4 r[1]; a_raw(i, k, r); a_fin(i, k, r, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const { float4 r[1]; b_raw(k, j, r); b_fin(k, j, r, v); }
     __device__ void epi(int i, int j, float acc, float*) const { Co[(size_t)i * tv.ns_ld + j] = acc; }
     __device__ void store_red(int, const float*) const {}
 };
@@ -155,12 +170,18 @@ struct ProbS {
     __device__ int M() const { return m; } __device__ int N() const { return m; } __device__ int K() const { return n; }
     __device__ float a(int i, int k) const { return Ci[(size_t)i * tv.ns_ld + k]; }
     __device__ float b(int k, int j) const { return os * kappa0(tv.kind, Dqs[(size_t)j * tv.ns_ld + k] * il2); }
-    __device__ void a4(int i, int k, float (&v)[4]) const { ld4(Ci + (size_t)i * tv.ns_ld + k, v); }
-    __device__ void b4(int k, int j, float (&v)[4]) const {
-        ld4(Dqs + (size_t)j * tv.ns_ld + k, v);
+    static constexpr int A_NRAW = 1, B_NRAW = 1;
+    __device__ bool raw_ok() const { return true; }
+    __device__ void a_raw(int i, int k, float4 (&r)[1]) const { r[0] = ldq(Ci + (size_t)i * tv.ns_ld + k); }
+    __device__ void a_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
+    __device__ void b_raw(int k, int j, float4 (&r)[1]) const { r[0] = ldq(Dqs + (size_t)j * tv.ns_ld + k); }
+    __device__ void b_fin(int, int, const float4 (&r)[1], float (&v)[4]) const {
+        unq(r[0], v);
 #pragma unroll
         for (int x = 0; x < 4; ++x) v[x] = os * kappa0(tv.kind, v[x] * il2);
     }
+    __device__ void a4(int i, int k, float (&v)[4]) const { float4 r[1]; a_raw(i, k, r); a_fin(i, k, r, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const { float4 r[1]; b_raw(k, j, r); b_fin(k, j, r, v); }
     // S is symmetric: tiles below the diagonal are written by their mirror images (exactly symmetric result)
     __device__ bool active(int m0, int n0) const { return m0 <= n0; }
     __device__ float value(int i, int j, float acc) const {
@@ -202,15 +223,22 @@ struct ProbOC {
     __device__ int M() const { return m; } __device__ int N() const { return n; } __device__ int K() const { return m; }
     __device__ float a(int i, int k) const { return 0.5f * (Si[(size_t)i * tv.nq_ld + k] - ev[i] * ev[k]); }
     __device__ float b(int k, int j) const { return Ci[(size_t)k * tv.ns_ld + j]; }
-    __device__ void a4(int i, int k, float (&v)[4]) const {
+    static constexpr int A_NRAW = 3, B_NRAW = 1;
+    __device__ bool raw_ok() const { return true; }
+    __device__ void a_raw(int i, int k, float4 (&r)[3]) const {
+        r[0] = ldq(Si + (size_t)i * tv.nq_ld + k); r[1] = ldq(ev + k); r[2].x = ev[i];
+    }
+    __device__ void a_fin(int, int, const float4 (&r)[3], float (&v)[4]) const {
         float e4[4];
-        ld4(Si + (size_t)i * tv.nq_ld + k, v);
-        ld4(ev + k, e4);
-        const float ei = ev[i];
+        unq(r[0], v); unq(r[1], e4);
+        const float ei = r[2].x;
 #pragma unroll
         for (int x = 0; x < 4; ++x) v[x] = 0.5f * (v[x] - ei * e4[x]);
     }
-    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(Ci + (size_t)k * tv.ns_ld + j, v); }
+    __device__ void b_raw(int k, int j, float4 (&r)[1]) const { r[0] = ldq(Ci + (size_t)k * tv.ns_ld + j); }
+    __device__ void b_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
+    __device__ void a4(int i, int k, float (&v)[4]) const { float4 r[3]; a_raw(i, k, r); a_fin(i, k, r, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const { float4 r[1]; b_raw(k, j, r); b_fin(k, j, r, v); }
     __device__ void epi(int i, int j, float acc, float* red) const {
         OCo[(size_t)i * tv.ns_ld + j] = acc;
         const float MB = -2.f * acc - ev[i] * al[j];
@@ -240,8 +268,14 @@ struct ProbMA {
     __device__ int M() const { return n; } __device__ int N() const { return n; } __device__ int K() const { return m; }
     __device__ float a(int i, int k) const { return Ci[(size_t)k * tv.ns_ld + i]; }
     __device__ float b(int k, int j) const { return OCi[(size_t)k * tv.ns_ld + j]; }
-    __device__ void a4(int i, int k, float (&v)[4]) const { ld4(Ci + (size_t)k * tv.ns_ld + i, v); }
-    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(OCi + (size_t)k * tv.ns_ld + j, v); }
+    static constexpr int A_NRAW = 1, B_NRAW = 1;
+    __device__ bool raw_ok() const { return true; }
+    __device__ void a_raw(int i, int k, float4 (&r)[1]) const { r[0] = ldq(Ci + (size_t)k * tv.ns_ld + i); }
+    __device__ void a_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
+    __device__ void b_raw(int k, int j, float4 (&r)[1]) const { r[0] = ldq(OCi + (size_t)k * tv.ns_ld + j); }
+    __device__ void b_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
+    __device__ void a4(int i, int k, float (&v)[4]) const { float4 r[1]; a_raw(i, k, r); a_fin(i, k, r, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const { float4 r[1]; b_raw(k, j, r); b_fin(k, j, r, v); }
     __device__ void epi(int i, int j, float acc, float* red) const {
         const float MA = acc + 0.5f * (cte[i] * al[j] + al[i] * cte[j]);
         float k0, k1, k2; const float u = Dss[(size_t)i * tv.ns_ld + j] * il2; kappa3(tv.kind, u, k0, k1, k2);
@@ -275,14 +309,19 @@ struct ProbMixed {
         return (cn - cs * noise) * ai + (i == k ? cs : 0.f) + cl * Pi[(size_t)i * tv.ns_ld + k];
     }
     __device__ float b(int k, int j) const { return Ai[(size_t)j * tv.ns_ld + k]; }
-    __device__ void a4(int i, int k, float (&v)[4]) const {
+    static constexpr int A_NRAW = 2, B_NRAW = 1;
+    __device__ bool raw_ok() const { return true; }
+    __device__ void a_raw(int i, int k, float4 (&r)[2]) const { r[0] = ldq(Ai + (size_t)i * tv.ns_ld + k); r[1] = ldq(Pi + (size_t)i * tv.ns_ld + k); }
+    __device__ void a_fin(int i, int k, const float4 (&r)[2], float (&v)[4]) const {
         float p4[4];
-        ld4(Ai + (size_t)i * tv.ns_ld + k, v);
-        ld4(Pi + (size_t)i * tv.ns_ld + k, p4);
+        unq(r[0], v); unq(r[1], p4);
 #pragma unroll
         for (int x = 0; x < 4; ++x) v[x] = (cn - cs * noise) * v[x] + (i == k + x ? cs : 0.f) + cl * p4[x];
     }
-    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(Ai + (size_t)j * tv.ns_ld + k, v); }
+    __device__ void b_raw(int k, int j, float4 (&r)[1]) const { r[0] = ldq(Ai + (size_t)j * tv.ns_ld + k); }
+    __device__ void b_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
+    __device__ void a4(int i, int k, float (&v)[4]) const { float4 r[2]; a_raw(i, k, r); a_fin(i, k, r, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const { float4 r[1]; b_raw(k, j, r); b_fin(k, j, r, v); }
     __device__ void epi(int i, int j, float acc, float*) const {
         const float fn = (float)n;
         const float dgdA = (-0.5f * acc + 0.5f * (wv[i] * al[j] + al[i] * wv[j])) / fn;
@@ -335,6 +374,25 @@ struct ProbDZ {
         }
     }
     __device__ void b4(int k, int j, float (&v)[4]) const { ld4((k < n ? Zsi + (size_t)k * d : Zqi + (size_t)(k - n) * d) + j, v); }
+    // two-phase path: the support count must be a multiple of the chunk, so that a chunk never straddles the two K segments
+    static constexpr int A_NRAW = 1, B_NRAW = 1;
+    __device__ bool raw_ok() const { return (n % GK) == 0; }
+    __device__ void a_raw(int i, int k, float4 (&r)[1]) const {
+        if (k < n) r[0] = ldq((QUERY ? Wqsi : Wssi) + (size_t)i * tv.ns_ld + k);
+        else if (QUERY) r[0] = ldq(Wqqi + (size_t)i * tv.nq_ld + (k - n));
+        else {   // W_qs^T: strided in k
+            const float* w = Wqsi + (size_t)(k - n) * tv.ns_ld + i;
+            r[0] = make_float4(w[0], w[tv.ns_ld], w[2 * (size_t)tv.ns_ld], w[3 * (size_t)tv.ns_ld]);
+        }
+    }
+    __device__ void a_fin(int, int k, const float4 (&r)[1], float (&v)[4]) const {
+        const float f = (k < n) == QUERY ? 2.f : 4.f;   // W_qs carries 2, W_ss and W_qq carry 4
+        unq(r[0], v);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[x] *= f;
+    }
+    __device__ void b_raw(int k, int j, float4 (&r)[1]) const { r[0] = ldq((k < n ? Zsi + (size_t)k * d : Zqi + (size_t)(k - n) * d) + j); }
+    __device__ void b_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
     __device__ void epi(int i, int j, float acc, float*) const {
         const float z = QUERY ? Zqi[(size_t)i * d + j] : Zsi[(size_t)i * d + j];
         dZo[(size_t)i * d + j] = coef[i] * z - acc;

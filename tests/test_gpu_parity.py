@@ -134,7 +134,10 @@ def test_fit_reaches_oracle_optimum(golden_dir, dev):
         phi, f, gn, ne, info = gp_ops.fit(b, phi0, max_evals=200)
         gp_ops.check_info(info)
         assert f[0].item() <= g["f_in"] + 1e-5 * abs(g["f_in"]) + 1e-6, (name, f[0].item(), float(g["f_in"]))
-        assert gn[0].item() <= 2e-4, (name, gn[0].item())
+        # The fit stops when f no longer decreases in float32.  With curvature h <= 0.4 (these fixtures) a gradient below
+        # sqrt(2 h eps32 f) ~ 3.5e-4 changes f by less than one float32 ulp, so that is what "converged" can resolve; which
+        # side of 2e-4 a run ends on depends on the rounding of the reductions (seen: 4e-7 and 2.4e-4 for the same f).
+        assert gn[0].item() <= 5e-4, (name, gn[0].item())
         assert ne[0].item() <= 200
 
 
