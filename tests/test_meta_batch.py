@@ -1,5 +1,6 @@
 """CPU: collating many single-task DKTBatches into one disconnected graph + index maps reproduces the per-task
 features exactly (the GP tail is not involved here)."""
+import pytest
 import torch
 
 from adkf_ift_amd.gnn import GNNConfig, GraphFeatureExtractorConfig, GraphReadoutConfig
@@ -156,3 +157,16 @@ def test_ingests_the_reference_numpy_batch_objects():
     with pytest.raises(ValueError):
         dkt_batch_from_fsmol(RefDKTBatch(bad, ref.support_labels, ref.support_numeric_labels, ref.query_features, ref.query_labels,
                                          ref.query_numeric_labels))
+
+
+def test_shipped_gemm_tuning_file_and_guards():
+    """adkf_ift_amd/gemm_tuning.py: the recorded library-GEMM choices are tied to gfx950 and are never written to."""
+    from adkf_ift_amd import gemm_tuning
+
+    lines = open(gemm_tuning.SHIPPED).read().splitlines()
+    assert any(l.startswith("Validator,GCN_ARCH_NAME,gfx950") for l in lines)
+    assert sum(l.startswith("Gemm") for l in lines) >= 20          # forward and both backward products of the C3 model
+    with pytest.raises(ValueError):
+        gemm_tuning.use_tuned_gemms(tune=True)                      # tuning appends: not into the tracked file
+    with pytest.raises(FileNotFoundError):
+        gemm_tuning.use_tuned_gemms("/nonexistent/gemm.csv")

@@ -37,8 +37,15 @@ def main():
     ap.add_argument("--query", type=int, default=128)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--gemm-tuning", choices=("off", "shipped", "tune"), default="shipped",
+                    help="library-GEMM algorithm selection (adkf_ift_amd/gemm_tuning.py): off = hipBLASLt heuristic, shipped = the recorded "
+                         "choices for these shapes, tune = measure now into --gemm-file")
+    ap.add_argument("--gemm-file", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    if a.gemm_tuning != "off":
+        from adkf_ift_amd.gemm_tuning import use_tuned_gemms
+        use_tuned_gemms(a.gemm_file, tune=a.gemm_tuning == "tune")
     gen = torch.Generator().manual_seed(0)
     tasks = []
     for _ in range(a.tasks):
@@ -60,7 +67,7 @@ def main():
     print(json.dumps({"workload": f"C3: {a.tasks} tasks/step, {a.support}-shot, {a.query} query molecules, default GNN+ECFP+fc model "
                                   f"({sum(p.numel() for p in model.parameters()) / 1e6:.1f} M params), inner fit to convergence",
                       "tasks_per_s": a.tasks / dt, "ms_per_step": dt * 1e3, "nodes": int(mb.molecules.node_features.shape[0]),
-                      "mean_loss": float(losses.mean())}))
+                      "mean_loss": float(losses.mean()), "gemm_tuning": a.gemm_tuning}))
 
 
 if __name__ == "__main__":
