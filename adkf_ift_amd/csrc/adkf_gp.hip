@@ -137,17 +137,13 @@ inline bool has_query(const adkf_batch_t* b) { return b->nq_max > 0 && b->Z_q !=
 // Stage A: centring, row norms, squared distances.  Skipped when the caller promises (ADKF_BATCH_REUSE_DIST) that
 // this workspace already holds them for exactly this batch.
 // parts: 1 = the support block (mean, norms, D2ss), 2 = the query blocks (needs the support mean / norms in place),
-// 4 = the features are already centred and w.mean holds zeros (ARD: Z~ = (Z - mu) / l has zero column mean by construction),
-// 8 / 16 = the support / query row norms are already in w.nrm_s / w.nrm_q (ARD: k_ard_scale_norm wrote them).
+// 4 = the features are already centred and w.mean holds zeros (ARD: Z~ = (Z - mu) / l has zero column mean by construction).
+// (The squared row norms are summed inside the distance GEMM while it stages its operands: no separate pass.)
 int stage_dist(const adkf_batch_t* b, const Workspace& w, bool with_query, hipStream_t st, int parts = 3) {
     if (b->flags & ADKF_BATCH_REUSE_DIST) return 0;
     const int T = b->T, ns = b->ns_max, nq = with_query ? b->nq_max : 0, d = b->d;
     if (!(parts & 2)) with_query = false;
-    if (parts & 1) {
-        if (!(parts & 4)) k_colmean<<<dim3(ceil_div(d, 64), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, T);
-        if (!(parts & 8)) k_rownorm<<<dim3(ceil_div(ns, 4), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, w.nrm_s, T);
-    }
-    if (with_query && !(parts & 16)) k_rownorm<<<dim3(ceil_div(nq, 4), T), 256, 0, st>>>(b->Z_q, b->n_q, nq, d, w.mean, w.nrm_q, T);
+    if ((parts & 1) && !(parts & 4)) k_colmean<<<dim3(ceil_div(d, 64), T), 256, 0, st>>>(b->Z_s, b->n_s, ns, d, w.mean, T);
     ProbDist p;
     p.mean = w.mean; p.d = d; p.vec = vec_ok(b, w);
     ProbDistMulti pm;
@@ -161,13 +157,13 @@ int stage_dist(const adkf_batch_t* b, const Workspace& w, bool with_query, hipSt
         total += tiles; ++nblk;
     };
     if (parts & 1) {
-        p.X = b->Z_s; p.Y = b->Z_s; p.nx = w.nrm_s; p.ny = w.nrm_s; p.n_x = b->n_s; p.n_y = b->n_s; p.x_ld = ns; p.y_ld = ns; p.symmetric = true; p.D2 = w.D2ss;
+        p.X = b->Z_s; p.Y = b->Z_s; p.n_x = b->n_s; p.n_y = b->n_s; p.x_ld = ns; p.y_ld = ns; p.symmetric = true; p.D2 = w.D2ss;
         add(p, ns, ns);
     }
     if (with_query) {
-        p.X = b->Z_q; p.Y = b->Z_s; p.nx = w.nrm_q; p.ny = w.nrm_s; p.n_x = b->n_q; p.n_y = b->n_s; p.x_ld = nq; p.y_ld = ns; p.symmetric = false; p.D2 = w.D2qs;
+        p.X = b->Z_q; p.Y = b->Z_s; p.n_x = b->n_q; p.n_y = b->n_s; p.x_ld = nq; p.y_ld = ns; p.symmetric = false; p.D2 = w.D2qs;
         add(p, nq, ns);
-        p.X = b->Z_q; p.Y = b->Z_q; p.nx = w.nrm_q; p.ny = w.nrm_q; p.n_x = b->n_q; p.n_y = b->n_q; p.x_ld = nq; p.y_ld = nq; p.symmetric = true; p.D2 = w.D2qq;
+        p.X = b->Z_q; p.Y = b->Z_q; p.n_x = b->n_q; p.n_y = b->n_q; p.x_ld = nq; p.y_ld = nq; p.symmetric = true; p.D2 = w.D2qq;
         add(p, nq, nq);
     }
     if (nblk > 0) k_bgemm<ProbDistMulti, GT><<<grid_for(T, total), 256, 0, st>>>(pm, T, 1, total);

@@ -29,6 +29,9 @@
 //                                                  lower tiles of a symmetric result, written by their mirror images)
 //   __device__ void  select(int& tile, int& tiles_n) : OPTIONAL - called before setup(): picks one of several sub-problems
 //                                                  from the flat tile index and rewrites it to that sub-problem's own
+//   __device__ void  set_rowsq(const float* a, const float* b, int m0, int n0) : OPTIONAL (both operands K-contiguous) - the kernel sums the
+//                                                  squares of the staged operand rows over all of K (a by-product of the staging
+//                                                  pass) and hands the tile's TM + TM sums to the functor before the epilogue
 //   __device__ void  epi4(int i0, int j, const float (&acc)[4], float* red) : OPTIONAL - four consecutive rows of one
 //                                                  column at once (what one lane holds after the MFMA), all in range
 #pragma once
@@ -63,6 +66,8 @@ template <class P> struct has_select<P, std::void_t<decltype(&P::select)>> : std
 template <class P, class = void> struct has_epi4 : std::false_type {};
 template <class P> struct has_epi4<P, std::void_t<decltype(&P::epi4)>> : std::true_type {};
 
+template <class P, class = void> struct has_rowsq : std::false_type {};
+template <class P> struct has_rowsq<P, std::void_t<decltype(&P::set_rowsq)>> : std::true_type {};
 template <class P, class = void> struct has_raw : std::false_type {};
 template <class P> struct has_raw<P, std::void_t<decltype(P::A_NRAW)>> : std::true_type {};
 
@@ -106,8 +111,8 @@ __device__ __forceinline__ void gemm_fetch(const P& p, float (&reg)[GemmCfg<TM>:
     }
 }
 
-template <bool KC, int TM>
-__device__ __forceinline__ void gemm_stage(float* S, const float (&reg)[GemmCfg<TM>::GPT]) {
+template <bool KC, int TM, bool SQ = false>
+__device__ __forceinline__ void gemm_stage(float* S, const float (&reg)[GemmCfg<TM>::GPT], float* sq = nullptr) {
     using C = GemmCfg<TM>;
     const int tid = threadIdx.x;
 #pragma unroll
@@ -116,6 +121,7 @@ __device__ __forceinline__ void gemm_stage(float* S, const float (&reg)[GemmCfg<
         for (int x = 0; x < 4; ++x) {
             if (KC) S[((tid >> 3) + ps * 32) * LD_MN + (tid & 7) * 4 + x] = reg[ps * 4 + x];
             else S[((tid / C::MNQ) + ps * C::KSTEP) * C::LD_K + (tid % C::MNQ) * 4 + x] = reg[ps * 4 + x];
+            if constexpr (SQ) sq[ps] = fmaf(reg[ps * 4 + x], reg[ps * 4 + x], sq[ps]);   // row (tid >> 3) + 32 ps, this thread's k group
         }
     }
 }
@@ -144,8 +150,8 @@ __device__ __forceinline__ void gemm_fetch_raw(const P& p, float4 (&raw)[GemmCfg
     }
 }
 
-template <class P, bool IS_A, int TM, int NR>
-__device__ __forceinline__ void gemm_stage_raw(const P& p, float* S, const float4 (&raw)[GemmCfg<TM>::GPT / 4][NR], int base, int k0) {
+template <class P, bool IS_A, int TM, int NR, bool SQ = false>
+__device__ __forceinline__ void gemm_stage_raw(const P& p, float* S, const float4 (&raw)[GemmCfg<TM>::GPT / 4][NR], int base, int k0, float* sq = nullptr) {
     using C = GemmCfg<TM>;
     constexpr bool KC = IS_A ? P::A_KCONTIG : P::B_KCONTIG;
     const int tid = threadIdx.x;
@@ -159,6 +165,7 @@ __device__ __forceinline__ void gemm_stage_raw(const P& p, float* S, const float
         for (int x = 0; x < 4; ++x) {
             if (KC) S[((tid >> 3) + ps * 32) * LD_MN + (tid & 7) * 4 + x] = v[x];
             else S[((tid / C::MNQ) + ps * C::KSTEP) * C::LD_K + (tid % C::MNQ) * 4 + x] = v[x];
+            if constexpr (SQ) sq[ps] = fmaf(v[x], v[x], sq[ps]);
         }
     }
 }
@@ -236,6 +243,11 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     };
+    constexpr bool SQ = has_rowsq<P>::value;
+    static_assert(!SQ || (P::A_KCONTIG && P::B_KCONTIG), "row sums of squares ride the K-contiguous staging map");
+    float sqa[GPT / 4], sqb[GPT / 4];
+#pragma unroll
+    for (int ps = 0; ps < GPT / 4; ++ps) { sqa[ps] = 0.f; sqb[ps] = 0.f; }
     bool fast = false;
 #ifndef ADKF_GEMM_NO_RAW   // diagnostics: -DADKF_GEMM_NO_RAW sends every tile through the checked path (tools/ab_lib.py)
     if constexpr (has_raw<P>::value) {
@@ -245,8 +257,8 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
             gemm_fetch_raw<P, true, TM, P::A_NRAW>(p, qa, m0, 0);
             gemm_fetch_raw<P, false, TM, P::B_NRAW>(p, qb, n0, 0);
             for (int k0 = 0; k0 < K; k0 += GK) {
-                gemm_stage_raw<P, true, TM, P::A_NRAW>(p, As, qa, m0, k0);
-                gemm_stage_raw<P, false, TM, P::B_NRAW>(p, Bs, qb, n0, k0);
+                gemm_stage_raw<P, true, TM, P::A_NRAW, SQ>(p, As, qa, m0, k0, sqa);
+                gemm_stage_raw<P, false, TM, P::B_NRAW, SQ>(p, Bs, qb, n0, k0, sqb);
                 ADKF_GEMM_SYNC();
                 if (k0 + GK < K && !(ADKF_GEMM_ABLATE & 4)) {
                     gemm_fetch_raw<P, true, TM, P::A_NRAW>(p, qa, m0, k0 + GK);
@@ -264,8 +276,8 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
         gemm_fetch<P, true, TM>(p, ra, m0, 0, M, K);
         gemm_fetch<P, false, TM>(p, rb, n0, 0, N, K);
         for (int k0 = 0; k0 < K; k0 += GK) {
-            gemm_stage<P::A_KCONTIG, TM>(As, ra);
-            gemm_stage<P::B_KCONTIG, TM>(Bs, rb);
+            gemm_stage<P::A_KCONTIG, TM, SQ>(As, ra, sqa);
+            gemm_stage<P::B_KCONTIG, TM, SQ>(Bs, rb, sqb);
             __syncthreads();
             if (k0 + GK < K) {  // next chunk's loads fly while this chunk is multiplied
                 gemm_fetch<P, true, TM>(p, ra, m0, k0 + GK, M, K);
@@ -274,6 +286,20 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
             multiply_chunk();
             __syncthreads();
         }
+    }
+
+    if constexpr (SQ) {
+        // the eight threads that staged a row sit in eight adjacent lanes: three DPP steps, then one LDS hop to the epilogue's lanes
+        __shared__ float rowsq[2][TM];
+#pragma unroll
+        for (int ps = 0; ps < GPT / 4; ++ps) {
+            float a = sqa[ps], b = sqb[ps];
+            a += dpp_f<DPP_XOR1>(a); a += dpp_f<DPP_XOR2>(a); a += dpp_f<DPP_HALF_MIRROR>(a);
+            b += dpp_f<DPP_XOR1>(b); b += dpp_f<DPP_XOR2>(b); b += dpp_f<DPP_HALF_MIRROR>(b);
+            if ((tid & 7) == 0) { rowsq[0][(tid >> 3) + ps * 32] = a; rowsq[1][(tid >> 3) + ps * 32] = b; }
+        }
+        __syncthreads();
+        p.set_rowsq(&rowsq[0][0], &rowsq[1][0], m0, n0);
     }
 
     // ---- epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg ----

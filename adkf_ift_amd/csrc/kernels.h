@@ -26,33 +26,16 @@ __global__ __launch_bounds__(256) void k_colmean(const float* Zs, const int32_t*
     }
 }
 
-// ---- squared norms of the centred rows: one wave per row ----------------------------------------------
-__global__ __launch_bounds__(256) void k_rownorm(const float* Z, const int32_t* n_arr, int ld, int d, const float* mean, float* nrm, int T) {
-    const int t = blockIdx.y;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n = n_arr ? n_arr[t] : ld;
-    if (row >= ld) return;
-    const int lane = threadIdx.x & 63;
-    float s = 0.f;
-    if (row < n) {
-        const float* z = Z + ((size_t)t * ld + row) * d;
-        const float* mu = mean + (size_t)t * d;
-        for (int c = lane; c < d; c += 64) { const float v = z[c] - mu[c]; s += v * v; }
-    }
-    s = wave_sum(s);
-    if (lane == 0) nrm[(size_t)t * ld + row] = s;
-}
-
-// ---- K1: squared distances in GEMM form on the fp32 MFMA ----------------------------------------------
+// ---- K1: squared distances in GEMM form on the fp32 MFMA: D2_ij = |x_i|^2 + |y_j|^2 - 2 x_i . y_j on the centred rows ----
 struct ProbDist {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
     static constexpr int NRED = 0;
-    const float *X, *Y, *mean, *nx, *ny; const int32_t *n_x, *n_y; int x_ld, y_ld, d; bool symmetric; float* D2;
-    int mx, my; const float *Xi, *Yi, *mu, *nxi, *nyi; float* Do; bool vec;
+    const float *X, *Y, *mean; const int32_t *n_x, *n_y; int x_ld, y_ld, d; bool symmetric; float* D2;
+    int mx, my, i_base, j_base; const float *Xi, *Yi, *mu, *nxi, *nyi; float* Do; bool vec;
     __device__ bool setup(int t) {
         mx = n_x ? n_x[t] : x_ld; my = n_y ? n_y[t] : y_ld;
         Xi = X + (size_t)t * x_ld * d; Yi = Y + (size_t)t * y_ld * d; mu = mean + (size_t)t * d;
-        nxi = nx + (size_t)t * x_ld; nyi = ny + (size_t)t * y_ld; Do = D2 + (size_t)t * x_ld * y_ld;
+        nxi = nyi = nullptr; Do = D2 + (size_t)t * x_ld * y_ld;
         return mx > 0 && my > 0;
     }
     __device__ int M() const { return mx; } __device__ int N() const { return my; } __device__ int K() const { return d; }
@@ -71,8 +54,11 @@ struct ProbDist {
     // symmetric (X == Y): only the tiles on or above the diagonal are computed; they also write their mirror image, so
     // the result is EXACTLY symmetric
     __device__ bool active(int m0, int n0) const { return !symmetric || m0 <= n0; }
+    // squared norms of the centred rows: summed by the GEMM kernel itself while it stages the operands (gemm.h: set_rowsq),
+    // so no separate pass over Z and no norm arrays
+    __device__ void set_rowsq(const float* a, const float* b, int m0, int n0) { nxi = a; nyi = b; i_base = m0; j_base = n0; }
     __device__ float value(int i, int j, float acc) const {
-        const float v = fmaxf(nxi[i] + nyi[j] - 2.f * acc, 0.f);
+        const float v = fmaxf(nxi[i - i_base] + nyi[j - j_base] - 2.f * acc, 0.f);
         return (symmetric && i == j) ? 0.f : v;
     }
     __device__ void epi(int i, int j, float acc, float*) const {
@@ -123,6 +109,7 @@ struct ProbDistMulti {
     __device__ bool active(int m0, int n0) const { return q.active(m0, n0); }
     __device__ void epi(int i, int j, float acc, float* red) const { q.epi(i, j, acc, red); }
     __device__ void epi4(int i0, int j, const float (&acc)[4], float* red) const { q.epi4(i0, j, acc, red); }
+    __device__ void set_rowsq(const float* a, const float* b, int m0, int n0) { q.set_rowsq(a, b, m0, n0); }
     __device__ void store_red(int, const float*) const {}
 };
 

@@ -10,7 +10,7 @@ this module only wires it up:
                                    file; meant for a warm-up pass over a dataset's batch shapes, not for steady state
 
 The arithmetic is unchanged (float32 in, float32 accumulate): only which library kernel runs.  The file shipped in
-``tuning/gfx950_c3_gemm.csv`` holds the shapes of tools/bench_c3.py and is tied, by TunableOp's own validators, to this
+``tuning/gfx950_gemm.csv`` holds the shapes of tools/bench_c3.py and of bench.py (C2) and is tied, by TunableOp's own validators, to this
 image's hipBLASLt / rocBLAS build and to gfx950; on any other stack it is ignored and the default heuristic applies.
 The hand-written HIP path (libadkf_gp) is not affected."""
 from __future__ import annotations
@@ -20,7 +20,7 @@ from typing import Optional
 
 import torch
 
-SHIPPED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "gfx950_c3_gemm.csv")
+SHIPPED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "gfx950_gemm.csv")
 
 
 def use_tuned_gemms(results_file: Optional[str] = None, tune: bool = False) -> str:

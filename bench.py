@@ -53,6 +53,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--gemm-tuning", choices=("off", "shipped"), default="shipped",
+                    help="algorithm choice of the two library GEMMs of the theta = W feature map (adkf_ift_amd/gemm_tuning.py): "
+                         "hipBLASLt's heuristic, or the recorded choice for these shapes (same float32 arithmetic)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / collective rehearsal without a GPU: ranks rendezvous (gloo), all-reduce a dummy gradient, "
                          "time barriers and print a line with value null (tests/test_bench_launcher.py)")
@@ -158,6 +161,9 @@ def main():
         dist.barrier()
     else:
         ge.build()
+    if args.gemm_tuning == "shipped":
+        from adkf_ift_amd.gemm_tuning import use_tuned_gemms
+        use_tuned_gemms()
 
     T = args.global_tasks // world if args.global_tasks else args.tasks
     N, Nq, d, I = args.n_support, args.n_query, args.d, args.inner_evals
@@ -296,7 +302,8 @@ def main():
             "config": {"workload": f"{cfg_name}: {T} tasks/GPU/step, N_support={N}, N_query={Nq}, d={d}, kernel={args.kernel}, "
                                    f"inner fit = {'to convergence' if args.converge else f'exactly {I} MLL value+grad evals'}, "
                                    "IFT hypergradient, theta = W[d,d] linear feature map, Adam + clip 1.0",
-                       "tasks_per_gpu": T, "global_tasks": T * world, "parallelism": f"task-sharded dp{world}"},
+                       "tasks_per_gpu": T, "global_tasks": T * world, "parallelism": f"task-sharded dp{world}",
+                       "library_gemm_choice": args.gemm_tuning},
             "whole_path_tflops": value * fl["total"] / 1e12,
             "whole_path_frac_of_fp32_peak": value * fl["total"] / 1e12 / (roofline.PEAK_FP32_TFLOPS * world),
             # the frozen SURVEY 8d model prices the dZ GEMMs at 4d(N^2+N Nq+Nq^2); the kernels execute 2d(N+Nq)^2

@@ -133,6 +133,21 @@ def test_meta_step_with_device_fit(golden_dir, dev, name):
     W = tasks.W.clone().requires_grad_(True)
     feats = lambda: (tasks.X_s @ W / math.sqrt(d), tasks.X_q @ W / math.sqrt(d))
     losses, phi = meta_step(feats, [W], None, tasks.y_s, tasks.y_q, MetaStepConfig(gp_kernel="rbf", clip_value=1.0), check=True)
-    assert np.abs(phi.cpu().numpy() - g["phi"]).max() <= 5e-3
+    # Same optimum?  Judged on the OBJECTIVE, not on the distance in phi: along the flat lengthscale valley a 1e-3 relative
+    # move of l changes f_inner by less than a float32 ulp, so where exactly a float32 fit stops there depends on the rounding
+    # of its reductions (seen: |d phi_l| = 1e-3 and 1.6e-2 for the same f).  The device optimum must be at least as good as
+    # the reference's under the device's own evaluation, stationary to float32 resolution (test_fit_reaches_oracle_optimum
+    # explains the 5e-4), and in the same basin.
+    from adkf_ift_amd import gp_ops
+    with torch.no_grad():
+        Zs, _ = feats()
+    _, pri, _ = gp_ops.init_params(Zs)
+    b = gp_ops.GPBatch(Zs, tasks.y_s, pri, "rbf")
+    phi_ref = torch.tensor(g["phi"], dtype=torch.float32).to(dev)
+    f_dev, g_dev, _, _ = gp_ops.mll_value_grad(b, phi)
+    f_ref, _, _, _ = gp_ops.mll_value_grad(b, phi_ref)
+    assert (f_dev <= f_ref + 2e-7 * f_ref.abs() + 1e-7).all(), (f_dev, f_ref)
+    assert g_dev.abs().max().item() <= 5e-4
+    assert np.abs(phi.cpu().numpy() - g["phi"]).max() <= 5e-2
     assert rel(W.grad.cpu().numpy(), g["grad_clipped"]) <= 2e-3
     assert rel(losses.cpu().numpy() * N, g["f_out"]) <= 1e-3

@@ -18,7 +18,7 @@ int main() {
     hipMemcpy(Zs, h.data(), h.size() * 4, hipMemcpyHostToDevice); hipMemcpy(Zq, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMemset(mean, 0, (size_t)T * d * 4); hipMemset(nrm, 0, (size_t)T * n * 4);
     ProbDist p;
-    p.mean = mean; p.d = d; p.vec = true; p.nx = nrm; p.ny = nrm; p.n_x = nullptr; p.n_y = nullptr; p.x_ld = n; p.y_ld = n;
+    p.mean = mean; p.d = d; p.vec = true; p.n_x = nullptr; p.n_y = nullptr; p.x_ld = n; p.y_ld = n;
     ProbDistMulti pm;
     pm.vec = true;
     p.X = Zs; p.Y = Zs; p.symmetric = true; p.D2 = Dss; pm.s0 = p;
