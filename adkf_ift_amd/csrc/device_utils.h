@@ -164,6 +164,52 @@ __device__ __forceinline__ int block_sum_i(int v, int* red) {
     return s;
 }
 
+// CB consecutive floats of one matrix row starting at column j0, of which the first n columns exist: 16-byte accesses where
+// a group of four lies inside the row and `vec` says the row starts are 16-byte aligned (leading dimension a multiple of 4 on
+// an aligned base), element-wise otherwise.  A thread's register block of a matrix is RB such segments: 8 instead of 32
+// memory instructions per lane for the 4 x 8 blocks of the 128-point kernels.
+template <int CB>
+__device__ __forceinline__ void load_segment(const float* rowp, int j0, int n, bool row_ok, bool vec, float (&o)[CB]) {
+    if constexpr (CB % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < CB / 4; ++q) {
+            const int j = j0 + 4 * q;
+            if (vec && row_ok && j + 4 <= n) {
+                const float4 t = *reinterpret_cast<const float4*>(rowp + j);
+                o[4 * q] = t.x; o[4 * q + 1] = t.y; o[4 * q + 2] = t.z; o[4 * q + 3] = t.w;
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) o[4 * q + x] = (row_ok && j + x < n) ? rowp[j + x] : 0.f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CB; ++c) o[c] = (row_ok && j0 + c < n) ? rowp[j0 + c] : 0.f;
+    }
+}
+template <int CB>
+__device__ __forceinline__ void store_segment(float* rowp, int j0, int n, bool row_ok, bool vec, const float (&v)[CB]) {
+    if (!row_ok) return;
+    if constexpr (CB % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < CB / 4; ++q) {
+            const int j = j0 + 4 * q;
+            if (vec && j + 4 <= n) {
+                *reinterpret_cast<float4*>(rowp + j) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    if (j + x < n) rowp[j + x] = v[4 * q + x];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+            if (j0 + c < n) rowp[j0 + c] = v[c];
+    }
+}
+__device__ __forceinline__ bool rows_aligned16(const void* base, int ld) { return ((reinterpret_cast<uintptr_t>(base) & 15u) == 0) && (ld & 3) == 0; }
+
 // XCD-aware block -> (task, tile) map: consecutive block ids are dealt round-robin to the 8 XCDs, so all
 // tiles of task t, in every kernel of the pipeline, run on the XCD labelled (t & 7) and find the task's
 // matrices in that XCD's L2.  Speed only: any placement is correct.  Grid = roundup8(T) * tiles.

@@ -47,13 +47,12 @@ struct D2Block {
     static constexpr int RB = SW::RB, CB = SW::CB;
     float reg[RB][CB];
     __device__ __forceinline__ void init(const float* D2, int ld, int n) {
+        const bool vec = rows_aligned16(D2, ld);
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int c = 0; c < CB; ++c) {
-                const int i = SW::row(r), j = SW::col(c);
-                reg[r][c] = (i < n && j < n) ? D2[(size_t)i * ld + j] : 0.f;  // exactly symmetric by construction (ProbDist mirrors its tiles)
-            }
+        for (int r = 0; r < RB; ++r) {
+            const int i = SW::row(r);
+            load_segment<CB>(D2 + (size_t)i * ld, SW::col(0), n, i < n, vec, reg[r]);   // exactly symmetric by construction (ProbDist mirrors its tiles); 0 outside n x n
+        }
     }
     __device__ __forceinline__ float get(int r, int c) const { return reg[r][c]; }
 };
@@ -422,13 +421,15 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
         asm volatile("" : "+s"(t_late));
         asm volatile("" : "+v"(i_late));
         float* Ao = a.Ainv + (size_t)t_late * a.ld * a.ld;
+        const bool vec = rows_aligned16(Ao, a.ld);
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
+        for (int r = 0; r < RB; ++r) {
+            const int i = i_late + (SW::row(r) - SW::row(0));   // (a compile-time offset in every layout)
+            float neg[CB];
 #pragma unroll
-            for (int c = 0; c < CB; ++c) {
-                const int i = i_late + (SW::row(r) - SW::row(0)), j = j0 + c;   // (a compile-time offset in every layout)
-                if (i < n && j < n) Ao[(size_t)i * a.ld + j] = -m[r][c];
-            }
+            for (int c = 0; c < CB; ++c) neg[c] = -m[r][c];
+            store_segment<CB>(Ao + (size_t)i * a.ld, j0, n, i < n, vec, neg);
+        }
     }
 }
 

@@ -158,12 +158,13 @@ __global__ __launch_bounds__(NT) void k_median(const float* D2ss, const int32_t*
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
         const int e = r * NT + tid;
-        uint32_t val = 0u;   // entries are clamped >= 0: 0 marks "not a candidate"
-        if (e < slots) {
-            const int fr = e / nm1, c = e - fr * nm1, top = nm1 - fr;   // row fr holds `top` candidates, row n-1-fr holds fr
-            const int i = c < top ? fr : top, j = c < top ? fr + 1 + c : top + 1 + (c - top);
-            if (c < top || top != fr) val = D[(size_t)i * ld + j];       // odd n: the middle row is folded onto itself
-        }
+        // entries are clamped >= 0: 0 marks "not a candidate".  The load itself is unconditional (slot clamped into range, value
+        // discarded): a branch around it would give each of the EPT loads its own basic block and its own s_waitcnt
+        const int ec = e < slots ? e : slots - 1;
+        const int fr = ec / nm1, c = ec - fr * nm1, top = nm1 - fr;     // row fr holds `top` candidates, row n-1-fr holds fr
+        const int i = c < top ? fr : top, j = c < top ? fr + 1 + c : top + 1 + (c - top);
+        uint32_t val = D[(size_t)i * ld + j];
+        if (!(e < slots && (c < top || top != fr))) val = 0u;          // odd n: the middle row is folded onto itself
         v[r] = val;
         nonzero += __popcll(__ballot(val != 0u));
     }
@@ -263,16 +264,17 @@ __global__ __launch_bounds__(SMALL_NT) void k_hess(HessArgs a) {
             const float aj = al[j];
             float d2v[RF], av[RF];
 #pragma unroll
-            for (int q = 0; q < RF; ++q) {
-                const int i = i0 + q * NW;
-                d2v[q] = i < n ? D2[(size_t)i * ld + j] : 0.f;
-                av[q] = i < n ? Ai[(size_t)i * ld + j] : 0.f;
+            for (int q = 0; q < RF; ++q) {   // rows beyond n: clamped address, result discarded (no branch around a load)
+                const int i = i0 + q * NW, ic = i < n ? i : n - 1;
+                d2v[q] = D2[(size_t)ic * ld + j];
+                av[q] = Ai[(size_t)ic * ld + j];
             }
 #pragma unroll
             for (int q = 0; q < RF; ++q) {
                 float k0, k1, k2; const float u = d2v[q] * il2; kappa3(kind, u, k0, k1, k2);
-                sb[q] += os * k1 * u * (-2.f / ls) * aj;
-                sg[q] += av[q] * aj;
+                const bool in = i0 + q * NW < n;
+                sb[q] += in ? os * k1 * u * (-2.f / ls) * aj : 0.f;
+                sg[q] += in ? av[q] * aj : 0.f;
             }
         }
 #pragma unroll
@@ -291,11 +293,11 @@ __global__ __launch_bounds__(SMALL_NT) void k_hess(HessArgs a) {
         for (int q = 0; q < RF; ++q) sd[q] = 0.f;
         for (int j = lane; j < n; j += 64) {
             const float bj = be[j];
+            float av[RF];
 #pragma unroll
-            for (int q = 0; q < RF; ++q) {
-                const int i = i0 + q * NW;
-                if (i < n) sd[q] += Ai[(size_t)i * ld + j] * bj;
-            }
+            for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; av[q] = Ai[(size_t)(i < n ? i : n - 1) * ld + j]; }
+#pragma unroll
+            for (int q = 0; q < RF; ++q) sd[q] += (i0 + q * NW < n) ? av[q] * bj : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < RF; ++q) {
@@ -307,24 +309,40 @@ __global__ __launch_bounds__(SMALL_NT) void k_hess(HessArgs a) {
     __threadfence_block();
     __syncthreads();
     ADKF_SST(2);
-    // elementwise traces
+    // elementwise traces, by 32 x 32 tiles: thread (ty, tx) of tile (ib, jb) owns element (i, j) = (32 ib + ty, 32 jb + tx); the
+    // partner P_ji of tr(P P) comes from tile (jb, ib), loaded row-wise as well and turned through LDS (read straight from
+    // memory it is a column walk: 64 cache lines per wave instruction, the whole phase was 26 k cycles, 12 us).  At most
+    // 16 tiles (this kernel serves up to 128 points): every load of every tile is issued before the first is used, to
+    // clamped addresses where the tile sticks out of the matrix (no branch around a load), then one barrier per tile.
     float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // trA2, trPA, trPP, trAinvKll, aKlla, ag, bg, bd, ab
-    // four elements per thread per trip: their sixteen loads (one of them, P^T, strided) go out together
-    for (int e0 = tid; e0 < n * n; e0 += 4 * NT) {
-        float ai[4], pij[4], pji[4], d2v[4], aa[4];
+    {
+        constexpr int TS = 32, SIDE = 4, MAXT = SIDE * SIDE;
+        static_assert(NT == TS * TS, "one thread per tile element");
+        __shared__ float turn[2][TS][TS + 1];
+        const int ty = tid >> 5, tx = tid & 31, nside = (n + TS - 1) / TS;
+        float va[MAXT], vp[MAXT], vt[MAXT], vd[MAXT], vaa[MAXT];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = e0 + q * NT;
-            const bool in = e < n * n;
-            const int i = in ? e / n : 0, j = in ? e - i * n : 0;
-            ai[q] = in ? Ai[(size_t)i * ld + j] : 0.f; pij[q] = in ? Pi[(size_t)i * ld + j] : 0.f; pji[q] = in ? Pi[(size_t)j * ld + i] : 0.f;
-            d2v[q] = in ? D2[(size_t)i * ld + j] : 0.f; aa[q] = in ? al[i] * al[j] : 0.f;
+        for (int k = 0; k < MAXT; ++k) {
+            const int ib = k / SIDE, jb = k % SIDE;
+            const int i = min(ib * TS + ty, n - 1), j = min(jb * TS + tx, n - 1);      // my element
+            const int it = min(jb * TS + ty, n - 1), jt = min(ib * TS + tx, n - 1);    // my element of the partner tile
+            va[k] = Ai[(size_t)i * ld + j]; vp[k] = Pi[(size_t)i * ld + j]; vd[k] = D2[(size_t)i * ld + j];
+            vt[k] = Pi[(size_t)it * ld + jt];
+            vaa[k] = al[i] * al[j];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float k0, k1, k2; const float u = d2v[q] * il2; kappa3(kind, u, k0, k1, k2);
-            const float Kll = os * (k2 * 4.f * u * u + k1 * 6.f * u) * il2;
-            acc[0] += ai[q] * ai[q]; acc[1] += pij[q] * ai[q]; acc[2] += pij[q] * pji[q]; acc[3] += ai[q] * Kll; acc[4] += aa[q] * Kll;
+        for (int k = 0; k < MAXT; ++k) {
+            const int ib = k / SIDE, jb = k % SIDE;
+            if (ib < nside && jb < nside) {     // workgroup-uniform
+                turn[k & 1][ty][tx] = vt[k];    // = P[32 jb + ty][32 ib + tx]
+                __syncthreads();                // (one barrier per tile: buffer k & 1 was last read before the previous barrier)
+                const float pji = turn[k & 1][tx][ty];   // = P[32 jb + tx][32 ib + ty] = P_ji; bank (tx + ty) mod 32: conflict-free
+                if (ib * TS + ty < n && jb * TS + tx < n) {
+                    float k0, k1, k2; const float u = vd[k] * il2; kappa3(kind, u, k0, k1, k2);
+                    const float Kll = os * (k2 * 4.f * u * u + k1 * 6.f * u) * il2;
+                    acc[0] += va[k] * va[k]; acc[1] += vp[k] * va[k]; acc[2] += vp[k] * pji; acc[3] += va[k] * Kll; acc[4] += vaa[k] * Kll;
+                }
+            }
         }
     }
     if (tid < n) { acc[5] = al[tid] * ga[tid]; acc[6] = be[tid] * ga[tid]; acc[7] = be[tid] * de[tid]; acc[8] = al[tid] * be[tid]; }
@@ -388,16 +406,19 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
     const int j0 = SW::bc() * CB;
     if (tid < NMAX) sm.vec_in[tid] = 0.f;
     __syncthreads();
+    ADKF_SST(0);
     // this thread's block of S (exactly symmetric by construction), identity-padded: the loads are issued first and
     // land while the residual below is formed
     float mm[RB][CB];
+    const bool s_vec = rows_aligned16(Si, a.tv.nq_ld);
 #pragma unroll
-    for (int r = 0; r < RB; ++r)
+    for (int r = 0; r < RB; ++r) {
+        const int i = SW::row(r);
+        load_segment<CB>(Si + (size_t)i * a.tv.nq_ld, j0, m, i < m, s_vec, mm[r]);   // ProbS mirrors its tiles
 #pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            const int i = SW::row(r), j = j0 + c;
-            mm[r][c] = (i < m && j < m) ? Si[(size_t)i * a.tv.nq_ld + j] : (i == j ? 1.f : 0.f);   // ProbS mirrors its tiles
-        }
+        for (int c = 0; c < CB; ++c)
+            if (i == j0 + c && i >= m) mm[r][c] = 1.f;                                 // identity padding
+    }
     // residual r = y_q - C y_s  (wave per row; ALL of a wave's rows in flight at once: a row at a time is a chain of L2
     // round trips - 17 us at 128 x 128, measured; four at a time left four trips)
     {
@@ -405,13 +426,15 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
         float s[RW];
 #pragma unroll
         for (int u = 0; u < RW; ++u) s[u] = 0.f;
-        for (int j = lane; j < n; j += 64) {
+        for (int j = lane; j < (m > 0 ? n : 0); j += 64) {
             const float yj = ys[j];
+            // (rows beyond m: the load goes to row m - 1 and is discarded - a wave-uniform branch per row would put every
+            // load in its own basic block with its own s_waitcnt: 32 serial round trips instead of 2, measured 22 k cycles)
+            float cv[RW];
 #pragma unroll
-            for (int u = 0; u < RW; ++u) {
-                const int i = wv + u * NW;
-                if (i < m) s[u] += Ci[(size_t)i * a.tv.ns_ld + j] * yj;
-            }
+            for (int u = 0; u < RW; ++u) { const int i = wv + u * NW; cv[u] = Ci[(size_t)(i < m ? i : m - 1) * a.tv.ns_ld + j]; }
+#pragma unroll
+            for (int u = 0; u < RW; ++u) { const int i = wv + u * NW; s[u] += i < m ? cv[u] * yj : 0.f; }
         }
 #pragma unroll
         for (int u = 0; u < RW; ++u) {
@@ -421,12 +444,16 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
         }
     }
     __syncthreads();
+    ADKF_SST(1);
     SW::run(mm, m, sm);
+    ADKF_SST(2);
     float logdet;
     const int info = SW::finish(m, sm, logdet);
     const float pivr = pivot_ratio<NT>(sm.pivs, m, sm.red);
+    ADKF_SST(3);
     if (tid == 0) a.scal[(size_t)t * NSCAL + S_PIVR_S] = pivr;
     SW::solve(mm, sm.vec_in, sm.vec_out);  // e = S^-1 r
+    ADKF_SST(4);
     float q[1] = {0.f};
     if (tid < m) {
         const float e = sm.vec_out[tid], r = sm.vec_in[tid];
@@ -435,13 +462,16 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
         q[0] = r * e;
     }
     block_sum<1, NT>(q, sm.red);
+    ADKF_SST(5);
 #pragma unroll
-    for (int r = 0; r < RB; ++r)
+    for (int r = 0; r < RB; ++r) {
+        const int i = SW::row(r);
+        float neg[CB];
 #pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            const int i = SW::row(r), j = j0 + c;
-            if (i < m && j < m) Si[(size_t)i * a.tv.nq_ld + j] = -mm[r][c];
-        }
+        for (int c = 0; c < CB; ++c) neg[c] = -mm[r][c];
+        store_segment<CB>(Si + (size_t)i * a.tv.nq_ld, j0, m, i < m, s_vec, neg);
+    }
+    ADKF_SST(6);
     // Cte_j = sum_i C_ij e_i  (thread per column: coalesced; the rows are split over PARTS thread groups so that every
     // thread works and a column is PARTS short chains of loads instead of one long one: 12 -> 4 dependent round trips
     // at 128 x 128)
@@ -453,9 +483,16 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
         const int per = (m + PARTS - 1) / PARTS, i_lo = part * per, i_hi = min(m, i_lo + per);
         for (int jb = 0; jb < n; jb += COLS) {   // n is the SUPPORT count: it may exceed NMAX (which follows the query count)
             const int j = jb + jl;
-            float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // eight loads in flight
+            float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (j < n) {
                 int i = i_lo;
+                for (; i + 32 <= i_hi; i += 32) {   // a part of 32 rows (128 points, four parts) is ONE round of loads
+                    float cv[32];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) cv[u] = Ci[(size_t)(i + u) * a.tv.ns_ld + j];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) s8[u & 7] += cv[u] * sm.vec_out[i + u];
+                }
                 for (; i + 8 <= i_hi; i += 8) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) s8[u] += Ci[(size_t)(i + u) * a.tv.ns_ld + j] * sm.vec_out[i + u];
@@ -478,6 +515,7 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
             }
         }
     }
+    ADKF_SST(7);
     if (tid == 0) {
         const float f = 0.5f * q[0] + 0.5f * logdet + 0.5f * (float)m * LOG_2PI;
         a.scal[(size_t)t * NSCAL + S_FOUT] = f;
@@ -590,10 +628,9 @@ __global__ __launch_bounds__(SMALL_NT) void k_wqq(WqqArgs a) {
         float sv[4], dv[4], ee[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int e = e0 + q * NT;
-            const bool in = e < m * m;
-            const int i = in ? e / m : 0, j = in ? e - i * m : 0;
-            sv[q] = in ? Si[(size_t)i * ld + j] : 0.f; dv[q] = in ? D2[(size_t)i * ld + j] : 0.f; ee[q] = in ? ev[i] * ev[j] : 0.f;
+            const int e = min(e0 + q * NT, m * m - 1);   // clamped: no branch around the loads (the tail is skipped below)
+            const int i = e / m, j = e - i * m;
+            sv[q] = Si[(size_t)i * ld + j]; dv[q] = D2[(size_t)i * ld + j]; ee[q] = ev[i] * ev[j];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -641,7 +678,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_rowsums(RowsumArgs a) {
             for (int i0 = wv; i0 < m; i0 += RF * NW) {
                 float v[RF];
 #pragma unroll
-                for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; v[q] = i < m ? Wqs[(size_t)i * a.tv.ns_ld + j] : 0.f; }
+                for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; v[q] = Wqs[(size_t)(i < m ? i : m - 1) * a.tv.ns_ld + j]; if (i >= m) v[q] = 0.f; }
 #pragma unroll
                 for (int q = 0; q < RF; ++q) s += v[q];
             }
@@ -654,8 +691,11 @@ __global__ __launch_bounds__(SMALL_NT) void k_rowsums(RowsumArgs a) {
 #pragma unroll
         for (int q = 0; q < RF; ++q) s[q] = 0.f;
         for (int j = lane; j < n; j += 64) {
+            float v[RF];
 #pragma unroll
-            for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; if (i < n) s[q] += Wss[(size_t)i * a.tv.ns_ld + j]; }
+            for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; v[q] = Wss[(size_t)(i < n ? i : n - 1) * a.tv.ns_ld + j]; }   // clamped, discarded below
+#pragma unroll
+            for (int q = 0; q < RF; ++q) s[q] += (i0 + q * NW < n) ? v[q] : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < RF; ++q) {
@@ -675,12 +715,18 @@ __global__ __launch_bounds__(SMALL_NT) void k_rowsums(RowsumArgs a) {
 #pragma unroll
             for (int q = 0; q < RF; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
             for (int j = lane; j < n; j += 64) {
+                float v[RF];
 #pragma unroll
-                for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; if (i < m) s1[q] += Wqs[(size_t)i * a.tv.ns_ld + j]; }
+                for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; v[q] = Wqs[(size_t)(i < m ? i : m - 1) * a.tv.ns_ld + j]; }
+#pragma unroll
+                for (int q = 0; q < RF; ++q) s1[q] += (i0 + q * NW < m) ? v[q] : 0.f;
             }
             for (int j = lane; j < m; j += 64) {
+                float v[RF];
 #pragma unroll
-                for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; if (i < m) s2[q] += Wqq[(size_t)i * a.tv.nq_ld + j]; }
+                for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; v[q] = Wqq[(size_t)(i < m ? i : m - 1) * a.tv.nq_ld + j]; }
+#pragma unroll
+                for (int q = 0; q < RF; ++q) s2[q] += (i0 + q * NW < m) ? v[q] : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < RF; ++q) {

@@ -37,7 +37,33 @@ int main() {
 #if ADKF_STAMP_SMALL
     unsigned long long st[16];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_small_stamps), sizeof(st));
-    for (int k = 1; k <= 4; ++k) printf("phase %d: %llu cycles (100 MHz ticks x?)\n", k, st[k] - st[k - 1]);
+    for (int k = 1; k <= 4; ++k) printf("k_hess phase %d: %llu cycles\n", k, st[k] - st[k - 1]);
 #endif
+    {   // k_outer_factor on the same buffers (S = D2 + 200 I is diagonally dominant: a valid sweep)
+        std::vector<float> hs(h);
+        for (int t = 0; t < T; ++t) for (int i = 0; i < n; ++i) { for (int j = 0; j < n; ++j) { float& v = hs[((size_t)t * n + i) * n + j]; v = 0.5f * (v + h[((size_t)t * n + j) * n + i]); } }
+        for (int t = 0; t < T; ++t) for (int i = 0; i < n; ++i) hs[((size_t)t * n + i) * n + i] += 200.f;
+        float* fo; int32_t* info;
+        hipMalloc(&fo, T * 4); hipMalloc(&info, T * 4); hipMemset(info, 0, T * 4);
+        OuterArgs oa{a.tv, Ainv, D2, ys, ys, vecs, scal, fo, info, T, 1};
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0);
+            for (int i = 0; i < 20; ++i) { hipMemcpyAsync(D2, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, 0); k_outer_factor<128, 512><<<T, 512>>>(oa); }
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+        }
+        hipMemcpy(D2, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
+        hipEventRecord(e0);
+        k_outer_factor<128, 512><<<T, 512>>>(oa);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("k_outer_factor %.2f us (single launch)\n", ms * 1000);
+#if ADKF_STAMP_SMALL
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(g_small_stamps), sizeof(st));
+        const char* nm[] = {"", "S loads + residual", "sweep", "finish + pivot ratio", "solve", "block_sum", "store S^-1", "C^T e"};
+        for (int k = 1; k <= 7; ++k) printf("k_outer_factor %-22s %llu cycles\n", nm[k], st[k] - st[k - 1]);
+#endif
+    }
     return 0;
 }
