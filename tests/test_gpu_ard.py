@@ -64,11 +64,12 @@ def test_ard_golden_cases(golden_dir, dev, pad):
             if k == "g_in":   # vanishes at a fitted point: measure against the O(1e-2) scale of an unfitted gradient
                 e = np.abs(np.asarray(v, dtype=np.float64) - z[k]).max() / max(np.abs(z[k]).max(), 1e-2)
             worst[k] = max(worst.get(k, 0.0), e)
-            # (round 1 allowed 1e-3 on v and 2.5e-4 on the unfitted dL/dZ_s; the observed worst is now 5e-5: everything at 1e-4)
-            # v solves the (2 + d)-dimensional Hessian system by CG: it carries cond(H) times the rounding of g_out and of the
-            # Hessian-vector products, and sits at 0.5e-4 .. 1.1e-4 depending on the summation order inside the distance
-            # kernel; the quantities computed FROM it (dZ totals) stay inside 1e-4
-            tol = 2 * TOL if k == "v" else TOL
+            # v = H^-1 g_out in float32 cannot be better than eps32 cond(H): H has 2 + d rows here and cond(H) = 1.6e3 for the
+            # 128-point fixture (10 .. 25 for the others), where the v-dependent term is 88 % of dL/dZ_s.  Those two outputs are
+            # held to max(1e-4, 4 eps32 cond(H)) with cond(H) taken from the fixture's own dense Hessian (3.9e-4 for that
+            # fixture, 1e-4 for the rest; observed 1.0e-4 .. 1.1e-4 depending on the summation order of the distance kernel);
+            # everything else to 1e-4.
+            tol = max(TOL, 4 * 6e-8 * float(np.linalg.cond(z["H"]))) if k in ("v", "dZs_total") else TOL
             assert e <= tol, (os.path.basename(f), k, e, int(out["cg_iters"][0]))
         if pad[0]:
             assert float(out["dZ_s"][0, n:].abs().max()) == 0.0 and float(out["dZ_q"][0, m:].abs().max()) == 0.0
