@@ -90,6 +90,42 @@ __device__ __forceinline__ void inner_finalize(int n, const float* x, const floa
     extra[6] = gt0; extra[7] = gt1; extra[8] = gt2;
 }
 
+// The same, called by ALL 64 lanes of one wave: the transcendental work per raw parameter (softplus, sigmoid, the log-normal
+// prior term: ~10 dependent libm calls when one lane does all three) runs on three lanes side by side and is gathered with
+// readlane.  Same functions, same order of the two prior terms: the results are bit-identical to inner_finalize.
+__device__ __forceinline__ void inner_finalize_wave(int n, const float* x, const float* pri, float logdet, const float* acc,
+                                                    float& f, float* g, float* extra) {
+    const int lane = threadIdx.x & 63;
+    const float xq = lane == 0 ? x[0] : (lane == 1 ? x[1] : x[2]);
+    const float tq = softplus_f(xq) + (lane == 0 ? NOISE_LB : 0.f);          // noise | outputscale | lengthscale
+    const float dq = sigmoid_f(xq);
+    const float pm = lane == 0 ? pri[0] : pri[2], ps = lane == 0 ? pri[1] : (lane == 2 ? pri[3] : -1.f);   // no prior on the outputscale
+    float lpq = 0.f, dpq = 0.f;
+    if (ps > 0.f) {
+        const float lx = logf(tq), z = (lx - pm) / (ps * ps);
+        lpq = -lx - logf(ps) - 0.5f * LOG_2PI - 0.5f * (lx - pm) * z;
+        dpq = (-1.f - z) / tq;
+    }
+    auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+    const float noise = rl(tq, 0), os = rl(tq, 1);
+    const float d1n = rl(dq, 0), d1s = rl(dq, 1), d1l = rl(dq, 2);
+    float lp = 0.f;
+    lp += rl(lpq, 0); lp += rl(lpq, 2);
+    const float dpn = rl(dpq, 0), dpl = rl(dpq, 2);
+    const float trAinvG = acc[0], aGa = acc[1], trAinv = acc[2], aa = acc[3], ya = acc[4];
+    const float fn = (float)n;
+    const float nll = 0.5f * ya + 0.5f * logdet + 0.5f * fn * LOG_2PI;
+    f = (nll - lp) / fn;
+    const float gt0 = 0.5f * trAinv - 0.5f * aa - dpn;
+    const float gt1 = (0.5f * (fn - noise * trAinv) - 0.5f * (ya - noise * aa)) / os;
+    const float gt2 = 0.5f * trAinvG - 0.5f * aGa - dpl;
+    g[0] = gt0 * d1n / fn;
+    g[1] = gt1 * d1s / fn;
+    g[2] = gt2 * d1l / fn;
+    extra[0] = logdet; extra[1] = trAinv; extra[2] = aa; extra[3] = ya; extra[4] = trAinvG; extra[5] = aGa;
+    extra[6] = gt0; extra[7] = gt1; extra[8] = gt2;
+}
+
 template <int NMAX, int NT, int KIND>
 struct InnerEval {
     using D2 = D2Block<NMAX, NT>;
@@ -109,6 +145,43 @@ struct InnerEval {
         ADKF_ES(0);
         const float noise = tr[0], os = tr[1], ls = tr[2];   // softplus of x, computed once per trial point (FitShared)
         const float il2 = 1.f / (ls * ls), gl = -2.f / ls;
+        if (fast) {
+            // Search evaluations: exp as ONE v_exp_f32 of a pre-scaled argument (RBF: d2 * (-log2(e) / (2 l^2)); Matern: -sqrt(5)
+            // log2(e) r): 1 ulp of the hardware exp2 plus the rounding of its argument (relative 2^-24 |arg|, i.e. below 2e-6 even
+            // where the kernel value is 1e-9) - the noise level of the float32 matrix entries themselves - and no range checks when
+            // the task fills the block (every C2 task).  The reported evaluation (fast == false) takes the loop with libm's expf
+            // below.  RBF: 6 instead of 22 VALU instructions per element; the loop was 8 % of an evaluation (5.7 k -> 1.4 k cycles).
+            const bool full = n == NMAX;   // workgroup-uniform
+            const float ce = -0.72134752044448170368f * il2, ck = -0.5f * il2;   // RBF: -log2(e) / (2 l^2);  kappa'(u) u = k0 d2 ck
+            const float cm = -3.2259784787f;                                        // Matern: -sqrt(5) log2(e)
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int i = SW::row(r), dc = i - j0;   // the diagonal sits at column offset dc, if 0 <= dc < CB
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    if (c % 4 == 0) __builtin_amdgcn_sched_barrier(0);   // four exponentials in flight at a time: keeps the pressure of this loop out of the sweep's allocation
+                    const float d2v = d2.get(r, c);
+                    float k0, k1u;
+                    if (KIND == 0) {
+                        k0 = __builtin_amdgcn_exp2f(d2v * ce);
+                        k1u = k0 * (d2v * ck);
+                    } else {
+                        const float u = d2v * il2, sr = SQRT5 * __builtin_amdgcn_sqrtf(u);
+                        const float e = __builtin_amdgcn_exp2f(sr * (cm / SQRT5));
+                        k0 = (1.f + sr + (5.f / 3.f) * u) * e;
+                        k1u = -(5.f / 6.f) * (1.f + sr) * e * u;
+                    }
+                    float mv = fmaf(os, k0, dc == c ? noise : 0.f);
+                    if (!full) {
+                        const bool in = i < n && j0 + c < n;
+                        mv = in ? mv : (dc == c ? 1.f : 0.f);
+                        k1u = in ? k1u : 0.f;
+                    }
+                    m[r][c] = mv;
+                    cache[(r * CB + c) * NT + tid] = k1u;   // lane-private slots, conflict-free
+                }
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
 #pragma unroll
@@ -167,7 +240,7 @@ struct InnerEval {
         int info = 0;
         if (acc[6] > 0.f) info = SW::finish(n, sm, logdet);   // rare: locate the first non-positive pivot (uniform branch)
         if (tid >= 64) { f = 0.f; return info; }   // the scalar epilogue is consumed by lane 0 only: one wave computes it
-        inner_finalize(n, x, pri, logdet, acc, f, g, extra);
+        inner_finalize_wave(n, x, pri, logdet, acc, f, g, extra);
         ADKF_ES(7);
         if (info != 0 || !(f == f)) {
             f = INFINITY;
@@ -266,7 +339,7 @@ struct FitShared {
 enum { PH_INIT = 0, PH_SEARCH, PH_BURN, PH_FINAL };
 
 // Consumes the evaluation (fe, ge, ie) made at fs.xe and decides what is evaluated next (lane 0 only).
-__device__ __forceinline__ void fit_advance(FitShared& fs, const InnerArgs& a, float fe, const float* ge, int ie) {
+__device__ __forceinline__ void fit_advance(FitShared& fs, const InnerArgs& a, float fe, const float* ge, int ie, bool transforms = true) {
     Bfgs& st = fs.st;
     const int budget = a.max_evals - 1;  // the last evaluation is the output evaluation
     int phase = fs.phase;
@@ -306,7 +379,7 @@ __device__ __forceinline__ void fit_advance(FitShared& fs, const InnerArgs& a, f
     } else {
         st.trial(fs.xe);
     }
-    fs.set_transforms();
+    if (transforms) fs.set_transforms();   // (k_inner computes the three softplus on three lanes instead)
     fs.phase = phase;
 }
 
@@ -378,7 +451,11 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
         const float tr[3] = {fs.tr[0], fs.tr[1], fs.tr[2]};
         const int ie = EV::run(sm, d2, m, n, xe, tr, pri, fe, ge, extra, phase != PH_FINAL, inner_cache);
         if (phase == PH_FINAL) { info = ie; evals = fs.evals + 1; break; }
-        if (tid == 0) fit_advance(fs, a, fe, ge, ie);
+        if (tid < 64) {   // wave 0: lane 0 moves the state machine, then lanes 0..2 transform one raw parameter each
+            if (tid == 0) fit_advance(fs, a, fe, ge, ie, false);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (LDS runs one wave's instructions in order: only the compiler needs telling)
+            if (tid < 3) fs.tr[tid] = softplus_f(fs.xe[tid]) + (tid == 0 ? NOISE_LB : 0.f);
+        }
         __syncthreads();
     }
     const float f = fe;

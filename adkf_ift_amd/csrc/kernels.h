@@ -320,27 +320,31 @@ __global__ __launch_bounds__(SMALL_NT) void k_hess(HessArgs a) {
         static_assert(NT == TS * TS, "one thread per tile element");
         __shared__ float turn[2][TS][TS + 1];
         const int ty = tid >> 5, tx = tid & 31, nside = (n + TS - 1) / TS;
-        float va[MAXT], vp[MAXT], vt[MAXT], vd[MAXT], vaa[MAXT];
+        constexpr int HALF = MAXT / 4;   // four rounds of four tiles: 20 values in flight per thread (a 1024-thread workgroup has 128 registers per lane)
 #pragma unroll
-        for (int k = 0; k < MAXT; ++k) {
-            const int ib = k / SIDE, jb = k % SIDE;
-            const int i = min(ib * TS + ty, n - 1), j = min(jb * TS + tx, n - 1);      // my element
-            const int it = min(jb * TS + ty, n - 1), jt = min(ib * TS + tx, n - 1);    // my element of the partner tile
-            va[k] = Ai[(size_t)i * ld + j]; vp[k] = Pi[(size_t)i * ld + j]; vd[k] = D2[(size_t)i * ld + j];
-            vt[k] = Pi[(size_t)it * ld + jt];
-            vaa[k] = al[i] * al[j];
-        }
+        for (int h = 0; h < 4; ++h) {
+            float va[HALF], vp[HALF], vt[HALF], vd[HALF], vaa[HALF];
 #pragma unroll
-        for (int k = 0; k < MAXT; ++k) {
-            const int ib = k / SIDE, jb = k % SIDE;
-            if (ib < nside && jb < nside) {     // workgroup-uniform
-                turn[k & 1][ty][tx] = vt[k];    // = P[32 jb + ty][32 ib + tx]
-                __syncthreads();                // (one barrier per tile: buffer k & 1 was last read before the previous barrier)
-                const float pji = turn[k & 1][tx][ty];   // = P[32 jb + tx][32 ib + ty] = P_ji; bank (tx + ty) mod 32: conflict-free
-                if (ib * TS + ty < n && jb * TS + tx < n) {
-                    float k0, k1, k2; const float u = vd[k] * il2; kappa3(kind, u, k0, k1, k2);
-                    const float Kll = os * (k2 * 4.f * u * u + k1 * 6.f * u) * il2;
-                    acc[0] += va[k] * va[k]; acc[1] += vp[k] * va[k]; acc[2] += vp[k] * pji; acc[3] += va[k] * Kll; acc[4] += vaa[k] * Kll;
+            for (int kk = 0; kk < HALF; ++kk) {
+                const int k = h * HALF + kk, ib = k / SIDE, jb = k % SIDE;
+                const int i = min(ib * TS + ty, n - 1), j = min(jb * TS + tx, n - 1);      // my element
+                const int it = min(jb * TS + ty, n - 1), jt = min(ib * TS + tx, n - 1);    // my element of the partner tile
+                va[kk] = Ai[(size_t)i * ld + j]; vp[kk] = Pi[(size_t)i * ld + j]; vd[kk] = D2[(size_t)i * ld + j];
+                vt[kk] = Pi[(size_t)it * ld + jt];
+                vaa[kk] = al[i] * al[j];
+            }
+#pragma unroll
+            for (int kk = 0; kk < HALF; ++kk) {
+                const int k = h * HALF + kk, ib = k / SIDE, jb = k % SIDE;
+                if (ib < nside && jb < nside) {     // workgroup-uniform
+                    turn[k & 1][ty][tx] = vt[kk];   // = P[32 jb + ty][32 ib + tx]
+                    __syncthreads();                // (one barrier per tile: buffer k & 1 was last read before the previous barrier)
+                    const float pji = turn[k & 1][tx][ty];   // = P[32 jb + tx][32 ib + ty] = P_ji; bank (tx + ty) mod 32: conflict-free
+                    if (ib * TS + ty < n && jb * TS + tx < n) {
+                        float k0, k1, k2; const float u = vd[kk] * il2; kappa3(kind, u, k0, k1, k2);
+                        const float Kll = os * (k2 * 4.f * u * u + k1 * 6.f * u) * il2;
+                        acc[0] += va[kk] * va[kk]; acc[1] += vp[kk] * va[kk]; acc[2] += vp[kk] * pji; acc[3] += va[kk] * Kll; acc[4] += vaa[kk] * Kll;
+                    }
                 }
             }
         }
