@@ -141,12 +141,27 @@ __device__ __forceinline__ void block_sum(float (&v)[K], float* red) {
         for (int q = 0; q < K; ++q) red[q * NW + w] = v[q];
     }
     __syncthreads();
+    // every thread sums the NW partials of each value, in wave order; they are fetched with 16-byte LDS reads when `red` allows
+    // (K * NW dword reads by every lane were the larger part of this function: 56 at <7, 512>, 144 at <9, 1024>)
+    if (NW % 4 == 0 && (reinterpret_cast<uintptr_t>(red) & 15u) == 0) {
 #pragma unroll
-    for (int q = 0; q < K; ++q) {
-        float s = 0.f;
+        for (int q = 0; q < K; ++q) {
+            float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) s += red[q * NW + i];
-        v[q] = s;
+            for (int i = 0; i < NW / 4; ++i) {
+                const float4 t = reinterpret_cast<const float4*>(red + q * NW)[i];
+                s += t.x; s += t.y; s += t.z; s += t.w;
+            }
+            v[q] = s;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) s += red[q * NW + i];
+            v[q] = s;
+        }
     }
 }
 

@@ -1,11 +1,11 @@
-# end-of-round evidence (run through gpurun): GPU tests, bench lines at the BASELINE configurations, profiles
+# end-of-round evidence, first half (run through gpurun; tools/round_end2.sh is the second): GPU tests, bench lines at the BASELINE configurations
 python -m pytest tests -m gpu -x -q > gpurun_out/r02_gpu_tests.log 2>&1; echo "gpu tests rc $?"; tail -2 gpurun_out/r02_gpu_tests.log
 python bench.py > gpurun_out/r02_bench_c2.json 2> gpurun_out/r02_bench.err; echo "bench rc $?"
 for T in 64 128 512; do python bench.py --steps 20 --warmup 5 --tasks $T --no-cpu-baseline --no-parity > gpurun_out/r02_bench_T$T.json 2>> gpurun_out/r02_bench.err; done
 python bench.py --steps 20 --warmup 5 --tasks 64 --n-support 32 --n-query 32 --d 64 --no-cpu-baseline > gpurun_out/r02_bench_c1.json 2>> gpurun_out/r02_bench.err
 python bench.py --steps 10 --warmup 3 --tasks 8 --n-support 1024 --n-query 1024 --d 512 --no-cpu-baseline --converge-steps 0 > gpurun_out/r02_bench_c5.json 2>> gpurun_out/r02_bench.err
 ADKF_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-parity --converge-steps 0 > gpurun_out/r02_bench_gloo2.json 2>> gpurun_out/r02_bench.err; echo "gloo2 rc $?"
-ADKF_BENCH_BACKEND=gloo python bench.py --gpus 2 --global-tasks 512 --steps 10 --warmup 3 --no-cpu-baseline --no-parity --converge-steps 0 > gpurun_out/r02_bench_gloo2_strong.json 2>> gpurun_out/r02_bench.err
-python tools/bench_c3.py --steps 5 --warmup 2 > gpurun_out/r02_bench_c3.json 2>> gpurun_out/r02_bench.err
-bash tools/profile_round.sh > /dev/null 2>&1
-for f in c2 T64 T128 T512 c1 c5 gloo2 gloo2_strong c3; do echo "== $f"; tail -1 gpurun_out/r02_bench_$f.json | cut -c1-420; done
+
+
+
+for f in c2 T64 T128 T512 c1 c5 gloo2; do echo "== $f"; tail -1 gpurun_out/r02_bench_$f.json | cut -c1-420; done
