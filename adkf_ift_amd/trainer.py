@@ -31,7 +31,10 @@ class MetaStepConfig:
     inner_gtol: float = 1e-5
     inner_ftol: float = 2.22e-9            # SciPy L-BFGS-B default (factr * eps): on an fp32 objective "no decrease at all"
     uneven_shards: bool = False            # ranks hold different numbers of tasks (node-balanced shards): the global
-                                           # task count rides in the gradient all-reduce
+                                           # task count rides in the gradient all-reduce (one host sync per step to read it)
+    global_tasks: Optional[int] = None     # ... unless the caller states it: every rank computes the same shard plan
+                                           # (meta_batch.shard_tasks_by_nodes is deterministic), so the total is known up
+                                           # front and the step stays free of host synchronisation
 
 
 class HipGPBackend:
@@ -247,7 +250,10 @@ def meta_step(features_fn: Callable[[], Tuple[torch.Tensor, torch.Tensor]], para
     else:
         torch.autograd.backward([Z_s, Z_q], [dZ_s.to(Z_s.dtype), dZ_q.to(Z_q.dtype)])
     if distributed and world > 1:
-        if cfg.uneven_shards:
+        if cfg.global_tasks is not None:
+            allreduce_flat_grads(params)
+            T_global = int(cfg.global_tasks)
+        elif cfg.uneven_shards:
             T_global = allreduce_flat_grads(params, local_tasks=T_local)   # host reads the count: one sync per step
         else:
             allreduce_flat_grads(params)

@@ -37,7 +37,7 @@ class OracleBackend:
         return torch.stack(phis), torch.tensor(f), torch.stack(ds), torch.stack(dq), zero, zero
 
 
-def _run_rank(rank, world, port, fixture, ret, split=None):
+def _run_rank(rank, world, port, fixture, ret, split=None, stated_total=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -51,7 +51,8 @@ def _run_rank(rank, world, port, fixture, ret, split=None):
     tasks = make_tasks(cnt, N, d, first_task=500 + lo)
     W = tasks.W.double().clone().requires_grad_(True)
     opt = torch.optim.SGD([W], lr=0.5)
-    cfg = MetaStepConfig(gp_kernel="rbf" if kind == 0 else "matern", clip_value=1.0, uneven_shards=split is not None)
+    cfg = MetaStepConfig(gp_kernel="rbf" if kind == 0 else "matern", clip_value=1.0,
+                         uneven_shards=split is not None and stated_total is None, global_tasks=stated_total)
     Xs, Xq = tasks.X_s.double(), tasks.X_q.double()
     feats = lambda: (Xs @ W / math.sqrt(d), Xq @ W / math.sqrt(d))
     W0 = W.detach().clone()
@@ -89,14 +90,16 @@ def test_meta_step_matches_reference_loop(golden_dir, world):
         assert np.abs(ret[r]["phi"] - g["phi"][sl]).max() <= 1e-5
 
 
-def test_uneven_shards_divide_by_the_global_task_count(golden_dir):
+@pytest.mark.parametrize("stated_total", [None, 4])
+def test_uneven_shards_divide_by_the_global_task_count(golden_dir, stated_total):
     """3 + 1 tasks on two ranks (what node-balanced sharding produces): the task count rides in the gradient
-    all-reduce and the result is still the reference's clipped task-mean."""
+    all-reduce - or is stated by the caller, who knows the shard plan (no host sync) - and the result is still the
+    reference's clipped task-mean."""
     fixture = os.path.join(golden_dir, "harness_T4_N16_d8_k0.npz")
     g = np.load(fixture)
     ret = mp.Manager().dict()
-    port = 29500 + (os.getpid() % 2000) + 7
-    mp.spawn(_run_rank, args=(2, port, fixture, ret, (3, 1)), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + 7 + (stated_total or 0)
+    mp.spawn(_run_rank, args=(2, port, fixture, ret, (3, 1), stated_total), nprocs=2, join=True)
     scale = np.abs(g["grad_clipped"]).max()
     for r in range(2):
         assert np.abs(ret[r]["grad"] - g["grad_clipped"]).max() <= 2e-6 * scale, r
