@@ -48,24 +48,31 @@ __global__ __launch_bounds__(512) void k_lg_diag(LgMat a, int step) {
     const int nloc = min(LB, n - p0);
     if (nloc <= 0) return;
     const float* Mi = a.M + (size_t)t * a.ld * a.ld;
+    // the diagonal block, identity-padded; M is exactly symmetric (ProbLgUpdate writes every tile together with its mirror image),
+    // so the rows are read as they are: 8 sixteen-byte loads per lane instead of 32 conditional dword loads
     float m[RB][CB];
+    const float* blk = Mi + (size_t)p0 * a.ld + p0;
+    const bool vec = rows_aligned16(blk, a.ld);
 #pragma unroll
-    for (int r = 0; r < RB; ++r)
+    for (int r = 0; r < RB; ++r) {
+        const int i = SW::row(r);
+        load_segment<CB>(blk + (size_t)i * a.ld, SW::col(0), nloc, i < nloc, vec, m[r]);
 #pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            const int i = SW::row(r), j = SW::col(c);
-            const int hi = i > j ? i : j, lo = i > j ? j : i;  // exactly symmetric input to the sweep
-            m[r][c] = (i < nloc && j < nloc) ? Mi[(size_t)(p0 + hi) * a.ld + p0 + lo] : (i == j ? 1.f : 0.f);
-        }
+        for (int c = 0; c < CB; ++c)
+            if (i == SW::col(c) && i >= nloc) m[r][c] = 1.f;
+    }
     __syncthreads();
     SW::run(m, nloc, sm);
     float logdet;
     const int info = SW::finish(nloc, sm, logdet);
     float* Dv = a.Dinv + (size_t)t * LB * LB;
 #pragma unroll
-    for (int r = 0; r < RB; ++r)
+    for (int r = 0; r < RB; ++r) {
+        float neg[CB];
 #pragma unroll
-        for (int c = 0; c < CB; ++c) Dv[SW::row(r) * LB + SW::col(c)] = -m[r][c];
+        for (int c = 0; c < CB; ++c) neg[c] = -m[r][c];
+        store_segment<CB>(Dv + SW::row(r) * LB, SW::col(0), LB, true, true, neg);   // Dinv is [LB, LB] in the 256-byte-aligned workspace
+    }
     if (threadIdx.x == 0) {
         a.logdet[t] = (step == 0 ? 0.f : a.logdet[t]) + logdet;
         const int prev = step == 0 ? 0 : a.info[t];
@@ -92,6 +99,12 @@ struct ProbLgPanel {
     __device__ float b(int k, int j) const { return Mi[(size_t)(p0 + k) * m.ld + j]; }
     __device__ void a4(int i, int k, float (&v)[4]) const { ld4(Dv + i * LB + k, v); }
     __device__ void b4(int k, int j, float (&v)[4]) const { ld4(Mi + (size_t)(p0 + k) * m.ld + j, v); }
+    static constexpr int A_NRAW = 1, B_NRAW = 1;   // two-phase operand path of gemm.h
+    __device__ bool raw_ok() const { return true; }
+    __device__ void a_raw(int i, int k, float4 (&r)[1]) const { r[0] = ldq(Dv + i * LB + k); }
+    __device__ void a_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
+    __device__ void b_raw(int k, int j, float4 (&r)[1]) const { r[0] = ldq(Mi + (size_t)(p0 + k) * m.ld + j); }
+    __device__ void b_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
     __device__ void epi(int i, int j, float acc, float*) const {
         Fb[(size_t)i * m.ld + j] = acc;
         Cb[(size_t)i * m.ld + j] = Mi[(size_t)(p0 + i) * m.ld + j];
@@ -120,6 +133,12 @@ struct ProbLgUpdate {
     __device__ float b(int k, int j) const { return Fb[(size_t)k * m.ld + j]; }
     __device__ void a4(int i, int k, float (&v)[4]) const { ld4(Cb + (size_t)k * m.ld + i, v); }
     __device__ void b4(int k, int j, float (&v)[4]) const { ld4(Fb + (size_t)k * m.ld + j, v); }
+    static constexpr int A_NRAW = 1, B_NRAW = 1;   // two-phase operand path of gemm.h
+    __device__ bool raw_ok() const { return true; }
+    __device__ void a_raw(int i, int k, float4 (&r)[1]) const { r[0] = ldq(Cb + (size_t)k * m.ld + i); }
+    __device__ void a_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
+    __device__ void b_raw(int k, int j, float4 (&r)[1]) const { r[0] = ldq(Fb + (size_t)k * m.ld + j); }
+    __device__ void b_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
     __device__ void epi(int i, int j, float acc, float*) const {
         const int ti = i >> 6, tj = j >> 6;
         if (ti > tj) return;
