@@ -226,9 +226,17 @@ __global__ __launch_bounds__(256) void k_lg_build(LgInner a) {
     const float il2 = 1.f / (ls * ls);
     const float* D2 = a.in.D2ss + (size_t)t * ld * ld;
     float* Mi = a.mat.M + (size_t)t * ld * ld;
-    for (int e = threadIdx.x; e < GT * GT; e += 256) {
-        const int i = m0 + (e >> 6), j = n0 + (e & 63);
-        if (i < n && j < n) Mi[(size_t)i * ld + j] = os * kappa0(a.in.kind, D2[(size_t)i * ld + j] * il2) + (i == j ? noise : 0.f);
+    // sixteen elements per thread: all their loads first, to clamped addresses (no branch around a load: kernels.h), then the
+    // arithmetic and the predicated stores
+    constexpr int EPT = GT * GT / 256;
+    const int j = n0 + (threadIdx.x & 63), jc = min(j, n - 1);
+    float d2v[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) d2v[q] = D2[(size_t)min(m0 + (threadIdx.x >> 6) + 4 * q, n - 1) * ld + jc];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int i = m0 + (threadIdx.x >> 6) + 4 * q;
+        if (i < n && j < n) Mi[(size_t)i * ld + j] = os * kappa0(a.in.kind, d2v[q] * il2) + (i == j ? noise : 0.f);
     }
 }
 
@@ -248,17 +256,27 @@ __global__ __launch_bounds__(256) void k_lg_traces(LgInner a) {
         const float* D2 = a.in.D2ss + (size_t)t * ld * ld;
         float* Mi = a.mat.M + (size_t)t * ld * ld;
         const float* al = a.in.vecs + ((size_t)t * NVEC + V_ALPHA) * a.in.vld;
-        for (int e = threadIdx.x; e < GT * GT; e += 256) {
-            const int i = m0 + (e >> 6), j = n0 + (e & 63);
+        constexpr int EPT = GT * GT / 256;   // loads first, clamped (see k_lg_build)
+        const int j = n0 + (threadIdx.x & 63), jc = min(j, n - 1);
+        float mv[EPT], d2v[EPT], aa[EPT];
+        const float alj = al[jc];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int ic = min(m0 + (threadIdx.x >> 6) + 4 * q, n - 1);
+            mv[q] = Mi[(size_t)ic * ld + jc]; d2v[q] = D2[(size_t)ic * ld + jc]; aa[q] = al[ic] * alj;
+        }
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int i = m0 + (threadIdx.x >> 6) + 4 * q;
             if (i < n && j < n) {
-                const float ai = -Mi[(size_t)i * ld + j];
+                const float ai = -mv[q];
                 Mi[(size_t)i * ld + j] = ai;
                 float k0, k1, k2;
-                const float u = D2[(size_t)i * ld + j] * il2;
+                const float u = d2v[q] * il2;
                 kappa3(a.in.kind, u, k0, k1, k2);
                 const float G = os * k1 * u * gl;
                 acc[0] += ai * G;
-                acc[1] += al[i] * al[j] * G;
+                acc[1] += aa[q] * G;
                 if (i == j) acc[2] += ai;
             }
         }
