@@ -40,7 +40,7 @@ void launch_gemm(const P& p, int T, int M, int N, hipStream_t st) {
 }
 
 struct Workspace {
-    float *mean, *nrm_s, *nrm_q, *D2ss, *D2qs, *D2qq, *Ainv, *P, *C, *S, *OC, *Wss, *Wqs, *Wqq, *vecs, *scal, *part_oc, *part_ma, *l0;
+    float *mean, *D2ss, *D2qs, *D2qq, *Ainv, *P, *C, *S, *OC, *Wss, *Wqs, *Wqq, *vecs, *scal, *part_oc, *part_ma, *l0;
     // blocked path only (max(ns, nq) > REG_POINTS)
     float *lg_Dinv, *lg_C, *lg_F, *lg_logdet, *lg_part;
     int32_t *lg_info, *lg_med;  // lg_med: prefix[T], rank[T], hist[T, 256]
@@ -59,8 +59,6 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
     w.nt_oc = nq > 0 ? tiles_of(nq, ns) : 0;   // per-tile partial reductions of ProbOC / ProbMA
     w.nt_ma = tiles_of(ns, ns);
     w.mean = take(Tz * d);
-    w.nrm_s = take(Tz * ns);
-    w.nrm_q = take(Tz * (nq > 0 ? nq : 1));
     w.D2ss = take(Tz * ns * ns);
     w.D2qs = take(Tz * nq * ns);
     w.D2qq = take(Tz * nq * nq);
@@ -134,7 +132,7 @@ thread_local hipError_t g_last_hip_error = hipSuccess;  // diagnostics only: wha
 
 inline bool has_query(const adkf_batch_t* b) { return b->nq_max > 0 && b->Z_q != nullptr; }
 
-// Stage A: centring, row norms, squared distances.  Skipped when the caller promises (ADKF_BATCH_REUSE_DIST) that
+// Stage A: centring, squared distances.  Skipped when the caller promises (ADKF_BATCH_REUSE_DIST) that
 // this workspace already holds them for exactly this batch.
 // parts: 1 = the support block (mean, norms, D2ss), 2 = the query blocks (needs the support mean / norms in place),
 // 4 = the features are already centred and w.mean holds zeros (ARD: Z~ = (Z - mu) / l has zero column mean by construction).
@@ -511,8 +509,8 @@ void ard_dz_support(ArdCtx& c, const float* W, float* out, const int32_t* n_over
 int ard_eval(ArdCtx& c, const float* x, float* f, float* g, int32_t* info3) {
     hipStream_t st = c.st;
     k_ard_params<<<dim3(ceil_div(c.d, 256), c.T), 256, 0, st>>>(c.v, x);
-    k_ard_scale_norm<<<dim3(ceil_div(c.ns, 4), c.T), 256, 0, st>>>(c.v, c.b->Z_s, c.a.Zt_s, c.b->n_s, c.ns, c.w.nrm_s);
-    int rc = stage_dist(&c.bt, c.w, false, st, 1 | 4 | 8);
+    k_ard_scale<<<dim3(ceil_div(c.ns, 4), c.T), 256, 0, st>>>(c.v, c.b->Z_s, c.a.Zt_s, c.b->n_s, c.ns);
+    int rc = stage_dist(&c.bt, c.w, false, st, 1 | 4);
     if (rc) return rc;
     InnerArgs ia = inner_args(&c.bt, c.w, c.a.phi3, info3);
     ia.f_out = c.a.f3; ia.g_out = c.a.g3;
@@ -627,8 +625,8 @@ int ard_outer(ArdCtx& c, const float* phi, int flags, float* f_out, int32_t* inf
     } else {
         hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)c.T, st);
     }
-    k_ard_scale_norm<<<dim3(ceil_div(c.nq, 4), c.T), 256, 0, st>>>(c.v, c.b->Z_q, c.a.Zt_q, c.b->n_q, c.nq, c.w.nrm_q);
-    rc = stage_dist(&c.bt, c.w, true, st, 2 | 4 | 16);
+    k_ard_scale<<<dim3(ceil_div(c.nq, 4), c.T), 256, 0, st>>>(c.v, c.b->Z_q, c.a.Zt_q, c.b->n_q, c.nq);
+    rc = stage_dist(&c.bt, c.w, true, st, 2 | 4);
     if (rc) return rc;
     if (!want_grads) return 0;
     adkf_batch_t bq = c.bt;

@@ -74,22 +74,15 @@ __global__ __launch_bounds__(256) void k_ard_params(ArdView a, const float* x) {
     }
 }
 
-// Zt = (Z - mu) / ell (rows beyond n are zeroed) with the squared row norms of Zt alongside (what k_rownorm would compute
-// against a zero mean): one wave per row, grid (ceil(ld / 4), T).
-__global__ __launch_bounds__(256) void k_ard_scale_norm(ArdView a, const float* Z, float* Zt, const int32_t* n_arr, int ld, float* nrm) {
+// Zt = (Z - mu) / ell (rows beyond n are zeroed): one wave per row, grid (ceil(ld / 4), T).  (The squared row norms the
+// distance stage needs are summed by the distance GEMM itself while it stages Zt: gemm.h set_rowsq.)
+__global__ __launch_bounds__(256) void k_ard_scale(ArdView a, const float* Z, float* Zt, const int32_t* n_arr, int ld) {
     const int t = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= ld) return;
     const int n = n_arr ? n_arr[t] : ld;
     const size_t o = ((size_t)t * ld + i) * a.d;
     const float *mu = a.mu + (size_t)t * a.d, *el = a.ell + (size_t)t * a.d;
-    float s = 0.f;
-    for (int k = lane; k < a.d; k += 64) {
-        const float v = i < n ? (Z[o + k] - mu[k]) / el[k] : 0.f;
-        Zt[o + k] = v;
-        s += v * v;
-    }
-    s = wave_sum(s);
-    if (lane == 0) nrm[(size_t)t * ld + i] = s;
+    for (int k = lane; k < a.d; k += 64) Zt[o + k] = i < n ? (Z[o + k] - mu[k]) / el[k] : 0.f;
 }
 
 // out[k] = sum_i A_ik B_ik over the rows of one task (64 columns x 4 row groups; grid: ceil(d / 64) x T); optional second

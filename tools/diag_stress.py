@@ -26,8 +26,6 @@ def au(nfloat):
 def d2_offsets(T, ns, nq, d):
     off = 0
     off += au(T * d)            # mean
-    off += au(T * ns)           # nrm_s
-    off += au(T * max(nq, 1))   # nrm_q
     o_ss = off
     off += au(T * ns * ns)
     o_qs = off
