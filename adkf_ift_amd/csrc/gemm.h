@@ -3,10 +3,12 @@
 // from squared distances, Omega from S^-1 and e, ...) and a fused epilogue functor (elementwise chain rule +
 // reductions), so no intermediate kernel matrix is ever written to HBM.
 //
-// Pipeline: K is consumed in chunks of 32; the global loads (and the functor arithmetic, e.g. exp) of chunk c+1
-// are issued into registers before the MFMAs of chunk c and written to LDS after them, so memory latency and the
-// VALU work of operand generation hide under the matrix pipe.  LDS layouts are conflict-free for the b32
-// fragment reads: [mn][34] for K-contiguous operands (bank = 2 i + k), [k][TM + 16] for MN-contiguous ones.
+// Pipeline: K is consumed in chunks of 32.  Tiles that lie fully inside their task take the two-phase operand path: the
+// 16-byte global loads of chunk c+1 (x_raw) are issued before the MFMAs of chunk c, the functor arithmetic on them
+// (x_fin: centring, exp, scaling) and the LDS stores come after, so no wave waits for memory in front of its matrix
+// instructions.  Ragged tiles take the checked path (a4 / b4 or element-wise, range-checked per lane, loaded AND
+// transformed before the MFMAs).  LDS layouts are conflict-free for the b32 fragment reads: [mn][34] for K-contiguous
+// operands (bank = 2 i + k), [k][TM + 16] for MN-contiguous ones.
 //
 // Tile size: the 128 x 128 tile halves the L2 -> CU operand traffic of the 64 x 64 one, but with 256 threads it leaves
 // one wave per SIMD and nothing to cover the stage/barrier phases: measured 1.4-1.8x SLOWER on every C2 stage, so the
@@ -34,6 +36,8 @@
 //                                                  pass) and hands the tile's TM + TM sums to the functor before the epilogue
 //   __device__ void  epi4(int i0, int j, const float (&acc)[4], float* red) : OPTIONAL - four consecutive rows of one
 //                                                  column at once (what one lane holds after the MFMA), all in range
+//   static constexpr int A_NRAW / B_NRAW, raw_ok(), a_raw / a_fin, b_raw / b_fin : OPTIONAL - the two-phase operand path (see
+//                                                  above gemm_group); a4 / b4 are then a_raw followed by a_fin
 #pragma once
 #include <type_traits>
 
