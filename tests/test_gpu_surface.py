@@ -437,3 +437,32 @@ def test_clip_adam_equals_clip_grad_norm_plus_torch_adam(dev, clip, wd):
         ClipAdam([p], lr=1e-2).clip_step(1.0, 1.0)
         outs.append(p.detach().clone())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("T,N,Nq,d,kern", [(1, 2, 1, 3, "rbf"), (3, 2, 5, 1, "matern"), (300, 17, 9, 5, "rbf"),
+                                           (9, 129, 40, 33, "matern"), (5, 64, 130, 7, "rbf"), (2, 200, 200, 35, "rbf")])
+def test_awkward_shapes_match_oracle(dev, T, N, Nq, d, kern):
+    """Edges of the launch geometry: task counts that are not multiples of 8 (XCD map), two points, feature widths with K tails
+    (3, 5, 7, 33, 35: checked staging path + fused row norms), support / query counts just past the register-resident size."""
+    from adkf_ift_amd import gp_ops
+    from adkf_ift_amd.synthetic import make_tasks
+    from oracle import gp_oracle as O
+
+    tasks = make_tasks(T, N, d, N_q=Nq)
+    Zs, Zq = tasks.features()
+    phi, pri, _ = gp_ops.init_params(Zs.to(dev))
+    b = gp_ops.GPBatch(Zs.to(dev), tasks.y_s.to(dev), pri, kern, Z_q=Zq.to(dev), y_q=tasks.y_q.to(dev))
+    phi, f, gn, ne, info = gp_ops.fit(b, phi, max_evals=40)
+    gp_ops.check_info(info)
+    out = gp_ops.ift_hypergrad(b, phi)
+    gp_ops.check_info(out["info"])
+    kind = gp_ops.kernel_id(kern)
+    for t in sorted({0, T // 2, T - 1}):
+        p = O.Priors(*pri[t].double().cpu().tolist())
+        q = O.full_reference_quantities(Zs[t], tasks.y_s[t], Zq[t], tasks.y_q[t], phi[t].double().cpu(), p, kind)
+        assert abs(f[t].item() - q["f_in"]) <= 1e-5 * abs(q["f_in"])
+        assert abs(out["f_out"][t].item() - q["f_out"]) <= 1e-5 * abs(q["f_out"])
+        ref = np.asarray(q["dZs_total"])
+        assert np.abs(out["dZ_s"][t].cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+        refq = np.asarray(q["dZq_total"])
+        assert np.abs(out["dZ_q"][t].cpu().numpy() - refq).max() <= 1e-4 * max(np.abs(refq).max(), 1e-30)
