@@ -242,7 +242,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_hess(HessArgs a) {
     if (!task_tile(a.T, 1, t, tile)) return;
     const int n = a.tv.ns(t), ld = a.tv.ns_ld, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float* sc = a.scal + (size_t)t * NSCAL;
-    const float noise = sc[S_NOISE], os = sc[S_OS], ls = sc[S_LS], il2 = 1.f / (ls * ls);
+    const float os = sc[S_OS], ls = sc[S_LS], il2 = 1.f / (ls * ls);
     const float* Ai = a.Ainv + (size_t)t * ld * ld;
     const float* Pi = a.P + (size_t)t * ld * ld;
     const float* D2 = a.D2ss + (size_t)t * ld * ld;
