@@ -295,16 +295,21 @@ void launch_c(const TaskView& tv, const adkf_batch_t* b, const Workspace& w, hip
     launch_gemm(pf, T, nq, ns, st);
 }
 
+// ADKF_R64_THRESHOLD (read once) moves the switch-over for experiments: 0 sends every task through float64, a huge value none
+float r64_threshold() {
+    static const float thresh = [] {
+        const char* e = getenv("ADKF_R64_THRESHOLD");
+        return e ? (float)atof(e) : R64_THRESHOLD;
+    }();
+    return thresh;
+}
+
 // Ill-conditioned tasks redo the factorisation-type stages in float64 (refine64.h); everybody else leaves the kernel after
 // reading two scalars.  level: 0 = inner quantities (A^-1, alpha, scalars), 1 = + C, mu (prediction), 2 = + S^-1, e, f_out.
 void launch_refine(const TaskView& tv, const adkf_batch_t* b, const Workspace& w, bool with_hessian, int level, float* f_out,
                    int32_t* info, hipStream_t st, float* f_in = nullptr, float* g_in = nullptr, float* gnorm = nullptr) {
     if (!w.w64) return;
-    // ADKF_R64_THRESHOLD (read once) moves the switch-over for experiments: 0 sends every task through float64, a huge value none
-    static const float thresh = [] {
-        const char* e = getenv("ADKF_R64_THRESHOLD");
-        return e ? (float)atof(e) : R64_THRESHOLD;
-    }();
+    const float thresh = r64_threshold();
     Refine64Args ra{tv, w.D2ss, w.D2qs, w.D2qq, b->y_s, b->y_q, b->priors, w.Ainv, with_hessian ? w.P : nullptr, level >= 1 ? w.C : nullptr,
                     level >= 2 ? w.S : nullptr, w.vecs, w.scal, f_out, info, f_in, g_in, gnorm, w.w64, w.w64_stride, thresh, b->T, with_hessian ? 1 : 0, level};
     k_refine64<<<b->T, R64_NT, 0, st>>>(ra);
@@ -429,6 +434,11 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
             ProbDZ<true> pz; pz.tv = tv; pz.Wss = w.Wss; pz.Wqs = w.Wqs; pz.Wqq = w.Wqq; pz.Zs = b->Z_s; pz.Zq = b->Z_q; pz.dZ = dZ_q; pz.d = d;
             launch_gemm(pz, T, nq, d, st);
         }
+    }
+    if (w.w64) {   // flagged (ill-conditioned) tasks: the cotangent algebra and dL/dZ once more, in float64, over what the kernels above wrote
+        Cot64Args ca{tv, w.D2ss, w.D2qs, w.D2qq, b->Z_s, b->Z_q, dZ_s, dZ_q, d, w.vecs, w.scal, w.w64, w.w64_stride, r64_threshold(), T,
+                     with_hessian ? 1 : 0, flags, dirscale, corrscale, g_phi_out, v_out};
+        k_cotangent64<<<T, R64_NT, 0, st>>>(ca);
     }
     LAUNCH_OK();
     return 0;

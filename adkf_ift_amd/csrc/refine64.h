@@ -343,4 +343,180 @@ __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
     }
 }
 
+// k_cotangent64: the cotangent stage of the SAME flagged tasks, after the float32 kernels have written theirs.
+//
+// With A^-1, C, Sigma_q^-1 and e computed in float64 the remaining error of flagged tasks (cond 2e3 .. 5e3) sat in the float32
+// products and reductions downstream: Omega C, C^T (Omega C), (A^-1 B_v) A^-1 and the sums behind grad_phi f_out - 1.2x .. 2.3x the
+// tolerance on v and dL/dZ for 4 of 180 stress tasks, none when the emulation runs them in float64 (tools/emulate_precision.py,
+// configuration "all64w").  This kernel redoes exactly that algebra from the float64 matrices k_refine64 left in the workspace
+// region - W_ss (direct and mixed part), W_qs, W_qq, grad_phi f_out, v, w - and then dL/dZ itself, in the difference form
+//     dZs_i = sum_k 4 Wss_ik (z_i - z_k) + sum_q 2 Wqs_qi (z_i - zq_q),   dZq_i = sum_k 2 Wqs_ik (zq_i - z_k) + sum_q 4 Wqq_iq (zq_i - zq_q)
+// (the float32 kernels form coef_i z_i - sum_k W_ik z_k: two large terms that cancel when the features are clustered, which
+// is exactly when a task is flagged - one stress task stayed at 1.9x the tolerance on dL/dZ_s until this was float64 as
+// well).  It runs LAST and overwrites grad_phi f_out, v and the rows of dL/dZ of its tasks.  Formulas: ProbOC / ProbMA / k_wqq /
+// solve_v_task / ProbMixed / ProbDZ (problems.h, kernels.h), i.e. oracle/closed_form.py::outer_stage, ::mixed_stage,
+// ::dz_from_weights.  Everybody else leaves after the flag test.
+struct Cot64Args {
+    TaskView tv; const float *D2ss, *D2qs, *D2qq; const float *Zs, *Zq; float *dZs, *dZq; int d; float* vecs; float* scal;
+    double* w64; size_t w64_stride; float thresh; int T, with_hessian, flags; float dirscale, corrscale; float *g_phi_out, *v_out;
+};
+
+__global__ __launch_bounds__(R64_NT) void k_cotangent64(Cot64Args a) {
+    __shared__ double red[R64_NT / 64];
+    __shared__ double coef[4];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    if (t >= a.T) return;
+    const int n = a.tv.ns(t), m = a.tv.nq(t), ld = a.tv.ns_ld, ldq = a.tv.nq_ld, vld = a.tv.vld;
+    if (n <= 0 || m <= 0) return;
+    float* sc = a.scal + (size_t)t * NSCAL;
+    const double noise = sc[S_NOISE], os = sc[S_OS], ls = sc[S_LS], il2 = 1.0 / (ls * ls), gl = -2.0 / ls;
+    const int kind = a.tv.kind;
+    const float bound = (float)((os + noise) / noise);                       // the flag test of k_refine64 (level 2)
+    const float ra = ld <= 128 ? sc[S_PIVR_A] : bound, rs = ldq <= 128 ? sc[S_PIVR_S] : bound;
+    if (!(ra > a.thresh || rs > a.thresh)) return;
+
+    double* W = a.w64 + (size_t)t * a.w64_stride;                            // the layout of k_refine64
+    double* A1 = W;                                 // A^-1
+    double* A2 = A1 + (size_t)ld * ld;              // (G: spent)        -> M_A -> W_ss
+    double* A3 = A2 + (size_t)ld * ld;              // P = A^-1 G  (valid when the Hessian was asked for)
+    double* B1 = A3 + (size_t)ld * ld;              // (K_qs: spent)     -> Omega C -> W_qs
+    double* B2 = B1 + (size_t)ldq * ld;             // C
+    double* S1 = B2 + (size_t)ldq * ld;             // S^-1
+    double* S2 = S1 + (size_t)ldq * ldq;            // (L_S^-1: spent)   -> W_qq
+    const int vmax = ld > ldq ? ld : ldq;
+    double* v_al = S2 + (size_t)ldq * ldq;
+    double* v_be = v_al + vmax; double* v_ga = v_be + vmax; double* v_de = v_ga + vmax;
+    double* v_w = v_de + vmax;                      // (r: written out)  -> w
+    double* v_e = v_w + vmax;
+    double* v_cte = v_e + vmax;                     // (mu: written out) -> C^T e
+    (void)v_be;
+    const float* Dss = a.D2ss + (size_t)t * ld * ld;
+    const float* Dqs = a.D2qs + (size_t)t * ldq * ld;
+    const float* Dqq = a.D2qq + (size_t)t * ldq * ldq;
+    float* vb = a.vecs + (size_t)t * NVEC * vld;
+    const double dir = a.dirscale, corr = a.with_hessian ? (double)a.corrscale : 0.0;
+
+    for (int j = tid; j < n; j += R64_NT) {        // C^T e
+        double s = 0.0;
+        for (int i = 0; i < m; ++i) s += B2[(size_t)i * ld + j] * v_e[i];
+        v_cte[j] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < m * n; e += R64_NT) {     // Omega C = (S^-1 C - e (C^T e)^T) / 2
+        const int i = e / n, j = e % n;
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s += S1[(size_t)i * ldq + k] * B2[(size_t)k * ld + j];
+        B1[(size_t)i * ld + j] = 0.5 * (s - v_e[i] * v_cte[j]);
+    }
+    __syncthreads();
+    double oc0 = 0, oc1 = 0, ma0 = 0, ma1 = 0, ma2 = 0, qq0 = 0, qq1 = 0, qq2 = 0;
+    for (int e = tid; e < n * n; e += R64_NT) {     // M_A = C^T (Omega C) + sym(C^T e alpha^T)
+        const int i = e / n, j = e % n;
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s += B2[(size_t)k * ld + i] * B1[(size_t)k * ld + j];
+        const double MA = s + 0.5 * (v_cte[i] * v_al[j] + v_al[i] * v_cte[j]);
+        A2[(size_t)i * ld + j] = MA;
+        const double u = (double)Dss[(size_t)i * ld + j] * il2;
+        double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
+        if (i == j) ma0 += MA;
+        ma1 += MA * k0; ma2 += MA * os * k1 * u * gl;
+    }
+    __syncthreads();                                // Omega C has been read by everybody: it turns into W_qs in place
+    for (int e = tid; e < m * n; e += R64_NT) {     // M_B -> W_qs
+        const int i = e / n, j = e % n;
+        const double MB = -2.0 * B1[(size_t)i * ld + j] - v_e[i] * v_al[j];
+        const double u = (double)Dqs[(size_t)i * ld + j] * il2;
+        double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
+        B1[(size_t)i * ld + j] = dir * MB * os * k1 * il2;
+        oc0 += MB * k0; oc1 += MB * os * k1 * u * gl;
+    }
+    for (int e = tid; e < m * m; e += R64_NT) {     // Omega -> W_qq
+        const int i = e / m, j = e % m;
+        const double om = 0.5 * (S1[(size_t)i * ldq + j] - v_e[i] * v_e[j]);
+        const double u = (double)Dqq[(size_t)i * ldq + j] * il2;
+        double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
+        S2[(size_t)i * ldq + j] = dir * om * os * k1 * il2;
+        if (i == j) qq0 += om;
+        qq1 += om * k0; qq2 += om * os * k1 * u * gl;
+    }
+    oc0 = r64_sum(oc0, red); oc1 = r64_sum(oc1, red); ma0 = r64_sum(ma0, red); ma1 = r64_sum(ma1, red); ma2 = r64_sum(ma2, red);
+    qq0 = r64_sum(qq0, red); qq1 = r64_sum(qq1, red); qq2 = r64_sum(qq2, red);
+    if (tid == 0) {                                 // grad_phi f_out, v = H^-1 grad (solve_v_task)
+        const double d1[3] = {sc[S_D1N], sc[S_D1S], sc[S_D1L]};
+        const double g[3] = {(qq0 + ma0) * d1[0], (ma1 + oc0 + qq1) * d1[1], (ma2 + oc1 + qq2) * d1[2]};
+        double vd[3] = {0.0, 0.0, 0.0};
+        if (a.with_hessian && !(a.flags & 1)) {
+            double Mx[3][4];
+            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Mx[i][j] = sc[S_H0 + i * 3 + j]; Mx[i][3] = g[i]; }
+            for (int c = 0; c < 3; ++c) {
+                int pv = c;
+                for (int r = c + 1; r < 3; ++r) if (fabs(Mx[r][c]) > fabs(Mx[pv][c])) pv = r;
+                if (pv != c) for (int j = 0; j < 4; ++j) { const double tmp = Mx[c][j]; Mx[c][j] = Mx[pv][j]; Mx[pv][j] = tmp; }
+                const double ip = 1.0 / Mx[c][c];
+                for (int r = c + 1; r < 3; ++r) { const double f = Mx[r][c] * ip; for (int j = c; j < 4; ++j) Mx[r][j] -= f * Mx[c][j]; }
+            }
+            for (int c = 2; c >= 0; --c) { double s = Mx[c][3]; for (int j = c + 1; j < 3; ++j) s -= Mx[c][j] * vd[j]; vd[c] = s / Mx[c][c]; }
+        }
+        for (int q = 0; q < 3; ++q) { sc[S_GOUT0 + q] = (float)g[q]; sc[S_V0 + q] = (float)vd[q]; }
+        if (a.g_phi_out) for (int q = 0; q < 3; ++q) a.g_phi_out[t * 3 + q] = (float)g[q];
+        if (a.v_out) for (int q = 0; q < 3; ++q) a.v_out[t * 3 + q] = (float)vd[q];
+        coef[0] = vd[0] * d1[0]; coef[1] = vd[1] * d1[1] / os; coef[2] = vd[2] * d1[2];
+        sc[S_CN] = (float)coef[0]; sc[S_CS] = (float)coef[1]; sc[S_CL] = (float)coef[2];
+    }
+    __syncthreads();
+    const double cn = coef[0], cs = coef[1], cl = coef[2];
+    if (a.with_hessian) {
+        for (int i = tid; i < n; i += R64_NT) {
+            const double w = cn * v_ga[i] + cs * (v_al[i] - noise * v_ga[i]) + cl * v_de[i];
+            v_w[i] = w;
+            vb[V_W * vld + i] = (float)w;
+        }
+    }
+    __syncthreads();
+    const double fn = (double)n;
+    for (int e = tid; e < n * n; e += R64_NT) {     // W_ss = direct part - mixed-partial part (ProbMA / ProbMixed epilogues)
+        const int i = e / n, j = e % n;
+        const double u = (double)Dss[(size_t)i * ld + j] * il2;
+        double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
+        double wss = dir * A2[(size_t)i * ld + j] * os * k1 * il2;
+        if (corr != 0.0) {
+            double xa = 0.0;                        // ((A^-1 B_v) A^-1)_ij,  A^-1 B_v = (cn - cs noise) A^-1 + cs I + cl P
+            for (int k = 0; k < n; ++k)
+                xa += ((cn - cs * noise) * A1[(size_t)i * ld + k] + (i == k ? cs : 0.0) + cl * A3[(size_t)i * ld + k]) * A1[(size_t)k * ld + j];
+            const double dgdA = (-0.5 * xa + 0.5 * (v_w[i] * v_al[j] + v_al[i] * v_w[j])) / fn;
+            const double Q = 0.5 * (A1[(size_t)i * ld + j] - v_al[i] * v_al[j]) / fn;
+            const double dBv = cs * os * k1 + cl * os * gl * (k1 + u * k2);
+            wss -= corr * (dgdA * os * k1 * il2 + Q * dBv * il2);
+        }
+        A2[(size_t)i * ld + j] = wss;               // (element (i, j) of M_A is read by this thread only)
+    }
+    __syncthreads();
+    // ---- dL/dZ in the difference form, from the float64 weights
+    const int d = a.d;
+    const float* Zs = a.Zs + (size_t)t * ld * d;
+    const float* Zq = a.Zq + (size_t)t * ldq * d;
+    if (a.dZs) {
+        float* out = a.dZs + (size_t)t * ld * d;
+        for (int e = tid; e < n * d; e += R64_NT) {
+            const int i = e / d, c = e % d;
+            const double zi = Zs[(size_t)i * d + c];
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += 4.0 * A2[(size_t)i * ld + k] * (zi - (double)Zs[(size_t)k * d + c]);
+            for (int q = 0; q < m; ++q) s += 2.0 * B1[(size_t)q * ld + i] * (zi - (double)Zq[(size_t)q * d + c]);
+            out[(size_t)i * d + c] = (float)s;
+        }
+    }
+    if (a.dZq) {
+        float* out = a.dZq + (size_t)t * ldq * d;
+        for (int e = tid; e < m * d; e += R64_NT) {
+            const int i = e / d, c = e % d;
+            const double zi = Zq[(size_t)i * d + c];
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += 2.0 * B1[(size_t)i * ld + k] * (zi - (double)Zs[(size_t)k * d + c]);
+            for (int q = 0; q < m; ++q) s += 4.0 * S2[(size_t)i * ldq + q] * (zi - (double)Zq[(size_t)q * d + c]);
+            out[(size_t)i * d + c] = (float)s;
+        }
+    }
+}
+
 }  // namespace adkf
