@@ -310,7 +310,7 @@ void launch_refine(const TaskView& tv, const adkf_batch_t* b, const Workspace& w
                    int32_t* info, hipStream_t st, float* f_in = nullptr, float* g_in = nullptr, float* gnorm = nullptr) {
     if (!w.w64) return;
     const float thresh = r64_threshold();
-    Refine64Args ra{tv, w.D2ss, w.D2qs, w.D2qq, b->y_s, b->y_q, b->priors, w.Ainv, with_hessian ? w.P : nullptr, level >= 1 ? w.C : nullptr,
+    Refine64Args ra{tv, b->Z_s, b->Z_q, b->d, b->y_s, b->y_q, b->priors, w.Ainv, with_hessian ? w.P : nullptr, level >= 1 ? w.C : nullptr,
                     level >= 2 ? w.S : nullptr, w.vecs, w.scal, f_out, info, f_in, g_in, gnorm, w.w64, w.w64_stride, thresh, b->T, with_hessian ? 1 : 0, level};
     k_refine64<<<b->T, R64_NT, 0, st>>>(ra);
 }
@@ -436,7 +436,7 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         }
     }
     if (w.w64) {   // flagged (ill-conditioned) tasks: the cotangent algebra and dL/dZ once more, in float64, over what the kernels above wrote
-        Cot64Args ca{tv, w.D2ss, w.D2qs, w.D2qq, b->Z_s, b->Z_q, dZ_s, dZ_q, d, w.vecs, w.scal, w.w64, w.w64_stride, r64_threshold(), T,
+        Cot64Args ca{tv, b->Z_s, b->Z_q, dZ_s, dZ_q, d, w.vecs, w.scal, w.w64, w.w64_stride, r64_threshold(), T,
                      with_hessian ? 1 : 0, flags, dirscale, corrscale, g_phi_out, v_out};
         k_cotangent64<<<T, R64_NT, 0, st>>>(ca);
     }

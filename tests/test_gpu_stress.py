@@ -115,12 +115,6 @@ def test_random_shapes_against_the_oracle(dev, chunk):
                 e = _rel(v, q[k])
                 e32 = _rel(q32[k], q[k])
                 tol = max(TOL * slack.get(k, 1.0), 4.0 * e32)
-                if cond > 2.0e3 and k == "dZs_total":
-                    # Known residual: ONE of the 1620 comparisons - a float64-path task of cond 2.3e3 with 96
-                    # support points in two dimensions (noise ~0.01) - sits at 1.9x the rule on dL/dZ_s even with the whole
-                    # cotangent stage and dL/dZ in float64 (k_cotangent64); what is left in float32 there are the squared distances.
-                    # Held to 2.5x instead of being excluded.  (Before k_cotangent64: four comparisons, v and dL/dZ, up to 2.3x.)
-                    tol *= 2.5
                 worst[k] = max(worst.get(k, 0.0), e / tol)
                 if e > 0.1 * TOL:
                     kk = ("well " if well else "ill ") + k
