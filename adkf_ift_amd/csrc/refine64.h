@@ -13,10 +13,11 @@
 // this file).
 //
 // So: after the float32 stages have run for everybody, ONE workgroup per flagged task redoes, in float64 from the
-// float32 squared distances, everything between the kernel matrices and the cotangent stage
+// float32 FEATURES (squared distances in the difference form: r64_distances), everything up to the cotangent stage
 //     A -> Cholesky -> A^-1, alpha, log|A| -> P = A^-1 G, beta, gamma, delta, the nine traces -> 3 x 3 Hessian
 //     C = K_qs A^-1, mu, r, S = K_qq - C K_sq + noise I -> Cholesky -> S^-1, e, log|S|, f_out, C^T e
-// and overwrites the float32 buffers the later kernels read.  A task is flagged when the pivot ratio max d_k / min d_k of
+// and overwrites the float32 buffers the later kernels read; k_cotangent64 (end of this file) then does the same for the
+// cotangent stage and dL/dZ.  A task is flagged when the pivot ratio max d_k / min d_k of
 // its sweep (a lower bound of the condition number; <= (s + noise) / noise) exceeds `thresh` for A or for Sigma_q; tasks on
 // the blocked path (> 128 points, no pivot ratio at hand) are flagged by (s + noise) / noise itself.  Everything lives in
 // a float64 region of the caller's workspace (L2-resident); plain loops - this is the slow path, it only has to be right.
