@@ -72,6 +72,8 @@ struct SweepSmemBlk {
 #if ADKF_STAMP
     unsigned long long stamp[(NT / 64) * 16];
 #endif
+    static constexpr int SCRATCH_FLOATS = 3 * B * NMAX;
+    __device__ __forceinline__ float* scratch() { return &cross[0][0][0]; }   // free for the caller between two sweeps
 };
 
 __device__ __forceinline__ float fast_rcp(float p) {
@@ -380,9 +382,16 @@ template <int NMAX, int NT> struct Sweep : SweepBlk<NMAX, NT> {};
 
 }  // namespace adkf
 
+// 128 points x 512 threads: ADKF_SWEEP_M (default) = rank-4 updates on the matrix pipe (factor_m.h); ADKF_SWEEP_M=0 keeps the
+// VALU variant of factor_w.h, ADKF_SWEEP_M=0 ADKF_SWEEP_W=0 the blocked one above, for A/B measurements.
+#ifndef ADKF_SWEEP_M
+#define ADKF_SWEEP_M 1
+#endif
 #ifndef ADKF_SWEEP_W
 #define ADKF_SWEEP_W 1
 #endif
-#if ADKF_SWEEP_W
+#if ADKF_SWEEP_M
+#include "factor_m.h"
+#elif ADKF_SWEEP_W
 #include "factor_w.h"
 #endif

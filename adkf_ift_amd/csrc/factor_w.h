@@ -47,6 +47,8 @@ template <> struct SweepSmem<128, 512> {
 #if ADKF_STAMP
     unsigned long long stamp[8 * 16];
 #endif
+    static constexpr int SCRATCH_FLOATS = NSLOT * 4 * 128;
+    __device__ __forceinline__ float* scratch() { return &cross[0][0][0]; }   // free for the caller between two sweeps
 };
 
 #if ADKF_STAMP   // diagnostic build (tools/sweepw_bench.hip -DADKF_STAMP=<step>): s_memtime of the phases of block step <step>, per wave

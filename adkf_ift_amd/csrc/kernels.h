@@ -481,8 +481,8 @@ __global__ __launch_bounds__(NT) void k_outer_factor(OuterArgs a) {
     // at 128 x 128)
     {
         constexpr int PARTS = NMAX >= 64 ? NT / NMAX : 1, COLS = NT / PARTS;
-        static_assert(PARTS == 1 || sizeof(sm.cross) >= sizeof(float) * NT, "the partial sums reuse the sweep's LDS slots");
-        float* part_s = &sm.cross[0][0][0];
+        static_assert(PARTS == 1 || SweepSmem<NMAX, NT>::SCRATCH_FLOATS >= NT, "the partial sums reuse the sweep's LDS slots");
+        float* part_s = sm.scratch();
         const int jl = tid % COLS, part = tid / COLS;
         const int per = (m + PARTS - 1) / PARTS, i_lo = part * per, i_hi = min(m, i_lo + per);
         for (int jb = 0; jb < n; jb += COLS) {   // n is the SUPPORT count: it may exceed NMAX (which follows the query count)
