@@ -303,7 +303,9 @@ __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
     if (m <= 0) return;
 
     // ---- outer: C, mu, r, S, S^-1, e, f_out, C^T e   (oracle/closed_form.py::outer_stage)
-    const float* yq = a.y_q + (size_t)t * ldq;
+    // (the labels of the query points exist at level 2 only: adkf_predict's batch may carry y_q = NULL, and level 1 - C and mu -
+    // does not read them)
+    const float* yq = a.y_q ? a.y_q + (size_t)t * ldq : nullptr;
     for (int e = tid; e < m * n; e += R64_NT) {
         const int i = e / n, j = e % n;
         double k0, k1, k2; kappa3_d(kind, DDqs[(size_t)i * ld + j] * il2, k0, k1, k2);
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
     for (int i = tid; i < m; i += R64_NT) {
         double s = 0.0;
         for (int j = 0; j < n; ++j) s += B1[(size_t)i * ld + j] * v_al[j];
-        v_mu[i] = s; v_r[i] = (double)yq[i] - s;
+        v_mu[i] = s; v_r[i] = yq ? (double)yq[i] - s : 0.0;
     }
     __syncthreads();
     if (a.C) {

@@ -27,6 +27,7 @@ import math
 import os
 import socket
 import subprocess
+import tempfile
 import sys
 import time
 
@@ -70,21 +71,46 @@ def _free_port() -> int:
     return port
 
 
-def launch_ranks(n: int, argv) -> int:
-    """Parent of a self-launched multi-GPU run.  Touches no GPU API (torch is not even imported here)."""
+def launch_ranks(n: int, argv, timeout_s: float = 3000.0) -> int:
+    """Parent of a self-launched multi-GPU run.  Touches no GPU API (torch is not even imported here).  Polls ALL children:
+    the first rank that exits non-zero (or the wall-clock limit) ends the run - the siblings, which would wait for it in the
+    rendezvous or in an all-reduce for ever, are terminated (these exact child processes) and that status is returned."""
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        rc = rc or p.returncode
-    sys.stdout.write(out.decode())
+        # rank 0's stdout is the result line: it goes to a temporary file (a pipe nobody drains could fill up and block the rank)
+        out0 = tempfile.TemporaryFile() if r == 0 else None
+        procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                       stdout=out0 if r == 0 else subprocess.DEVNULL), out0))
+    deadline = time.monotonic() + timeout_s
+    rc = 0
+    while True:
+        codes = [p.poll() for p, _ in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            rc = 124
+            sys.stderr.write(f"bench.py: ranks still running after {timeout_s:.0f} s\n")
+            break
+        time.sleep(0.05)
+    for p, _ in procs:
+        if p.poll() is None:
+            p.terminate()
+    for p, _ in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    f0 = procs[0][1]
+    f0.seek(0)
+    sys.stdout.write(f0.read().decode())
     sys.stdout.flush()
     return rc
 
@@ -97,6 +123,8 @@ def dry_run(args, rank: int, world: int):
     import torch
     import torch.distributed as dist
 
+    if os.environ.get("ADKF_BENCH_DRYRUN_FAIL_RANK") == str(rank):   # (tests/test_bench_launcher.py: a rank that dies before the rendezvous)
+        raise SystemExit(3)
     if world > 1:
         dist.init_process_group(os.environ.get("ADKF_BENCH_BACKEND", "gloo"))
     T = args.global_tasks // world if args.global_tasks else args.tasks

@@ -50,6 +50,17 @@ def test_mismatch_between_gpus_and_world_size_is_refused():
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
 
 
+def test_a_dead_rank_ends_the_run_instead_of_hanging_it():
+    """Rank 1 exits before the rendezvous: rank 0 would wait for it for ever - the parent must notice, end rank 0 and return
+    the dead rank's status."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--dry-run"], env=_env(ADKF_BENCH_DRYRUN_FAIL_RANK="1"),
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert time.monotonic() - t0 < 200
+
+
 def test_metric_string_follows_the_configuration():
     sys.path.insert(0, ROOT)
     import bench

@@ -36,20 +36,38 @@ def _random_case(rng):
     return N, Nq, d, kind, regression, n_s, n_q
 
 
-@pytest.mark.parametrize("chunk", range(4))     # 4 x 15 cases: one test per chunk keeps the suite's output alive (~90 s each)
-def test_random_shapes_against_the_oracle(dev, chunk):
+@pytest.fixture(scope="module")
+def oracle_pool():
+    """CPU-only worker processes for the float64 oracle side (fresh interpreters: "spawn"; they never touch the GPU)."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+
+    from _stress_oracle import worker_init
+    # (four workers: with this process that stays inside the GPU box's bound of 6 processes on the card even if a worker's
+    # runtime should open the device in spite of worker_init hiding it)
+    pool = ProcessPoolExecutor(max_workers=4, mp_context=mp.get_context("spawn"), initializer=worker_init)
+    yield pool
+    pool.shutdown(wait=True, cancel_futures=True)
+
+
+@pytest.mark.parametrize("chunk", range(4))     # 4 x 15 cases, one test per chunk
+def test_random_shapes_against_the_oracle(dev, chunk, oracle_pool):
+    """The device runs its 15 cases first (fit, hypergradient, prediction); the float64 oracle side of the 45 tasks - evaluated
+    AT THE DEVICE's fitted point - is then computed by the worker pool (tests/_stress_oracle.py), which is what used to take
+    ~90 s per chunk sequentially."""
     from adkf_ift_amd import gp_ops
     from adkf_ift_amd.synthetic import make_tasks
-    from oracle import gp_oracle as O
+    from _stress_oracle import oracle_bundle
 
     rng = np.random.default_rng(20260)
-    worst, worst32, failures = {}, {}, []
+    worst, worst32, failures, jobs = {}, {}, [], []
+    n_cmp = n_e32_branch = 0
     for case in range(15 * chunk + 15):
         N, Nq, d, kind, regression, n_s, n_q = _random_case(rng)
         if case < 15 * chunk:
             continue
         desc = dict(case=case, N=N, Nq=Nq, d=d, kind=kind, regression=regression, n_s=n_s, n_q=n_q)
-        print("case", desc, flush=True)      # (progress: the oracle side takes several seconds per case)
+        print("case", desc, flush=True)
         tasks = make_tasks(3, N, d, N_q=Nq, regression=regression, first_task=100 * case)
         Zs, Zq = tasks.features()
         Zs, Zq, ys, yq = Zs.clone(), Zq.clone(), tasks.y_s.clone(), tasks.y_q.clone()
@@ -71,60 +89,47 @@ def test_random_shapes_against_the_oracle(dev, chunk):
         assert int(info.abs().max()) == 0
         for t in range(3):
             n, m = n_s[t], n_q[t]
-            zs, zq = Zs[t, :n], Zq[t, :m]
-            p0, opri = O.init_phi(zs.double(), regression, True)
-            assert abs(l0[t].item() - O.median_lengthscale_init(zs.double()).item()) <= 1e-5 * l0[t].item(), desc
-            assert np.abs(phi0[t].cpu().numpy() - p0.numpy()).max() <= 1e-4, desc
-            q = O.full_reference_quantities(zs, ys[t, :n], zq, yq[t, :m], phi[t].double().cpu(), opri, kind)
-            # the optimiser: no worse than the float64 L-BFGS-B optimum
-            f_star = float(O.f_inner(zs.double(), ys[t, :n].double(), O.fit_phi(zs.double(), ys[t, :n].double(), p0, opri, kind)[0], opri, kind))
-            # (judged on the float64 value AT the device's point: the fp32 value the device reports is compared below)
-            assert q["f_in"] <= f_star + 1e-5 * abs(f_star) + 2e-6, (desc, t, q["f_in"], f_in[t].item(), f_star)
+            assert float(out["dZ_s"][t, n:].abs().max() if n < N else 0.0) == 0.0, desc
+            assert float(out["dZ_q"][t, m:].abs().max() if m < Nq else 0.0) == 0.0, desc
             got = {"f_in": f_in[t].item(), "H": out["H"][t].cpu().numpy(), "f_out": out["f_out"][t].item(),
                    "g_out": out["g_phi"][t].cpu().numpy(), "v": out["v"][t].cpu().numpy(),
                    "dZs_total": out["dZ_s"][t, :n].cpu().numpy(), "dZq_total": out["dZ_q"][t, :m].cpu().numpy(),
                    "pred_mean": mean[t, :m].cpu().numpy(), "pred_var": var[t, :m].cpu().numpy()}
-            # Tolerance: 1e-4 (north star) on every output of every case - no allowance for ill-conditioning - or, where the
-            # SAME restatement run in float32 with Cholesky solves on the CPU (what the reference's GPyTorch path does) cannot
-            # do better, 4x that float32 error.  `slack` only accounts for outputs that are themselves sums of cancelling
-            # terms (f_out, grad_phi f_out, v): their error is measured against the size of the terms.
-            noise, os_, ls = O.transform_phi(phi[t].double().cpu())
-            A = O.kernel_matrix(zs.double(), zs.double(), os_, ls, kind) + noise * torch.eye(n, dtype=torch.float64)
-            cond = max(float(torch.linalg.cond(A)), float(np.linalg.cond(q["pred_cov"])))
-            well = cond <= 100.0
-            O.DT = torch.float32
-            try:
-                q32 = O.full_reference_quantities(zs, ys[t, :n], zq, yq[t, :m], phi[t].cpu(), opri, kind)
-            finally:
-                O.DT = torch.float64
-            # grad_phi f_out is a difference of traces of the size of f_out that nearly cancel for a well-fitted task
-            # (seen: |g| = 0.046 at f_out = 9.9), and the explicit A^-1 of the sweep carries eps32 * cond(A) into each of
-            # them: g_out is held to 1e-4 of max(|g_out|, 0.01 |f_out|), and v = H^-1 g_out to what that allows.
-            g_floor = 1e-2 * abs(q["f_out"])
-            # f_out = (quad + logdet + m log 2pi) / 2 is itself a sum that can cancel (seen: 0.55 from terms of 58, -114, 57):
-            # its error is measured against the size of the terms
-            ld_q = float(np.linalg.slogdet(q["pred_cov"])[1])
-            quad = 2.0 * q["f_out"] - ld_q - m * math.log(2.0 * math.pi)
-            terms = 0.5 * (abs(quad) + abs(ld_q) + m * math.log(2.0 * math.pi))
-            slack = {"f_out": max(1.0, terms / abs(q["f_out"])),
-                     "g_out": max(1.0, g_floor / np.abs(q["g_out"]).max()),
-                     # v = H^-1 g_out: whatever absolute error g_out is allowed, times |H^-1|_inf
-                     "v": max(1.0, np.abs(np.linalg.inv(q["H"])).sum(1).max() * max(g_floor, np.abs(q["g_out"]).max())
-                              / np.abs(q["v"]).max())}
-            for k, v in got.items():
-                e = _rel(v, q[k])
-                e32 = _rel(q32[k], q[k])
-                tol = max(TOL * slack.get(k, 1.0), 4.0 * e32)
-                worst[k] = max(worst.get(k, 0.0), e / tol)
-                if e > 0.1 * TOL:
-                    kk = ("well " if well else "ill ") + k
-                    worst32[kk] = max(worst32.get(kk, 0.0), float("%.1e" % e))
-                if e > tol:
-                    failures.append((case, t, k, float("%.2e" % e), float("%.2e" % e32), float("%.1e" % cond), n, m, d, kind))
-            assert float(out["dZ_s"][t, n:].abs().max() if n < N else 0.0) == 0.0, desc
-            assert float(out["dZ_q"][t, m:].abs().max() if m < Nq else 0.0) == 0.0, desc
+            fut = oracle_pool.submit(oracle_bundle, (Zs[t, :n].clone(), ys[t, :n].clone(), Zq[t, :m].clone(), yq[t, :m].clone(),
+                                                     phi[t].cpu().clone(), kind, regression))
+            jobs.append((desc, t, n, m, d, kind, got, l0[t].item(), phi0[t].cpu().numpy(), fut))
+    for desc, t, n, m, d, kind, got, l0_dev, phi0_dev, fut in jobs:
+        o = fut.result(timeout=600)
+        q = o["q"]
+        assert abs(l0_dev - o["l0"]) <= 1e-5 * l0_dev, desc
+        assert np.abs(phi0_dev - o["p0"]).max() <= 1e-4, desc
+        # the optimiser: no worse than the float64 L-BFGS-B optimum (judged on the float64 value AT the device's point)
+        assert float(q["f_in"]) <= o["f_star"] + 1e-5 * abs(o["f_star"]) + 2e-6, (desc, t, float(q["f_in"]), got["f_in"], o["f_star"])
+        # Tolerance: 1e-4 (north star) on every output of every case - no allowance for ill-conditioning - or, where the SAME
+        # restatement run in float32 with Cholesky solves on the CPU (what the reference's GPyTorch path does) cannot do
+        # better, 4x that float32 error.  `slack` only accounts for outputs that are themselves sums of cancelling terms:
+        # f_out = (quad + logdet + m log 2pi) / 2 (seen: 0.55 from terms of 58, -114, 57: measured against the size of the
+        # terms); grad_phi f_out, a difference of traces of the size of f_out that nearly cancel for a well-fitted task (seen:
+        # |g| = 0.046 at f_out = 9.9: held to 1e-4 of max(|g_out|, 0.01 |f_out|)); and v = H^-1 g_out (whatever absolute error
+        # g_out is allowed, times |H^-1|_inf).  How many comparisons pass ONLY through the 4 x e32 branch is counted and listed.
+        well = o["cond"] <= 100.0
+        for k, v in got.items():
+            e, e32 = _rel(v, q[k]), o["e32"][k]
+            tol_plain = TOL * o["slack"].get(k, 1.0)
+            tol = max(tol_plain, 4.0 * e32)
+            n_cmp += 1
+            if e > tol_plain and e <= tol:
+                n_e32_branch += 1
+                print("passes through 4 x e32 only (case, task, output, err, e32, cond):", desc["case"], t, k, "%.2e" % e, "%.2e" % e32, "%.1e" % o["cond"])
+            worst[k] = max(worst.get(k, 0.0), e / tol)
+            if e > 0.1 * TOL:
+                kk = ("well " if well else "ill ") + k
+                worst32[kk] = max(worst32.get(kk, 0.0), float("%.1e" % e))
+            if e > tol:
+                failures.append((desc["case"], t, k, float("%.2e" % e), float("%.2e" % e32), float("%.1e" % o["cond"]), n, m, d, kind))
     print("worst error / tolerance:", {k: float("%.2f" % v) for k, v in worst.items()})
     print("worst relative error by regime (where > 1e-5):", worst32)
+    print("comparisons: %d, of which %d needed the 4 x e32 branch" % (n_cmp, n_e32_branch))
     for f_ in failures:
         print("FAIL (case, task, output, err, fp32-autograd err, cond, n, m, d, kind):", f_)
     assert not failures, failures[:5]
@@ -199,3 +204,11 @@ def test_ill_conditioned_regression_task_is_resolved_stably(dev):
     mean, var, _, _ = gp_ops.predict(b, phi)
     assert _rel(mean[0].cpu().numpy(), q["pred_mean"]) <= 1e-4
     assert _rel(var[0].cpu().numpy(), q["pred_var"]) <= 1e-4
+    # the same prediction on a batch WITHOUT query labels (models._posterior, evaluate.meta_test and bayes_opt build theirs that
+    # way): this task is on the float64 path, whose level 1 - C and mu - must not touch y_q (it read through the null pointer)
+    b_nolab = gp_ops.GPBatch(zs[None].to(dev), ys[None].to(dev), b.priors, "rbf", Z_q=zq[None].to(dev), y_q=None)
+    mean2, var2, _, info2 = gp_ops.predict(b_nolab, phi)
+    torch.cuda.synchronize()
+    gp_ops.check_info(info2)
+    assert _rel(mean2[0].cpu().numpy(), q["pred_mean"]) <= 1e-4
+    assert _rel(var2[0].cpu().numpy(), q["pred_var"]) <= 1e-4
