@@ -169,17 +169,39 @@ int stage_dist(const adkf_batch_t* b, const Workspace& w, bool with_query, hipSt
     return 0;
 }
 
-template <int NMAX, int NT>
-void launch_inner_k(const InnerArgs& a, hipStream_t st) {
-    constexpr size_t cache_bytes = sizeof(float) * NMAX * NMAX;   // the kappa' u cache of inner.h (one float per matrix element)
+int num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();
+    return n;
+}
+
+template <int NMAX, int NT, bool LOW>
+void launch_inner_kl(const InnerArgs& a, hipStream_t st) {
+    constexpr size_t cache_bytes = sizeof(float) * NMAX * NMAX;   // the kappa' u cache of inner.h (one float per matrix element), or D^2 (LOW)
     static const bool attr_set = [] {   // 64 KB of dynamic LDS on top of the static part needs the opt-in
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner<NMAX, NT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cache_bytes);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner<NMAX, NT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cache_bytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner<NMAX, NT, 0, LOW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cache_bytes);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inner<NMAX, NT, 1, LOW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cache_bytes);
         return true;
     }();
     (void)attr_set;
-    if (a.kind == ADKF_KERNEL_RBF) k_inner<NMAX, NT, 0><<<grid_for(a.T, 1), NT, cache_bytes, st>>>(a);
-    else k_inner<NMAX, NT, 1><<<grid_for(a.T, 1), NT, cache_bytes, st>>>(a);
+    if (a.kind == ADKF_KERNEL_RBF) k_inner<NMAX, NT, 0, LOW><<<grid_for(a.T, 1), NT, cache_bytes, st>>>(a);
+    else k_inner<NMAX, NT, 1, LOW><<<grid_for(a.T, 1), NT, cache_bytes, st>>>(a);
+}
+
+// ADKF_INNER_LOWREG (read once): 1 / 0 force the two-tasks-per-CU variant of the 128-point fit on / off; unset: taken when the
+// batch has more tasks than the chip has CUs (up to that every task has a CU to itself and the resident variant is 20 % faster;
+// beyond it the resident variant needs a second round of workgroups, the low-register one runs two tasks per CU side by side)
+template <int NMAX, int NT>
+void launch_inner_k(const InnerArgs& a, hipStream_t st) {
+    if constexpr (NMAX == 128) {
+        static const int forced = [] { const char* e = getenv("ADKF_INNER_LOWREG"); return e ? atoi(e) : -1; }();
+        const bool low = forced >= 0 ? forced != 0 : a.T > num_cus();
+        if (low) { launch_inner_kl<NMAX, NT, true>(a, st); return; }
+    }
+    launch_inner_kl<NMAX, NT, false>(a, st);
 }
 
 LgMat lg_mat(const Workspace& w, float* M, int ld, const int32_t* n_arr, const FitShared* fit, int T) {

@@ -211,7 +211,14 @@ template <> struct Sweep<128, 512> {
         const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4, a = p & 3;
         if (g == gn && (p >> 2) == gn) {
             *reinterpret_cast<float4*>(&sm.dinv[SW][a][0]) = make_float4(D[0], D[1], D[2], D[3]);
-            if (a == 0) *reinterpret_cast<float4*>(&sm.pivs[16 * WN + 4 * gn]) = make_float4(piv[0], piv[1], piv[2], piv[3]);
+            if (a == 0) {
+                // (the index is formed HERE from an opaque copy of gn: hoisted out of the unrolled sweep this uniform address
+                // sat in a VGPR that the 128-register build of k_inner spilled - one scratch reload per block step, on the
+                // owner's way to the barrier)
+                int gi = gn;
+                asm volatile("" : "+s"(gi));
+                *reinterpret_cast<float4*>(&sm.pivs[16 * WN + 4 * gi]) = make_float4(piv[0], piv[1], piv[2], piv[3]);
+            }
         }
     }
 

@@ -40,21 +40,32 @@ struct InnerArgs {
     float gtol, ftol;
 };
 
-// The squared distances of this thread's block: register-resident for the whole fit.
-template <int NMAX, int NT>
+// The squared distances of this thread's block.  LOW = false: register-resident for the whole fit.  LOW = true: parked in the
+// kernel's dynamic LDS (lane-private slots, conflict-free) and read back by the kernel build and the trace pass of every
+// evaluation, so that the fit lives in <= 128 registers and TWO tasks share a CU (k_inner below): the LDS then carries D^2
+// instead of kappa'(u) u, which the trace pass recomputes.
+template <int NMAX, int NT, bool LOW = false>
 struct D2Block {
     using SW = Sweep<NMAX, NT>;
     static constexpr int RB = SW::RB, CB = SW::CB;
-    float reg[RB][CB];
-    __device__ __forceinline__ void init(const float* D2, int ld, int n) {
+    float reg[LOW ? 1 : RB][LOW ? 1 : CB];
+    float* lds;
+    __device__ __forceinline__ void init(const float* D2, int ld, int n, float* lds_) {
         const bool vec = rows_aligned16(D2, ld);
+        lds = lds_ + threadIdx.x;
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int i = SW::row(r);
-            load_segment<CB>(D2 + (size_t)i * ld, SW::col(0), n, i < n, vec, reg[r]);   // exactly symmetric by construction (ProbDist mirrors its tiles); 0 outside n x n
+            float seg[CB];
+            load_segment<CB>(D2 + (size_t)i * ld, SW::col(0), n, i < n, vec, seg);   // exactly symmetric by construction (ProbDist mirrors its tiles); 0 outside n x n
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                if (LOW) lds[(r * CB + c) * NT] = seg[c];
+                else reg[LOW ? 0 : r][LOW ? 0 : c] = seg[c];
+            }
         }
     }
-    __device__ __forceinline__ float get(int r, int c) const { return reg[r][c]; }
+    __device__ __forceinline__ float get(int r, int c) const { return LOW ? lds[(r * CB + c) * NT] : reg[LOW ? 0 : r][LOW ? 0 : c]; }
 };
 
 // f_inner = (nll - log priors) / n and its raw-parameter gradient from the five reductions
@@ -126,9 +137,9 @@ __device__ __forceinline__ void inner_finalize_wave(int n, const float* x, const
     extra[6] = gt0; extra[7] = gt1; extra[8] = gt2;
 }
 
-template <int NMAX, int NT, int KIND>
+template <int NMAX, int NT, int KIND, bool LOW = false>
 struct InnerEval {
-    using D2 = D2Block<NMAX, NT>;
+    using D2 = D2Block<NMAX, NT, LOW>;
     using SW = Sweep<NMAX, NT>;
     static constexpr int RB = SW::RB, CB = SW::CB;
 
@@ -178,7 +189,7 @@ struct InnerEval {
                         k1u = in ? k1u : 0.f;
                     }
                     m[r][c] = mv;
-                    cache[(r * CB + c) * NT + tid] = k1u;   // lane-private slots, conflict-free
+                    if (!LOW) cache[(r * CB + c) * NT + tid] = k1u;   // lane-private slots, conflict-free
                 }
             }
         } else
@@ -197,7 +208,7 @@ struct InnerEval {
                     k1u = k1 * u;
                 }
                 else m[r][c] = (i == j) ? 1.f : 0.f;
-                cache[(r * CB + c) * NT + tid] = k1u;   // lane-private slots, conflict-free
+                if (!LOW) cache[(r * CB + c) * NT + tid] = k1u;   // lane-private slots, conflict-free
             }
         }
         ADKF_ES(1);
@@ -219,8 +230,33 @@ struct InnerEval {
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int c = 0; c < CB; ++c) {
-                // dK/dl = s kappa'(u) u (-2/l): kappa'(u) u was parked in LDS by the build (zero outside n x n)
-                const float G = os * gl * cache[(r * CB + c) * NT + tid];
+                // dK/dl = s kappa'(u) u (-2/l): kappa'(u) u was parked in LDS by the build (zero outside n x n); the
+                // two-tasks-per-CU variant keeps D^2 there instead and forms it again, with the build's own arithmetic
+                float k1u_;
+                if (!LOW) k1u_ = cache[(r * CB + c) * NT + tid];
+                else {
+                    const float d2v = d2.get(r, c);
+                    const bool in = SW::row(r) < n && j0 + c < n;
+                    if (fast) {
+                        // (the build's expressions, letter for letter: the two variants must run the same fit)
+                        const float ce = -0.72134752044448170368f * il2, ck = -0.5f * il2, cm = -3.2259784787f;
+                        if (KIND == 0) {
+                            const float k0 = __builtin_amdgcn_exp2f(d2v * ce);
+                            k1u_ = k0 * (d2v * ck);
+                        } else {
+                            const float u = d2v * il2, sr = SQRT5 * __builtin_amdgcn_sqrtf(u);
+                            const float e = __builtin_amdgcn_exp2f(sr * (cm / SQRT5));
+                            k1u_ = -(5.f / 6.f) * (1.f + sr) * e * u;
+                        }
+                    } else {
+                        const float u = d2v * il2;
+                        float k0, k1, k2;
+                        kappa3<KIND, false>(u, k0, k1, k2);
+                        k1u_ = k1 * u;
+                    }
+                    k1u_ = in ? k1u_ : 0.f;
+                }
+                const float G = os * gl * k1u_;
                 acc[0] -= m[r][c] * G;
                 acc[1] += ai[r] * aj[c] * G;
                 if (SW::row(r) == j0 + c && SW::row(r) < n) acc[2] -= m[r][c];
@@ -410,14 +446,17 @@ __device__ __forceinline__ void write_inner_scal(float* sc, const float* xe, flo
     sc[S_GT0] = extra[6]; sc[S_GT1] = extra[7]; sc[S_GT2] = extra[8];
 }
 
-template <int NMAX, int NT, int KIND>
-__global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
-    using EV = InnerEval<NMAX, NT, KIND>;
+// LOW = true (128 points only; launch_inner_k picks it when the batch has more tasks than the chip has CUs): the fit in <= 128
+// registers - 4 waves per SIMD, i.e. two workgroups per CU - with D^2 in LDS (D2Block above).  A block step of the sweep keeps
+// the matrix pipe busy for less than half of its duration (factor_m.h), so a second task on the same CU fills the rest.
+template <int NMAX, int NT, int KIND, bool LOW = false>
+__global__ __launch_bounds__(NT, LOW ? 4 : 1) void k_inner(InnerArgs a) {
+    using EV = InnerEval<NMAX, NT, KIND, LOW>;
     using SW = Sweep<NMAX, NT>;
     constexpr int RB = SW::RB, CB = SW::CB;
     __shared__ SweepSmem<NMAX, NT> sm;
     __shared__ FitShared fs;
-    extern __shared__ float inner_cache[];   // NT * RB * CB floats (launch_inner_k sets the dynamic size)
+    extern __shared__ float inner_cache[];   // NT * RB * CB floats (launch_inner_k sets the dynamic size): kappa'(u) u, or D^2 (LOW)
     int t, tile;
     if (!task_tile(a.T, 1, t, tile)) return;
     const int tid = threadIdx.x;
@@ -426,7 +465,7 @@ __global__ __launch_bounds__(NT) void k_inner(InnerArgs a) {
     const int j0 = SW::bc() * CB;
 
     typename EV::D2 d2;
-    d2.init(D2, a.ld, n);
+    d2.init(D2, a.ld, n, inner_cache);
     float m[RB][CB];
     if (tid < NMAX) sm.vec_in[tid] = (tid < n) ? a.y_s[(size_t)t * a.ld + tid] : 0.f;
     float pri[4];

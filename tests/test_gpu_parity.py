@@ -290,3 +290,37 @@ def test_fixed_evaluation_budget_does_not_iterate_past_convergence(golden_dir, d
         assert torch.isfinite(phi).all()
         assert (phi[done] - ref[done]).abs().max().item() <= 1e-3
         assert (f[done] - f_ref[done]).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("kernel", ["rbf", "matern"])
+def test_two_tasks_per_cu_fit_equals_the_resident_one(dev, kernel):
+    """More tasks than the chip has CUs: adkf_fit takes the <= 128-register build of k_inner (two workgroups per CU, D^2 in LDS,
+    kappa'(u) u formed again in the trace pass - csrc/inner.h).  Same arithmetic in the same order, so the same tasks fitted in
+    chunks that stay below the CU count (the resident build) must give the same numbers; ragged sizes included."""
+    from adkf_ift_amd import gp_ops
+    from adkf_ift_amd.synthetic import make_tasks
+
+    T, N, d = 2 * torch.cuda.get_device_properties(dev).multi_processor_count // 2 + 44, 128, 32      # 300 on an MI355X
+    tasks = make_tasks(T, N, d, regression=(kernel == "matern"), first_task=7000)
+    Zs, _ = tasks.features()
+    n_s = torch.full((T,), N, dtype=torch.int32)
+    n_s[::7] = 97
+    n_s[3::11] = 66
+    Zs, ys = Zs.to(dev), tasks.y_s.to(dev)
+
+    def run(lo, hi):
+        pri = torch.empty(hi - lo, 4, device=dev)
+        b = gp_ops.GPBatch(Zs[lo:hi].contiguous(), ys[lo:hi].contiguous(), pri, kernel, n_s=n_s[lo:hi].contiguous())
+        phi0, _ = gp_ops.init_params_batch(b, kernel == "matern", True)
+        b.flags = gp_ops.REUSE_DIST
+        phi, f, gn, ne, info = gp_ops.fit(b, phi0, 60)
+        gp_ops.check_info(info)
+        return phi, f, ne
+
+    phi_all, f_all, ne_all = run(0, T)
+    parts = [run(lo, min(lo + 100, T)) for lo in range(0, T, 100)]
+    phi_c, f_c, ne_c = (torch.cat([p[i] for p in parts]) for i in range(3))
+    assert torch.equal(ne_all, ne_c)
+    assert (f_all - f_c).abs().max().item() <= 1e-6 * f_c.abs().max().item(), (f_all - f_c).abs().max().item()
+    assert (phi_all - phi_c).abs().max().item() <= 1e-5, (phi_all - phi_c).abs().max().item()
+    print("two-tasks-per-CU fit vs resident: max |d f| %.2e, max |d phi| %.2e" % ((f_all - f_c).abs().max().item(), (phi_all - phi_c).abs().max().item()))
