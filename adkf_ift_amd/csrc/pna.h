@@ -29,26 +29,31 @@ __global__ __launch_bounds__(256) void k_pna_fwd(PnaArgs a) {
     const float deg = (float)(p1 - p0);
     for (int idx = threadIdx.x; idx < H * m; idx += blockDim.x) {
         const int h = idx / m, f = idx - h * m;
-        float s = 0.f, b = 0.f, mx = -INFINITY;
+        // mean and deviations in float64: the products b_e^2 and mean^2 of float32 numbers are exact there, so the difference
+        // under the relu - which cancels to ~1e-7 b^2 for nearly equal messages, where the reference's std has slope
+        // 1 / (2 sqrt(1e-7)) = 1581 - carries no rounding of this kernel's own (float32: eps b^2, i.e. as large as the 1e-7
+        // floor itself); what is left is the float32 rounding of the messages that come in
+        float s = 0.f, mx = -INFINITY;
+        double b = 0.0;
         int am = -1;
         for (int64_t p = p0; p < p1; ++p) {
             const int64_t e = a.perm[p];
             const float* row = a.msgs + ((size_t)e * H + h) * 3 * m;
             s += row[f];
-            b += row[m + f];
+            b += (double)row[m + f];
             const float c = row[2 * m + f];
             if (c > mx) { mx = c; am = (int)e; }
         }
-        const float mean = p1 > p0 ? b / deg : 0.f;
-        float dev = 0.f;
+        const double mean = p1 > p0 ? b / (double)deg : 0.0;
+        double dev = 0.0;
         for (int64_t p = p0; p < p1; ++p) {
-            const float bb = a.msgs[((size_t)a.perm[p] * H + h) * 3 * m + m + f];
-            dev += fmaxf(bb * bb - mean * mean, 0.f) + PNA_SMALL;
+            const double bb = (double)a.msgs[((size_t)a.perm[p] * H + h) * 3 * m + m + f];
+            dev += fmax(bb * bb - mean * mean, 0.0) + (double)PNA_SMALL;
         }
         float* out = a.agg + ((size_t)v * H + h) * 4 * m;
         out[f] = s;
-        out[m + f] = mean;
-        out[2 * m + f] = sqrtf(dev);
+        out[m + f] = (float)mean;
+        out[2 * m + f] = (float)sqrt(dev);
         out[3 * m + f] = p1 > p0 ? mx : 0.f;
         a.argmax[((size_t)v * H + h) * m + f] = am;
     }
@@ -66,22 +71,28 @@ __global__ __launch_bounds__(256) void k_pna_bwd(PnaArgs a) {
         const int h = idx / m, f = idx - h * m;
         const float* ag = a.agg + ((size_t)v * H + h) * 4 * m;
         const float* dg = a.d_agg + ((size_t)v * H + h) * 4 * m;
-        const float mean = ag[m + f], sd = ag[2 * m + f];
         const float d_sum = dg[f], d_mean = dg[m + f], d_std = dg[2 * m + f], d_max = dg[3 * m + f];
-        const float g = sd > 0.f ? d_std / (2.f * sd) : 0.f;
         const int am = a.argmax[((size_t)v * H + h) * m + f];
-        float cnt = 0.f;
+        // mean, the indicators [b_e^2 > mean^2] and std again in float64, exactly as the forward formed them (the stored mean
+        // and std are rounded to float32: an indicator evaluated with THAT mean can differ from the forward's)
+        double bsum = 0.0;
+        for (int64_t p = p0; p < p1; ++p) bsum += (double)a.msgs[((size_t)a.perm[p] * H + h) * 3 * m + m + f];
+        const double mean = bsum / (double)deg;
+        double dev = 0.0, cnt = 0.0;
         for (int64_t p = p0; p < p1; ++p) {
-            const float bb = a.msgs[((size_t)a.perm[p] * H + h) * 3 * m + m + f];
-            cnt += (bb * bb > mean * mean) ? 1.f : 0.f;
+            const double bb = (double)a.msgs[((size_t)a.perm[p] * H + h) * 3 * m + m + f];
+            const double x = bb * bb - mean * mean;
+            dev += fmax(x, 0.0) + (double)PNA_SMALL;
+            cnt += x > 0.0 ? 1.0 : 0.0;
         }
-        const float via_mean = (d_mean - 2.f * mean * g * cnt) / deg;
+        const double g = (double)d_std / (2.0 * sqrt(dev));
+        const double via_mean = ((double)d_mean - 2.0 * mean * g * cnt) / (double)deg;
         for (int64_t p = p0; p < p1; ++p) {
             const int64_t e = a.perm[p];
             const size_t o = ((size_t)e * H + h) * 3 * m;
-            const float bb = a.msgs[o + m + f];
+            const double bb = (double)a.msgs[o + m + f];
             a.d_msgs[o + f] = d_sum;
-            a.d_msgs[o + m + f] = ((bb * bb > mean * mean) ? 2.f * bb * g : 0.f) + via_mean;
+            a.d_msgs[o + m + f] = (float)(((bb * bb > mean * mean) ? 2.0 * bb * g : 0.0) + via_mean);
             a.d_msgs[o + 2 * m + f] = ((int)e == am) ? d_max : 0.f;
         }
     }

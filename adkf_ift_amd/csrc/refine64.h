@@ -140,6 +140,17 @@ __device__ void r64_xtx(const double* X, double* Out, int n, int ld) {
     __syncthreads();
 }
 
+// Diagnostic (adkf_float64_tasks): which tasks of the last adkf_ift_hypergrad / adkf_outer_nll_value_grad on this workspace took
+// the float64 path - the same test as in k_refine64 (level 2) below.
+__global__ void k_float64_tasks(const float* scal, int ld, int ldq, float thresh, int T, int32_t* flagged) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const float* sc = scal + (size_t)t * NSCAL;
+    const float bound = (sc[S_OS] + sc[S_NOISE]) / sc[S_NOISE];
+    const float ra = ld <= 128 ? sc[S_PIVR_A] : bound, rs = ldq <= 128 ? sc[S_PIVR_S] : bound;
+    flagged[t] = (ra > thresh || rs > thresh) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
     __shared__ double red[R64_NT / 64];
     const int t = blockIdx.x, tid = threadIdx.x;

@@ -47,6 +47,10 @@ def parse(argv=None):
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--inner-evals", type=int, default=20)
     ap.add_argument("--kernel", default="rbf", choices=["rbf", "matern"])
+    ap.add_argument("--regression", action="store_true",
+                    help="standardised real labels and the numeric-label initialisation (noise 0.01: fs_mol/utils/gp_utils.py:17, "
+                         "fs_mol/models/adaptive_dkt.py:112-119) instead of +-1 classification labels; the line then also reports "
+                         "which fraction of the tasks took the float64 path for ill-conditioned tasks")
     ap.add_argument("--converge", action="store_true", help="headline loop runs the inner fit to convergence instead of a fixed I")
     ap.add_argument("--converge-steps", type=int, default=5, help="steps of the second, run-to-convergence timed loop (0: skip)")
     ap.add_argument("--graph", action="store_true", help="replay the GP section of the step from a captured HIP graph")
@@ -199,14 +203,14 @@ def main():
 
     T = args.global_tasks // world if args.global_tasks else args.tasks
     N, Nq, d, I = args.n_support, args.n_query, args.d, args.inner_evals
-    tasks = make_tasks(T, N, d, N_q=Nq, first_task=rank * T)
+    tasks = make_tasks(T, N, d, N_q=Nq, regression=args.regression, first_task=rank * T)
     X_s, X_q, y_s, y_q = (a.to(dev) for a in (tasks.X_s, tasks.X_q, tasks.y_s, tasks.y_q))
     W = tasks.W.to(dev).clone().requires_grad_(True)
     opt = ClipAdam([W], lr=1e-4)  # fs_mol/adaptive_dkt_train.py --lr default; mean + clip + Adam in the library (2 launches)
 
     def step_cfg(converge: bool) -> MetaStepConfig:
         return MetaStepConfig(gp_kernel=args.kernel, inner_max_evals=(200 if converge else I),
-                              inner_exact_evals=not converge, clip_value=1.0, use_ard=args.ard)
+                              inner_exact_evals=not converge, clip_value=1.0, use_ard=args.ard, use_numeric_labels=args.regression)
 
     cfg = step_cfg(args.converge)
     backend = GraphedGPBackend() if args.graph else None
@@ -260,7 +264,7 @@ def main():
         with torch.no_grad():
             feats = features()
             Zs, Zq = feats[0], feats[1]
-        phi0, pri, _ = gp_ops.init_params(Zs)
+        phi0, pri, _ = gp_ops.init_params(Zs, use_numeric_labels=args.regression)
         b = gp_ops.GPBatch(Zs, y_s, pri, args.kernel, Z_q=Zq, y_q=y_q)
         phi_f, f_in, gn, nev, info = gp_ops.fit(b, phi0, cfg.inner_max_evals, exact_evals=cfg.inner_exact_evals)
         out = gp_ops.ift_hypergrad(b, phi_f)
@@ -275,6 +279,8 @@ def main():
             e_dz = max(e_dz, float((out["dZ_s"][t].double().cpu() - ref).abs().max() / ref.abs().max()))
         parity = {"logml_rel_err": e_in, "outer_nll_rel_err": e_out, "ift_dZ_rel_err": e_dz,
                   "fit_max_grad": float(gn.max().item()), "fit_mean_evals": float(nev.float().mean().item())}
+        if not args.ard:
+            parity["float64_path_fraction"] = float(gp_ops.float64_tasks(b).float().mean().item())
         if converged is not None:
             _, _, gn_c, nev_c, _ = gp_ops.fit(b, phi0, 200, exact_evals=False)
             converged["mean_evals"] = float(nev_c.float().mean().item())
@@ -289,6 +295,20 @@ def main():
                         "sample": f"first {n_done} tasks of the same workload, sequential, float32 torch restatement of the "
                                   f"reference algorithm (SciPy L-BFGS-B to convergence, mean {nfev:.0f} evals; dense "
                                   f"Hessian + nested-Jacobian hypergradient), torch threads = {cores}"}
+
+    # the second CPU baseline: the C++ twin of the C ABI (OpenMP over tasks, float64 inside), same unit of work
+    # as the GPU step (fresh parameters, exactly I evaluations, IFT hypergradient) on a prefix of the same workload
+    cpu_twin = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.ard:
+        try:
+            from oracle import cpu_twin as TW
+            rate, n_done, threads = TW.time_tasks(tasks, gp_ops.kernel_id(args.kernel), I, budget_s=args.cpu_baseline_seconds, regression=args.regression)
+            cpu_twin = {"value": rate, "unit": "tasks/s", "cores": threads, "kind": "twin",
+                        "sample": f"first {n_done} tasks of the same workload through libadkf_gp_cpu.so (C++ twin of the C ABI, "
+                                  f"adkf_ift_amd/csrc/cpu/adkf_gp_cpu.cpp: OpenMP over tasks, float64 inside): adkf_init_params -> "
+                                  f"adkf_fit (exactly {I} evaluations) -> adkf_ift_hypergrad, {threads} threads"}
+        except Exception as e:   # a missing host compiler must not cost the GPU line
+            print(f"[bench] CPU twin not timed ({type(e).__name__}: {e})", file=sys.stderr)
 
     if rank == 0:
         fl = roofline.flops_per_task(N, Nq, d, I)
@@ -331,7 +351,7 @@ def main():
             "metric": metric_name(N, d), "value": value, "unit": "tasks/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if args.global_tasks else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{cfg_name}: {T} tasks/GPU/step, N_support={N}, N_query={Nq}, d={d}, kernel={args.kernel}, "
+            "config": {"workload": f"{cfg_name}{' (regression labels, noise 0.01)' if args.regression else ''}: {T} tasks/GPU/step, N_support={N}, N_query={Nq}, d={d}, kernel={args.kernel}, "
                                    f"inner fit = {'to convergence' if args.converge else f'exactly {I} MLL value+grad evals'}, "
                                    "IFT hypergradient, theta = W[d,d] linear feature map, Adam + clip 1.0",
                        "tasks_per_gpu": T, "global_tasks": T * world, "parallelism": f"task-sharded dp{world}",
@@ -344,6 +364,7 @@ def main():
             "converged": converged,
             "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             "cpu_baseline": cpu_baseline,
+            "cpu_baseline_twin": cpu_twin,
             "parity": parity,
         }
         print(json.dumps(line), flush=True)

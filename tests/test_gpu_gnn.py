@@ -43,10 +43,12 @@ def test_default_width_extractor_forward_and_gradients_vs_oracle(dev):
     (got * w.float().to(dev)).sum().backward()
     mine = grads_under_reference_names(model)
     scale = max(v.grad.abs().max().item() for v in sd.values() if v.grad is not None)
-    # Yardstick for "what float32 can do" on this network: the same extractor in float32 through plain PyTorch ops on the
-    # CPU.  The reference's std aggregation sqrt(relu(E[x^2] - E[x]^2) + 1e-7) (fs_mol/modules/gnn.py:231-240) has slope
-    # 1 / (2 sqrt(1e-7)) = 1581 at zero variance (every node with a single incoming message), so float32 rounding of the
-    # argument moves gradients by ~1e-3 of the largest entry whatever the implementation.
+    # The reference's std aggregation sqrt(sum_e relu(b_e^2 - mean^2) + 1e-7) (fs_mol/modules/gnn.py:231-240) has slope
+    # 1 / (2 sqrt(1e-7)) = 1581 at zero variance, so for nearly equal incoming messages the float32 rounding of the MESSAGES
+    # (1e-7 b^2 against a floor of 1e-7) moves the gradient in any float32 implementation.  The fused kernels (csrc/pna.h) form
+    # mean, deviations and the indicators in float64 - exact for float32 inputs - which leaves only that input rounding: 2.9e-4
+    # of the largest gradient entry here, against 5.7e-4 with float32 accumulation (round 2) and 8.5e-4 for float32 PyTorch on
+    # the CPU (the yardstick below, printed, no longer part of the tolerance).  Fixed bound: 4e-4.
     cpu32 = GraphFeatureExtractor(cfg)
     cpu32.load_reference_state_dict({k: v.detach().float() for k, v in sd.items()})
     c32 = batch.to("cpu")
@@ -54,7 +56,7 @@ def test_default_width_extractor_forward_and_gradients_vs_oracle(dev):
     (cpu32(c32) * w.float()).sum().backward()
     yard = grads_under_reference_names(cpu32)
     e32 = max((yard[k].double() - v.grad).abs().max().item() / scale for k, v in sd.items() if v.grad is not None)
-    tol = max(2e-4, 2.0 * e32)
+    tol = 4e-4
     worst = 0.0
     for k, v in sd.items():
         if v.grad is None:
@@ -136,9 +138,9 @@ def test_c3_default_model_meta_step_vs_per_task_oracle_loop(dev):
             continue
         e = (mine[k].double().cpu() - v.grad).abs().max().item() / scale
         worst = max(worst, e)
-        assert e <= 5e-4, (k, e)
+        assert e <= 4e-4, (k, e)      # (see test_default_width_extractor_forward_and_gradients_vs_oracle: 2.9e-4 observed)
     for p, r in zip(model.fc.parameters(), fc):
         e = (p.grad.double().cpu() - r.grad).abs().max().item() / scale
         worst = max(worst, e)
-        assert e <= 5e-4, e
+        assert e <= 4e-4, e
     print("C3 default model: worst theta.grad error %.2e of the largest entry" % worst)
