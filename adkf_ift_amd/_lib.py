@@ -70,7 +70,7 @@ SIGNATURES = {
     "adkf_ift_hypergrad_cg": (C.c_int, [C.POINTER(Batch), C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                         C.c_void_p]),
-    "adkf_float64_tasks": (C.c_int, [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "adkf_double_path_tasks": (C.c_int, [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 

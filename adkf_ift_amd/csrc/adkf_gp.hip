@@ -917,14 +917,14 @@ int adkf_ift_hypergrad(const adkf_batch_t* b, const float* phi, int32_t flags, f
     return outer_pipeline(b, w, phi, flags, true, f_out, dZ_s, dZ_q, g_phi_out, v, H, info, static_cast<hipStream_t>(stream));
 }
 
-int adkf_float64_tasks(const adkf_batch_t* b, int32_t* flagged, void* ws, size_t ws_bytes, void* stream) {
+int adkf_double_path_tasks(const adkf_batch_t* b, int32_t* flagged, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_batch(b, true);
     if (rc) return rc;
     if (!flagged || !ws || is_ard(b)) return ADKF_E_BADARG;
     Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     (void)hipGetLastError();
-    k_float64_tasks<<<ceil_div(b->T, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(w.scal, b->ns_max, b->nq_max, w.w64 ? r64_threshold() : INFINITY, b->T, flagged);
+    k_double_path_tasks<<<ceil_div(b->T, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(w.scal, b->ns_max, b->nq_max, w.w64 ? r64_threshold() : INFINITY, b->T, flagged);
     LAUNCH_OK();
     return 0;
 }

@@ -140,9 +140,9 @@ __device__ void r64_xtx(const double* X, double* Out, int n, int ld) {
     __syncthreads();
 }
 
-// Diagnostic (adkf_float64_tasks): which tasks of the last adkf_ift_hypergrad / adkf_outer_nll_value_grad on this workspace took
+// Diagnostic (adkf_double_path_tasks): which tasks of the last adkf_ift_hypergrad / adkf_outer_nll_value_grad on this workspace took
 // the float64 path - the same test as in k_refine64 (level 2) below.
-__global__ void k_float64_tasks(const float* scal, int ld, int ldq, float thresh, int T, int32_t* flagged) {
+__global__ void k_double_path_tasks(const float* scal, int ld, int ldq, float thresh, int T, int32_t* flagged) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const float* sc = scal + (size_t)t * NSCAL;

@@ -263,14 +263,14 @@ def predict(b: GPBatch, phi: torch.Tensor, want_var=True, want_cov=False):
     return mean, var, cov, info
 
 
-def float64_tasks(b: GPBatch) -> torch.Tensor:
+def double_path_tasks(b: GPBatch) -> torch.Tensor:
     """[T] int32: 1 where the last ``ift_hypergrad`` / ``outer_nll_value_grad`` on this batch sent the task through the float64
     path (ill-conditioned tasks, csrc/refine64.h).  Diagnostic."""
     lib = _lib.load()
     flagged = _new(b, b.T, dtype=torch.int32)
     ws, nb = b.workspace()
     cb = b.c_struct()
-    _lib.check(lib.adkf_float64_tasks(C.byref(cb), _ptr(flagged), _ptr(ws), nb, _stream(b.device)), "adkf_float64_tasks")
+    _lib.check(lib.adkf_double_path_tasks(C.byref(cb), _ptr(flagged), _ptr(ws), nb, _stream(b.device)), "adkf_double_path_tasks")
     return flagged
 
 

@@ -280,7 +280,7 @@ def main():
         parity = {"logml_rel_err": e_in, "outer_nll_rel_err": e_out, "ift_dZ_rel_err": e_dz,
                   "fit_max_grad": float(gn.max().item()), "fit_mean_evals": float(nev.float().mean().item())}
         if not args.ard:
-            parity["float64_path_fraction"] = float(gp_ops.float64_tasks(b).float().mean().item())
+            parity["float64_path_fraction"] = float(gp_ops.double_path_tasks(b).float().mean().item())
         if converged is not None:
             _, _, gn_c, nev_c, _ = gp_ops.fit(b, phi0, 200, exact_evals=False)
             converged["mean_evals"] = float(nev_c.float().mean().item())

@@ -159,7 +159,7 @@ int adkf_ift_hypergrad(const adkf_batch_t* b, const float* phi, int32_t flags, f
  * Sigma_q above the threshold, csrc/refine64.h) in the last adkf_ift_hypergrad / adkf_outer_nll_value_grad on this
  * workspace, else 0.  Non-ARD batches.  No reference counterpart (GPyTorch has one precision); bench.py --regression
  * reports the fraction (fs_mol/utils/gp_utils.py:17: noise 0.01 for numeric labels is where such tasks come from). */
-int adkf_float64_tasks(const adkf_batch_t* b, int32_t* flagged, void* ws, size_t ws_bytes, void* stream);
+int adkf_double_path_tasks(const adkf_batch_t* b, int32_t* flagged, void* ws, size_t ws_bytes, void* stream);
 
 /* Workspace size for batches that carry ADKF_BATCH_ARD (a superset of adkf_workspace_bytes). */
 size_t adkf_workspace_bytes_ard(int32_t T, int32_t ns_max, int32_t nq_max, int32_t d);
