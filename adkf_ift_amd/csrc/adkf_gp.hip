@@ -332,9 +332,20 @@ void launch_refine(const TaskView& tv, const adkf_batch_t* b, const Workspace& w
                    int32_t* info, hipStream_t st, float* f_in = nullptr, float* g_in = nullptr, float* gnorm = nullptr) {
     if (!w.w64) return;
     const float thresh = r64_threshold();
+    // up to R64_LDS_POINTS points the float64 inverses run in LDS: 128 KB of dynamic shared memory (one workgroup per CU then; the
+    // kernel is a two-scalar test for everybody but the flagged tasks)
+    const bool lds_inv = w.vld <= R64_LDS_POINTS;
+    const size_t lds_bytes = lds_inv ? sizeof(double) * (size_t)w.vld * w.vld : 0;
+    static const bool attr_set = [] {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_refine64), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(double) * R64_LDS_POINTS * R64_LDS_POINTS));
+        return true;
+    }();
+    (void)attr_set;
     Refine64Args ra{tv, b->Z_s, b->Z_q, b->d, b->y_s, b->y_q, b->priors, w.Ainv, with_hessian ? w.P : nullptr, level >= 1 ? w.C : nullptr,
-                    level >= 2 ? w.S : nullptr, w.vecs, w.scal, f_out, info, f_in, g_in, gnorm, w.w64, w.w64_stride, thresh, b->T, with_hessian ? 1 : 0, level};
-    k_refine64<<<b->T, R64_NT, 0, st>>>(ra);
+                    level >= 2 ? w.S : nullptr, w.vecs, w.scal, f_out, info, f_in, g_in, gnorm, w.w64, w.w64_stride, thresh, b->T, with_hessian ? 1 : 0, level,
+                    lds_inv ? 1 : 0};
+    k_refine64<<<b->T, R64_NT, lds_bytes, st>>>(ra);
 }
 
 int launch_outer_factor(const OuterArgs& a, const Workspace& w, int nq, hipStream_t st) {

@@ -276,6 +276,8 @@ template <> struct Sweep<128, 512> {
         }
         __builtin_amdgcn_sched_barrier(0);
         bulk<WN, ADKF_M_EARLY + ADKF_M_MID, 7>(acc, prev);   // the rest issues under the latency of the LDS stores above
+        // (no scheduling fence here: hipcc sinks two of them behind the barrier, in front of the next step's LDS reads, and the
+        // sweep is 3 % FASTER that way than with all of them held in front of it - 37.3 k against 38.9 k cycles)
         prev = cur;
         ADKF_MTS(6);
     }

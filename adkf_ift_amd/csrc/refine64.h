@@ -27,6 +27,7 @@
 namespace adkf {
 
 constexpr int R64_NT = 512;
+constexpr int R64_LDS_POINTS = 128;   // r64_inverse works in LDS up to this many points (n^2 doubles of dynamic shared memory)
 constexpr int R64_MAXN = 256;          // float64 region is carved for batches up to this many points
 constexpr float R64_THRESHOLD = 30.f;
 
@@ -38,7 +39,7 @@ struct Refine64Args {
     float* vecs; float* scal; float* f_out; int32_t* info;
     float *f_in, *g_in, *gnorm;        // optional: the refined inner value / raw gradient / max |gradient| (adkf_fit, adkf_mll_value_grad)
     double* w64; size_t w64_stride;    // [T][stride] doubles
-    float thresh; int T, want_hess, want_outer;   // want_outer: 0 = inner quantities only, 1 = + C and mu (prediction), 2 = + S, S^-1, e, f_out
+    float thresh; int T, want_hess, want_outer, lds_inverse;   // lds_inverse: the launch carries R64_LDS_POINTS^2 doubles of dynamic LDS; want_outer: 0 = inner quantities only, 1 = + C and mu (prediction), 2 = + S, S^-1, e, f_out
 };
 
 // doubles per task: [A1 A2 A3 | B1 B2 | S1 S2 | 8 vectors | DDss DDqs DDqq | spare]
@@ -49,18 +50,70 @@ inline size_t refine64_doubles(int ns, int nq) {
     return r64_dd_offset(ns, nq) + (size_t)ns * ns + (size_t)nq * ns + (size_t)nq * nq + 64;
 }
 
-// Squared distances of a flagged task in float64, difference form, straight from the float32 features.  The GEMM form of the
-// float32 stage (|x|^2 + |y|^2 - 2 x.y) carries eps32 |x|^2 into every entry: nothing for the benchmark shapes, but for
-// clustered low-dimensional features (the flagged tasks) it was the LAST float32 input of the float64 path and the whole
-// remaining error of it (tools/diag_stress.py: dL/dZ_s 1.9e-4 -> 1.7e-6 on the one stress task that stayed above 1e-4).
-__device__ void r64_distances(const float* X, const float* Y, int nx, int ny, int d, double* out, int ldo) {
-    for (int e = threadIdx.x; e < nx * ny; e += R64_NT) {
-        const int i = e / ny, j = e % ny;
-        const float *xi = X + (size_t)i * d, *yj = Y + (size_t)j * d;
-        double s = 0.0;
-        for (int c = 0; c < d; ++c) { const double df = (double)xi[c] - (double)yj[c]; s += df * df; }
-        out[(size_t)i * ldo + j] = s;
+// C(i, j) = sum_k fa(i, k) fb(k, j), delivered element by element to fe(i, j, value): the O(n^3) products of the float64 path on
+// the FP64 matrix pipe (v_mfma_f64_16x16x4_f64: lane l carries A[l & 15][k = l >> 4] and B[k = l >> 4][l & 15]; its C/D map is
+// col = l & 15, row = (l >> 4) + 4 reg - NOT the float32 one).  The 16 x 16 output tiles are dealt round-robin to the eight
+// waves; operands come straight from L2 through the caller's accessors (out-of-range rows / columns / k read as zero).
+// Round 2 ran these products as one thread per output element with a scalar k loop over global memory: ~0.5 ms per 128^3
+// product and workgroup, ~4 ms per launch of the path (profiles/r03_bench_*_d4.json, "before").  Barrier at the end.
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+template <class FA, class FB, class FE>
+__device__ __forceinline__ void r64_mm(int M, int N, int K, FA fa, FB fb, FE fe) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tn = (N + 15) >> 4, tiles = ((M + 15) >> 4) * tn;
+    const int lr = lane & 15, lk = lane >> 4;
+    for (int tile = wv; tile < tiles; tile += R64_NT / 64) {
+        const int i0 = (tile / tn) << 4, j0 = (tile % tn) << 4;
+        const int ar = i0 + lr, bc = j0 + lr;
+        const bool aok = ar < M, bok = bc < N;
+        f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const int k = k0 + lk;
+            const double av = (aok && k < K) ? fa(ar, k) : 0.0;
+            const double bv = (bok && k < K) ? fb(k, bc) : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + lk + 4 * r, j = j0 + lr;
+            if (i < M && j < N) fe(i, j, acc[r]);
+        }
     }
+    __syncthreads();
+}
+
+// y_i = sum_k fa(i, k) fx(k), delivered to fe(i, value): a wave per row, the lanes along k (coalesced for a row-major matrix;
+// round 2 ran the row-wise mat-vecs as a thread per row - 128 different cache lines per k step), wave-reduced.  Barrier at the end.
+template <class FA, class FX, class FE>
+__device__ __forceinline__ void r64_mv(int M, int K, FA fa, FX fx, FE fe) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = wv; i < M; i += R64_NT / 64) {
+        double s = 0.0;
+        for (int k = lane; k < K; k += 64) s += fa(i, k) * fx(k);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) fe(i, s);
+    }
+    __syncthreads();
+}
+
+// Squared distances of a flagged task in float64, straight from the float32 features.  The GEMM form of the float32 stage
+// (|x|^2 + |y|^2 - 2 x.y) carries eps32 |x|^2 into every entry: nothing for the benchmark shapes, but for clustered
+// low-dimensional features (the flagged tasks) it was the LAST float32 input of the float64 path and the whole remaining error
+// of it (tools/diag_stress.py: dL/dZ_s 1.9e-4 -> 1.7e-6 on the one stress task that stayed above 1e-4).  In float64 the same
+// form carries eps64 |x|^2 - nothing - and runs on the matrix pipe (r64_mm); `same`: X == Y, the diagonal is exactly zero.
+// nx / ny: scratch for the squared row norms (nx + ny doubles).
+__device__ void r64_distances(const float* X, const float* Y, int nx, int ny, int d, double* out, int ldo, double* sx, double* sy, bool same) {
+    for (int i = threadIdx.x; i < nx + ny; i += R64_NT) {
+        const float* r = i < nx ? X + (size_t)i * d : Y + (size_t)(i - nx) * d;
+        double s = 0.0;
+        for (int c = 0; c < d; ++c) s += (double)r[c] * (double)r[c];
+        if (i < nx) sx[i] = s; else sy[i - nx] = s;
+    }
+    __syncthreads();
+    r64_mm(nx, ny, d, [=](int i, int k) { return (double)X[(size_t)i * d + k]; }, [=](int k, int j) { return (double)Y[(size_t)j * d + k]; },
+       [=](int i, int j, double v) { const double q = sx[i] + sy[j] - 2.0 * v; out[(size_t)i * ldo + j] = (same && i == j) ? 0.0 : (q > 0.0 ? q : 0.0); });
 }
 
 __device__ __forceinline__ void kappa3_d(int kind, double u, double& k0, double& k1, double& k2) {
@@ -86,58 +139,53 @@ __device__ __forceinline__ double r64_sum(double v, double* red) {
     return s;
 }
 
-// In-place Cholesky of the lower triangle of M (n x n, leading dimension ld); returns the first non-positive pivot
-// (1-based) or 0, log|M| through logdet.  Right-looking, the whole workgroup.
-__device__ int r64_cholesky(double* M, int n, int ld, double& logdet, double* red) {
+// M -> M^-1 in place (n x n SPD, leading dimension ld) by Gauss-Jordan steps without pivoting, the whole workgroup; returns the
+// first non-positive pivot (1-based) or 0, log|M| through logdet (the pivots are those of the LDL^T factorisation).  Every step
+// is one fully parallel rank-1 update of the n^2 entries from the pivot column and the scaled pivot row, which are parked in
+// LDS first: 2 n barriers in all.  (Round 2 factored M = L L^T, inverted L one column per thread and formed L^-T L^-1: with
+// 128 points that left 384 of the 512 threads idle through a dependent O(n^2) chain of global loads per column - the float64
+// path cost ~4 ms per launch, i.e. ONE flagged task multiplied the step time by nine; profiles/r03_bench_*_d4.json.)
+__device__ int r64_inverse(double* M, int n, int ld, double& logdet, double* colv, double* rowv, double* lds = nullptr) {
     const int tid = threadIdx.x;
+    // up to 128 points the matrix makes its n steps in LDS (`lds`: n * n doubles of dynamic shared memory, 128 KB at n = 128):
+    // in global memory every step is 32 dependent read-modify-writes per thread at L2 latency - 1.3 ms per inverse, measured
+    double* W = M;
+    int lw = ld;
+    if (lds && n <= R64_LDS_POINTS) {
+        for (int e = tid; e < n * n; e += R64_NT) { const int i = e / n, j = e - i * n; lds[e] = M[(size_t)i * ld + j]; }
+        W = lds; lw = n;
+    }
     int bad = 0;
     double ld_acc = 0.0;
     for (int k = 0; k < n; ++k) {
+        __syncthreads();                                   // the update of step k - 1 is complete
+        const double p = W[(size_t)k * lw + k];
+        if (!(p > 0.0) && !bad) bad = k + 1;
+        const double ps = p > 0.0 ? p : 1.0, r = 1.0 / ps;
+        if (tid == (k & (R64_NT - 1))) ld_acc += log(ps);   // (ONE thread per pivot takes the logarithm - a float64 log in every thread at every step was a tenth of the kernel)
+        for (int i = tid; i < n; i += R64_NT) { colv[i] = W[(size_t)i * lw + k]; rowv[i] = W[(size_t)k * lw + i] * r; }
         __syncthreads();
-        const double p = M[(size_t)k * ld + k];
-        if (!(p > 0.0)) { if (!bad) bad = k + 1; }
-        const double lkk = sqrt(p > 0.0 ? p : 1.0);
-        ld_acc += 2.0 * log(lkk);
-        __syncthreads();
-        for (int i = k + tid; i < n; i += R64_NT) M[(size_t)i * ld + k] = (i == k) ? lkk : M[(size_t)i * ld + k] / lkk;
-        __syncthreads();
-        const int rem = n - k - 1;
-        for (int e = tid; e < rem * rem; e += R64_NT) {
-            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
-            if (j <= i) M[(size_t)i * ld + j] -= M[(size_t)i * ld + k] * M[(size_t)j * ld + k];
+        // (element e = tid + 512 it is (i, j) with i, j stepped instead of divided: an integer division by the runtime n per
+        // element was most of this loop's instructions)
+        int i = tid / n, j = tid - i * n;
+        const int di = R64_NT / n, dj = R64_NT - di * n;
+#pragma unroll 4
+        for (int e = tid; e < n * n; e += R64_NT) {
+            double* mp = W + (size_t)i * lw + j;
+            if (i == k) *mp = (j == k) ? r : rowv[j];
+            else if (j == k) *mp = -colv[i] * r;
+            else *mp -= colv[i] * rowv[j];
+            i += di; j += dj;
+            if (j >= n) { j -= n; ++i; }
         }
     }
     __syncthreads();
-    (void)red;
-    logdet = ld_acc;
+    if (W != M) {
+        for (int e = tid; e < n * n; e += R64_NT) { const int i = e / n, j = e - i * n; M[(size_t)i * ld + j] = lds[e]; }
+        __syncthreads();
+    }
+    logdet = r64_sum(ld_acc, colv);   // (colv is free again; r64_sum needs R64_NT / 64 doubles)
     return bad;
-}
-
-// X = L^-1 (lower triangular) from the Cholesky factor in L; X and L distinct buffers.  One column per thread.
-__device__ void r64_tri_inverse(const double* L, double* X, int n, int ld) {
-    for (int j = threadIdx.x; j < n; j += R64_NT) {
-        for (int i = 0; i < j; ++i) X[(size_t)i * ld + j] = 0.0;
-        X[(size_t)j * ld + j] = 1.0 / L[(size_t)j * ld + j];
-        for (int i = j + 1; i < n; ++i) {
-            double s = 0.0;
-            for (int k = j; k < i; ++k) s += L[(size_t)i * ld + k] * X[(size_t)k * ld + j];
-            X[(size_t)i * ld + j] = -s / L[(size_t)i * ld + i];
-        }
-    }
-    __syncthreads();
-}
-
-// Out = X^T X for lower-triangular X (= the inverse of the factored matrix), full symmetric result
-__device__ void r64_xtx(const double* X, double* Out, int n, int ld) {
-    for (int e = threadIdx.x; e < n * n; e += R64_NT) {
-        const int i = e / n, j = e % n;
-        if (j > i) continue;
-        double s = 0.0;
-        for (int k = i; k < n; ++k) s += X[(size_t)k * ld + i] * X[(size_t)k * ld + j];
-        Out[(size_t)i * ld + j] = s;
-        Out[(size_t)j * ld + i] = s;
-    }
-    __syncthreads();
 }
 
 // Diagnostic (adkf_double_path_tasks): which tasks of the last adkf_ift_hypergrad / adkf_outer_nll_value_grad on this workspace took
@@ -153,6 +201,8 @@ __global__ void k_double_path_tasks(const float* scal, int ld, int ldq, float th
 
 __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
     __shared__ double red[R64_NT / 64];
+    __shared__ double gjc[R64_MAXN], gjr[R64_MAXN];   // pivot column / scaled pivot row of r64_inverse
+    extern __shared__ double r64_lds[];                 // R64_LDS_POINTS^2 doubles when the batch has at most that many points, else nothing
     const int t = blockIdx.x, tid = threadIdx.x;
     if (t >= a.T) return;
     const int n = a.tv.ns(t), m = a.want_outer ? a.tv.nq(t) : 0, ld = a.tv.ns_ld, ldq = a.tv.nq_ld, vld = a.tv.vld;
@@ -182,11 +232,11 @@ __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
     double* DDqs = DDss + (size_t)ld * ld;
     double* DDqq = DDqs + (size_t)ldq * ld;
     const float* Zs = a.Zs + (size_t)t * ld * a.d;
-    r64_distances(Zs, Zs, n, n, a.d, DDss, ld);
+    r64_distances(Zs, Zs, n, n, a.d, DDss, ld, gjc, gjr, true);
     if (m > 0) {
         const float* Zq = a.Zq + (size_t)t * ldq * a.d;
-        r64_distances(Zq, Zs, m, n, a.d, DDqs, ld);
-        r64_distances(Zq, Zq, m, m, a.d, DDqq, ldq);
+        r64_distances(Zq, Zs, m, n, a.d, DDqs, ld, gjc, gjr, false);
+        r64_distances(Zq, Zq, m, m, a.d, DDqq, ldq, gjc, gjr, true);
     }
     __syncthreads();
     const float* ys = a.y_s + (size_t)t * ld;
@@ -199,18 +249,11 @@ __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
         A1[(size_t)i * ld + j] = os * k0 + (i == j ? noise : 0.0);
     }
     double logdetA;
-    const int badA = r64_cholesky(A1, n, ld, logdetA, red);
-    r64_tri_inverse(A1, A2, n, ld);
-    r64_xtx(A2, A1, n, ld);
+    const int badA = r64_inverse(A1, n, ld, logdetA, gjc, gjr, a.lds_inverse ? r64_lds : nullptr);
     float* Ai32 = a.Ainv + (size_t)t * ld * ld;
     for (int e = tid; e < n * n; e += R64_NT) { const int i = e / n, j = e % n; Ai32[(size_t)i * ld + j] = (float)A1[(size_t)i * ld + j]; }
-    for (int i = tid; i < n; i += R64_NT) {
-        double s = 0.0;
-        for (int j = 0; j < n; ++j) s += A1[(size_t)i * ld + j] * (double)ys[j];
-        v_al[i] = s;
-        vb[V_ALPHA * vld + i] = (float)s;
-    }
-    __syncthreads();
+    r64_mv(n, n, [=](int i, int k) { return A1[(size_t)i * ld + k]; }, [=](int k) { return (double)ys[k]; },
+           [=](int i, double v) { v_al[i] = v; vb[V_ALPHA * vld + i] = (float)v; });
 
     // ---- inner scalars and the 3 x 3 Hessian (oracle/closed_form.py::inner_stage)
     {
@@ -221,24 +264,13 @@ __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
             A2[(size_t)i * ld + j] = os * k1 * u * (-2.0 / ls);
         }
         __syncthreads();
-        for (int i = tid; i < n; i += R64_NT) {
-            double sb = 0.0, sg = 0.0;
-            for (int j = 0; j < n; ++j) { sb += A2[(size_t)i * ld + j] * v_al[j]; sg += A1[(size_t)i * ld + j] * v_al[j]; }
-            v_be[i] = sb; v_ga[i] = sg;
-        }
-        __syncthreads();
-        for (int i = tid; i < n; i += R64_NT) {
-            double sd = 0.0;
-            for (int j = 0; j < n; ++j) sd += A1[(size_t)i * ld + j] * v_be[j];
-            v_de[i] = sd;
-        }
+        r64_mv(n, n, [=](int i, int k) { return A2[(size_t)i * ld + k]; }, [=](int k) { return v_al[k]; }, [=](int i, double v) { v_be[i] = v; });
+        r64_mv(n, n, [=](int i, int k) { return A1[(size_t)i * ld + k]; }, [=](int k) { return v_al[k]; }, [=](int i, double v) { v_ga[i] = v; });
+        r64_mv(n, n, [=](int i, int k) { return A1[(size_t)i * ld + k]; }, [=](int k) { return v_be[k]; }, [=](int i, double v) { v_de[i] = v; });
         if (a.want_hess) {
-            for (int e = tid; e < n * n; e += R64_NT) {   // P = A^-1 G
-                const int i = e / n, j = e % n;
-                double s = 0.0;
-                for (int k = 0; k < n; ++k) s += A1[(size_t)i * ld + k] * A2[(size_t)k * ld + j];
-                A3[(size_t)i * ld + j] = s;
-            }
+            __syncthreads();
+            r64_mm(n, n, n, [=](int i, int k) { return A1[(size_t)i * ld + k]; }, [=](int k, int j) { return A2[(size_t)k * ld + j]; },
+                   [=](int i, int j, double v) { A3[(size_t)i * ld + j] = v; });   // P = A^-1 G
         }
         __syncthreads();
         double trAinv = 0, trAinvG = 0, aGa = 0, trA2 = 0, trPA = 0, trPP = 0, trAinvKll = 0, aKlla = 0;
@@ -323,18 +355,10 @@ __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
         B1[(size_t)i * ld + j] = os * k0;
     }
     __syncthreads();
-    for (int e = tid; e < m * n; e += R64_NT) {
-        const int i = e / n, j = e % n;
-        double s = 0.0;
-        for (int k = 0; k < n; ++k) s += B1[(size_t)i * ld + k] * A1[(size_t)k * ld + j];
-        B2[(size_t)i * ld + j] = s;
-    }
-    for (int i = tid; i < m; i += R64_NT) {
-        double s = 0.0;
-        for (int j = 0; j < n; ++j) s += B1[(size_t)i * ld + j] * v_al[j];
-        v_mu[i] = s; v_r[i] = yq ? (double)yq[i] - s : 0.0;
-    }
-    __syncthreads();
+    r64_mm(m, n, n, [=](int i, int k) { return B1[(size_t)i * ld + k]; }, [=](int k, int j) { return A1[(size_t)k * ld + j]; },
+           [=](int i, int j, double v) { B2[(size_t)i * ld + j] = v; });           // C = K_qs A^-1
+    r64_mv(m, n, [=](int i, int k) { return B1[(size_t)i * ld + k]; }, [=](int k) { return v_al[k]; },
+           [=](int i, double v) { v_mu[i] = v; v_r[i] = yq ? (double)yq[i] - v : 0.0; });
     if (a.C) {
         float* C32 = a.C + (size_t)t * ldq * ld;
         for (int e = tid; e < m * n; e += R64_NT) { const int i = e / n, j = e % n; C32[(size_t)i * ld + j] = (float)B2[(size_t)i * ld + j]; }
@@ -343,28 +367,21 @@ __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
         for (int i = tid; i < m; i += R64_NT) vb[V_MU * vld + i] = (float)v_mu[i];
         return;
     }
-    for (int e = tid; e < m * m; e += R64_NT) {
-        const int i = e / m, j = e % m;
-        if (j > i) continue;
-        double k0, k1, k2; kappa3_d(kind, DDqq[(size_t)i * ldq + j] * il2, k0, k1, k2);
-        double s = os * k0 + (i == j ? noise : 0.0);
-        for (int k = 0; k < n; ++k) s -= B2[(size_t)i * ld + k] * B1[(size_t)j * ld + k];
-        S1[(size_t)i * ldq + j] = s; S1[(size_t)j * ldq + i] = s;
-    }
+    __syncthreads();
+    r64_mm(m, m, n, [=](int i, int k) { return B2[(size_t)i * ld + k]; }, [=](int k, int j) { return B1[(size_t)j * ld + k]; },
+           [=](int i, int j, double v) {                                            // Sigma_q = K_qq + noise I - C K_sq, the lower triangle mirrored
+               if (j > i) return;
+               double k0, k1, k2; kappa3_d(kind, DDqq[(size_t)i * ldq + j] * il2, k0, k1, k2);
+               const double sv = os * k0 + (i == j ? noise : 0.0) - v;
+               S1[(size_t)i * ldq + j] = sv; S1[(size_t)j * ldq + i] = sv;
+           });
     double logdetS;
-    const int badS = r64_cholesky(S1, m, ldq, logdetS, red);
-    r64_tri_inverse(S1, S2, m, ldq);
-    r64_xtx(S2, S1, m, ldq);
+    const int badS = r64_inverse(S1, m, ldq, logdetS, gjc, gjr, a.lds_inverse ? r64_lds : nullptr);
     if (a.S) {
         float* S32 = a.S + (size_t)t * ldq * ldq;
         for (int e = tid; e < m * m; e += R64_NT) { const int i = e / m, j = e % m; S32[(size_t)i * ldq + j] = (float)S1[(size_t)i * ldq + j]; }
     }
-    for (int i = tid; i < m; i += R64_NT) {
-        double s = 0.0;
-        for (int j = 0; j < m; ++j) s += S1[(size_t)i * ldq + j] * v_r[j];
-        v_e[i] = s;
-    }
-    __syncthreads();
+    r64_mv(m, m, [=](int i, int k) { return S1[(size_t)i * ldq + k]; }, [=](int k) { return v_r[k]; }, [=](int i, double v) { v_e[i] = v; });
     double q = 0.0;
     for (int i = tid; i < m; i += R64_NT) {
         q += v_r[i] * v_e[i];
@@ -443,26 +460,21 @@ __global__ __launch_bounds__(R64_NT) void k_cotangent64(Cot64Args a) {
         v_cte[j] = s;
     }
     __syncthreads();
-    for (int e = tid; e < m * n; e += R64_NT) {     // Omega C = (S^-1 C - e (C^T e)^T) / 2
-        const int i = e / n, j = e % n;
-        double s = 0.0;
-        for (int k = 0; k < m; ++k) s += S1[(size_t)i * ldq + k] * B2[(size_t)k * ld + j];
-        B1[(size_t)i * ld + j] = 0.5 * (s - v_e[i] * v_cte[j]);
-    }
-    __syncthreads();
+    r64_mm(m, n, m, [=](int i, int k) { return S1[(size_t)i * ldq + k]; }, [=](int k, int j) { return B2[(size_t)k * ld + j]; },
+           [=](int i, int j, double v) { B1[(size_t)i * ld + j] = 0.5 * (v - v_e[i] * v_cte[j]); });   // Omega C = (S^-1 C - e (C^T e)^T) / 2
     double oc0 = 0, oc1 = 0, ma0 = 0, ma1 = 0, ma2 = 0, qq0 = 0, qq1 = 0, qq2 = 0;
-    for (int e = tid; e < n * n; e += R64_NT) {     // M_A = C^T (Omega C) + sym(C^T e alpha^T)
-        const int i = e / n, j = e % n;
-        double s = 0.0;
-        for (int k = 0; k < m; ++k) s += B2[(size_t)k * ld + i] * B1[(size_t)k * ld + j];
-        const double MA = s + 0.5 * (v_cte[i] * v_al[j] + v_al[i] * v_cte[j]);
-        A2[(size_t)i * ld + j] = MA;
-        const double u = Dss[(size_t)i * ld + j] * il2;
-        double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
-        if (i == j) ma0 += MA;
-        ma1 += MA * k0; ma2 += MA * os * k1 * u * gl;
-    }
-    __syncthreads();                                // Omega C has been read by everybody: it turns into W_qs in place
+    {   // M_A = C^T (Omega C) + sym(C^T e alpha^T)   (the three reductions ride in the product's epilogue)
+        double* pm0 = &ma0; double* pm1 = &ma1; double* pm2 = &ma2;
+        r64_mm(n, n, m, [=](int i, int k) { return B2[(size_t)k * ld + i]; }, [=](int k, int j) { return B1[(size_t)k * ld + j]; },
+               [=](int i, int j, double v) {
+                   const double MA = v + 0.5 * (v_cte[i] * v_al[j] + v_al[i] * v_cte[j]);
+                   A2[(size_t)i * ld + j] = MA;
+                   const double u = Dss[(size_t)i * ld + j] * il2;
+                   double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
+                   if (i == j) *pm0 += MA;
+                   *pm1 += MA * k0; *pm2 += MA * os * k1 * u * gl;
+               });
+    }                                               // (barrier inside) Omega C has been read by everybody: it turns into W_qs in place
     for (int e = tid; e < m * n; e += R64_NT) {     // M_B -> W_qs
         const int i = e / n, j = e % n;
         const double MB = -2.0 * B1[(size_t)i * ld + j] - v_e[i] * v_al[j];
@@ -515,48 +527,55 @@ __global__ __launch_bounds__(R64_NT) void k_cotangent64(Cot64Args a) {
     }
     __syncthreads();
     const double fn = (double)n;
-    for (int e = tid; e < n * n; e += R64_NT) {     // W_ss = direct part - mixed-partial part (ProbMA / ProbMixed epilogues)
-        const int i = e / n, j = e % n;
+    // W_ss = direct part - mixed-partial part (ProbMA / ProbMixed epilogues); ((A^-1 B_v) A^-1)_ij with
+    // A^-1 B_v = (cn - cs noise) A^-1 + cs I + cl P comes out of the matrix pipe, the rest is its epilogue
+    auto wss_of = [=](int i, int j, double xa) {
         const double u = Dss[(size_t)i * ld + j] * il2;
         double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
         double wss = dir * A2[(size_t)i * ld + j] * os * k1 * il2;
         if (corr != 0.0) {
-            double xa = 0.0;                        // ((A^-1 B_v) A^-1)_ij,  A^-1 B_v = (cn - cs noise) A^-1 + cs I + cl P
-            for (int k = 0; k < n; ++k)
-                xa += ((cn - cs * noise) * A1[(size_t)i * ld + k] + (i == k ? cs : 0.0) + cl * A3[(size_t)i * ld + k]) * A1[(size_t)k * ld + j];
             const double dgdA = (-0.5 * xa + 0.5 * (v_w[i] * v_al[j] + v_al[i] * v_w[j])) / fn;
             const double Q = 0.5 * (A1[(size_t)i * ld + j] - v_al[i] * v_al[j]) / fn;
             const double dBv = cs * os * k1 + cl * os * gl * (k1 + u * k2);
             wss -= corr * (dgdA * os * k1 * il2 + Q * dBv * il2);
         }
-        A2[(size_t)i * ld + j] = wss;               // (element (i, j) of M_A is read by this thread only)
+        A2[(size_t)i * ld + j] = wss;               // (element (i, j) of M_A is read by this lane only)
+    };
+    if (corr != 0.0) {
+        const double ca = cn - cs * noise;
+        r64_mm(n, n, n, [=](int i, int k) { return ca * A1[(size_t)i * ld + k] + (i == k ? cs : 0.0) + cl * A3[(size_t)i * ld + k]; },
+               [=](int k, int j) { return A1[(size_t)k * ld + j]; }, wss_of);
+    } else {
+        for (int e = tid; e < n * n; e += R64_NT) wss_of(e / n, e % n, 0.0);
+        __syncthreads();
     }
-    __syncthreads();
     // ---- dL/dZ in the difference form, from the float64 weights
     const int d = a.d;
     const float* Zs = a.Zs + (size_t)t * ld * d;
     const float* Zq = a.Zq + (size_t)t * ldq * d;
+    // (float64: z_i sum_k W_ik - sum_k W_ik z_k loses cond digits of sixteen, not of seven - the difference form was what the
+    // float32 kernels could not afford to skip; the W Z products run on the matrix pipe)
+    double* rs_ss = v_be; double* rs_qs_col = v_ga; double* rs_qs_row = v_de; double* rs_qq = v_w;   // (all spent by now)
+    for (int i = tid; i < n; i += R64_NT) {          // column sums: a thread per column is coalesced
+        double s2 = 0.0;
+        for (int q = 0; q < m; ++q) s2 += B1[(size_t)q * ld + i];
+        rs_qs_col[i] = s2;
+    }
+    r64_mv(n, n, [=](int i, int k) { return A2[(size_t)i * ld + k]; }, [](int) { return 1.0; }, [=](int i, double v) { rs_ss[i] = v; });
+    r64_mv(m, n, [=](int i, int k) { return B1[(size_t)i * ld + k]; }, [](int) { return 1.0; }, [=](int i, double v) { rs_qs_row[i] = v; });
+    r64_mv(m, m, [=](int i, int k) { return S2[(size_t)i * ldq + k]; }, [](int) { return 1.0; }, [=](int i, double v) { rs_qq[i] = v; });
     if (a.dZs) {
         float* out = a.dZs + (size_t)t * ld * d;
-        for (int e = tid; e < n * d; e += R64_NT) {
-            const int i = e / d, c = e % d;
-            const double zi = Zs[(size_t)i * d + c];
-            double s = 0.0;
-            for (int k = 0; k < n; ++k) s += 4.0 * A2[(size_t)i * ld + k] * (zi - (double)Zs[(size_t)k * d + c]);
-            for (int q = 0; q < m; ++q) s += 2.0 * B1[(size_t)q * ld + i] * (zi - (double)Zq[(size_t)q * d + c]);
-            out[(size_t)i * d + c] = (float)s;
-        }
+        // dZs_i = 4 (rs_ss_i z_i - sum_k Wss_ik z_k) + 2 (cs_qs_i z_i - sum_q Wqs_qi zq_q): one product over k = [support | query]
+        r64_mm(n, d, n + m, [=](int i, int k) { return k < n ? 4.0 * A2[(size_t)i * ld + k] : 2.0 * B1[(size_t)(k - n) * ld + i]; },
+               [=](int k, int c) { return k < n ? (double)Zs[(size_t)k * d + c] : (double)Zq[(size_t)(k - n) * d + c]; },
+               [=](int i, int c, double v) { out[(size_t)i * d + c] = (float)((4.0 * rs_ss[i] + 2.0 * rs_qs_col[i]) * (double)Zs[(size_t)i * d + c] - v); });
     }
     if (a.dZq) {
         float* out = a.dZq + (size_t)t * ldq * d;
-        for (int e = tid; e < m * d; e += R64_NT) {
-            const int i = e / d, c = e % d;
-            const double zi = Zq[(size_t)i * d + c];
-            double s = 0.0;
-            for (int k = 0; k < n; ++k) s += 2.0 * B1[(size_t)i * ld + k] * (zi - (double)Zs[(size_t)k * d + c]);
-            for (int q = 0; q < m; ++q) s += 4.0 * S2[(size_t)i * ldq + q] * (zi - (double)Zq[(size_t)q * d + c]);
-            out[(size_t)i * d + c] = (float)s;
-        }
+        r64_mm(m, d, n + m, [=](int i, int k) { return k < n ? 2.0 * B1[(size_t)i * ld + k] : 4.0 * S2[(size_t)i * ldq + (k - n)]; },
+               [=](int k, int c) { return k < n ? (double)Zs[(size_t)k * d + c] : (double)Zq[(size_t)(k - n) * d + c]; },
+               [=](int i, int c, double v) { out[(size_t)i * d + c] = (float)((2.0 * rs_qs_row[i] + 4.0 * rs_qq[i]) * (double)Zq[(size_t)i * d + c] - v); });
     }
 }
 

@@ -327,18 +327,27 @@ def main():
             # command (tools/profile_round.sh), committed under profiles/ with the commit they were taken at; FETCH_SIZE is
             # doubled as MI355X_MICROARCH.md (HBM section) prescribes for 16-byte-per-lane streaming reads on gfx950.
             traffic = traffic_src = None
-            pmc = os.path.join(ROOT, "profiles", "r02_k_inner_pmc.json")
-            if os.path.exists(pmc) and (T, N, Nq, d, I) == (256, 128, 128, 256, 20) and args.kernel == "rbf" and not args.ard:
+            low = T > 256   # the <= 128-register build (two tasks per CU) is taken when the batch has more tasks than the chip has CUs
+            pmc = os.path.join(ROOT, "profiles", "r03_k_inner_pmc.json")
+            if os.path.exists(pmc) and (T, N, Nq, d, I) == (256, 128, 128, 256, 20) and args.kernel == "rbf" and not args.ard and not args.regression:
                 with open(pmc) as fh:
                     pm = json.load(fh)
                 traffic = (2.0 * pm["FETCH_SIZE_KB_per_launch"] + pm["WRITE_SIZE_KB_per_launch"]) * 1024.0
-                traffic_src = {"file": "profiles/r02_k_inner_pmc.json", "commit": pm.get("commit"),
+                traffic_src = {"file": "profiles/r03_k_inner_pmc.json", "commit": pm.get("commit"),
                                "correction": "2 x FETCH_SIZE + WRITE_SIZE"}
+            pmc5 = os.path.join(ROOT, "profiles", "r03_c5_fit_pmc.json")
+            if os.path.exists(pmc5) and (T, N, Nq, d, I) == (8, 1024, 1024, 512, 20) and args.kernel == "rbf" and not args.ard and not args.regression:
+                with open(pmc5) as fh:
+                    pm = json.load(fh)
+                traffic = (2.0 * pm["FETCH_SIZE_KB_per_fit"] + pm["WRITE_SIZE_KB_per_fit"]) * 1024.0
+                traffic_src = {"file": "profiles/r03_c5_fit_pmc.json", "commit": pm.get("commit"),
+                               "correction": "2 x FETCH_SIZE + WRITE_SIZE, summed over the launches of one fit"}
             if args.ard:
                 fit_kernel, bound = "ARD inner fit (all launches between the two events)", "mfma"
             elif N <= 128:
-                fit_kernel = "k_inner (in-kernel quasi-Newton fit: kernel build + register-resident sweep per evaluation)"
-                bound = "valu-fp32 (latency)"   # one workgroup per task, no MFMA: limited by the dependency chain of the sweep
+                fit_kernel = ("k_inner (in-kernel quasi-Newton fit: kernel build + register-resident sweep per evaluation; the sweep's "
+                              "rank-4 updates run as v_mfma_f32_16x16x4_f32" + ("; <= 128-register build, two tasks per CU)" if low and N > 64 else ")"))
+                bound = "mfma"   # FP32 matrix pipe (157.3 TFLOP/s = the FP32 vector peak); the kernel is limited by the hand-off chain of the sweep
             else:
                 fit_kernel = ("blocked inner fit (all launches between the two events: k_lg_build, k_lg_diag, panel/update "
                               "MFMA GEMMs, k_lg_traces, k_lg_advance per evaluation)")

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) and the --stats pass of tools/profile_round.sh into
-profiles/r02_k_inner_pmc.json + profiles/r02_bench_kernel_stats.csv.  Run where gpurun_out/ has been merged back.
+"""Turns the rocprofv3 passes of tools/round3_profiles.sh (merged back under gpurun_out/) into the tracked evidence:
+profiles/r03_bench_kernel_stats.csv, r03_k_inner_pmc.json (FETCH_SIZE / WRITE_SIZE per launch), r03_k_inner_sq_pmc.json
+(SQ, LDS and MFMA counters per launch), r03_c5_kernel_stats.csv and r03_c5_fit_pmc.json (traffic of one blocked fit).
     python tools/make_pmc_json.py [commit]"""
 import csv
 import glob
@@ -12,41 +13,83 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
+KINNER = "k_inner<128, 512, 0"
 
 
-def per_launch(pattern, counter, kernel="k_inner<128, 512, 0>"):
-    files = glob.glob(os.path.join(OUT, pattern, "**", "*counter_collection.csv"), recursive=True)
-    vals = {}
-    for f in files:
+def counter_rows(pattern):
+    for f in glob.glob(os.path.join(OUT, pattern, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
-            for row in csv.DictReader(fh):
-                if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                    vals.setdefault(row["Dispatch_Id"], 0.0)
-                    vals[row["Dispatch_Id"]] += float(row["Counter_Value"])
-    v = sorted(vals.values())
-    return (sum(v) / len(v) if v else None), len(v)
+            yield from csv.DictReader(fh)
+
+
+def per_launch(pattern, counters, kernel=KINNER):
+    """{counter: mean over the kernel's dispatches of the counter summed over its rows}, number of dispatches"""
+    vals = {c: {} for c in counters}
+    for row in counter_rows(pattern):
+        if kernel in row["Kernel_Name"] and row["Counter_Name"] in vals:
+            d = vals[row["Counter_Name"]]
+            d[row["Dispatch_Id"]] = d.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+    out = {c: (sum(d.values()) / len(d) if d else None) for c, d in vals.items()}
+    return out, max((len(d) for d in vals.values()), default=0)
+
+
+def stats_avg_us(stats_csv, name):
+    with open(stats_csv) as fh:
+        for row in csv.DictReader(fh):
+            if name in row["Name"]:
+                return float(row["AverageNs"]) / 1e3, int(row["Calls"])
+    return None, 0
 
 
 def main():
     commit = sys.argv[1] if len(sys.argv) > 1 else subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
-    fetch, nf = per_launch("prof_r02_fetch", "FETCH_SIZE")
-    write, nw = per_launch("prof_r02_write", "WRITE_SIZE")
-    stats = glob.glob(os.path.join(OUT, "prof_r02", "**", "*kernel_stats.csv"), recursive=True)
+    prof = os.path.join(ROOT, "profiles")
+    stats = glob.glob(os.path.join(OUT, "prof_r03", "**", "*kernel_stats.csv"), recursive=True)
     avg_us = None
     if stats:
-        shutil.copy(stats[0], os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.csv"))
-        with open(stats[0]) as fh:
-            for row in csv.DictReader(fh):
-                if "k_inner<128, 512, 0>" in row["Name"]:
-                    avg_us = float(row["AverageNs"]) / 1e3
-    out = {"kernel": "k_inner<128,512,0>", "workload": "C2: 256 tasks, N=Nq=128, d=256, I=20", "commit": commit,
-           "avg_duration_us": avg_us, "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write, "pmc_launches": [nf, nw],
-           "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `python bench.py --steps 5 --warmup 2`; KB as reported, summed over "
-                   "XCDs by rocprofv3; bench.py applies the guide's gfx950 correction (2 x FETCH_SIZE: the D2 reads are 16-byte-per-lane streams); "
-                   "compulsory traffic of the launch: read D2 (16.8 MB) + write A^-1 (16.8 MB) + vectors"}
-    with open(os.path.join(ROOT, "profiles", "r02_k_inner_pmc.json"), "w") as fh:
+        shutil.copy(stats[0], os.path.join(prof, "r03_bench_kernel_stats.csv"))
+        avg_us, _ = stats_avg_us(stats[0], KINNER)
+    fetch, nf = per_launch("prof_r03_fetch", ["FETCH_SIZE"])
+    write, nw = per_launch("prof_r03_write", ["WRITE_SIZE"])
+    out = {"kernel": "k_inner<128,512,0,false>", "workload": "C2: 256 tasks, N=Nq=128, d=256, I=20", "commit": commit, "avg_duration_us": avg_us,
+           "FETCH_SIZE_KB_per_launch": fetch["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": write["WRITE_SIZE"], "pmc_launches": [nf, nw],
+           "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters alone with --kernel-trace) of `python bench.py --steps 5 --warmup 2`; "
+                   "KB as reported, summed over XCDs by rocprofv3; bench.py applies the guide's gfx950 correction (2 x FETCH_SIZE: the D2 reads are "
+                   "16-byte-per-lane streams); compulsory traffic of the launch: read D2 (16.8 MB) + write A^-1 (16.8 MB) + vectors"}
+    with open(os.path.join(prof, "r03_k_inner_pmc.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print(out)
+    sq, n1 = per_launch("prof_r03_sq", ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"])
+    lds, n2 = per_launch("prof_r03_lds", ["SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"])
+    sqo = {"kernel": "k_inner<128,512,0,false>", "workload": out["workload"], "commit": commit, "per_launch": {**sq, **{k: v for k, v in lds.items() if k not in sq}},
+           "launches": [n1, n2],
+           "note": "two rocprofv3 --pmc passes (7 SQ/GRBM counters each); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over "
+                   "waves, SQ_VALU_MFMA_BUSY_CYCLES cycles summed over SIMDs (MI355X_MICROARCH.md)"}
+    if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_WAIT_ANY") is not None:
+        sqo["wait_any_frac_of_wave_cycles"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
+        sqo["valu_issue_frac_of_wave_cycles"] = (sq.get("SQ_ACTIVE_INST_VALU") or 0.0) / sq["SQ_WAVE_CYCLES"]
+    with open(os.path.join(prof, "r03_k_inner_sq_pmc.json"), "w") as fh:
+        json.dump(sqo, fh, indent=1)
+    print(sqo)
+    # configuration 5: the blocked fit is many launches; traffic of ONE fit = sum over the kernels between two adkf_fit calls
+    stats5 = glob.glob(os.path.join(OUT, "prof_r03_c5", "**", "*kernel_stats.csv"), recursive=True)
+    if stats5:
+        shutil.copy(stats5[0], os.path.join(prof, "r03_c5_kernel_stats.csv"))
+    fit_kernels = ("k_lg_build", "k_lg_diag", "ProbLgPanel", "ProbLgUpdate", "k_lg_traces", "k_lg_advance", "k_lg_matvec", "k_lg_")
+    def fit_total(pattern, counter, fits):
+        tot = 0.0
+        for row in counter_rows(pattern):
+            if row["Counter_Name"] == counter and any(k in row["Kernel_Name"] for k in fit_kernels):
+                tot += float(row["Counter_Value"])
+        return tot / fits if fits else None
+    fits = 3 + 1      # --steps 3 --warmup 1 in tools/round3_profiles.sh
+    c5 = {"workload": "C5: 8 tasks, N=Nq=1024, d=512, I=20 (blocked path, csrc/large.h)", "commit": commit,
+          "FETCH_SIZE_KB_per_fit": fit_total("prof_r03_c5_fetch", "FETCH_SIZE", fits), "WRITE_SIZE_KB_per_fit": fit_total("prof_r03_c5_write", "WRITE_SIZE", fits),
+          "note": "sum over every k_lg_* / ProbLg* launch of the profile (the blocked inner fit AND the blocked sweep of Sigma_q in the outer stage use "
+                  "these kernels) divided by the 4 meta-steps of the profiled command; KB as reported by rocprofv3"}
+    with open(os.path.join(prof, "r03_c5_fit_pmc.json"), "w") as fh:
+        json.dump(c5, fh, indent=1)
+    print(c5)
 
 
 if __name__ == "__main__":
