@@ -42,7 +42,7 @@ void launch_gemm(const P& p, int T, int M, int N, hipStream_t st) {
 struct Workspace {
     float *mean, *D2ss, *D2qs, *D2qq, *Ainv, *P, *C, *S, *OC, *Wss, *Wqs, *Wqq, *vecs, *scal, *part_oc, *part_ma, *l0;
     // blocked path only (max(ns, nq) > REG_POINTS)
-    float *lg_Dinv, *lg_C, *lg_F, *lg_logdet, *lg_part;
+    float *lg_Dinv, *lg_C, *lg_F, *lg_logdet, *lg_part, *lg_pext;
     int32_t *lg_info, *lg_med;  // lg_med: prefix[T], rank[T], hist[T, 256]
     FitShared* lg_fit;
     double* w64; size_t w64_stride;   // float64 region of the ill-conditioned-task path (refine64.h); null beyond R64_MAXN points
@@ -75,12 +75,13 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
     w.part_oc = take(Tz * (w.nt_oc > 0 ? w.nt_oc : 1) * 4);
     w.part_ma = take(Tz * w.nt_ma * 4);
     w.l0 = take(Tz);
-    w.lg_Dinv = w.lg_C = w.lg_F = w.lg_logdet = w.lg_part = nullptr; w.lg_info = w.lg_med = nullptr; w.lg_fit = nullptr;
+    w.lg_Dinv = w.lg_C = w.lg_F = w.lg_logdet = w.lg_part = w.lg_pext = nullptr; w.lg_info = w.lg_med = nullptr; w.lg_fit = nullptr;
     if (w.vld > REG_POINTS) {
         w.lg_Dinv = take(Tz * LB * LB);
         w.lg_C = take(Tz * LB * w.vld);
         w.lg_F = take(Tz * LB * w.vld);
         w.lg_logdet = take(Tz);
+        w.lg_pext = take(Tz * 2);
         const size_t tq = (size_t)((nq + GT - 1) / GT) * ((nq + GT - 1) / GT);
         const size_t ts = (size_t)((ns + GT - 1) / GT) * ((ns + GT - 1) / GT);
         w.lg_part = take(Tz * (ts > tq ? ts : tq) * 8);
@@ -207,7 +208,7 @@ void launch_inner_k(const InnerArgs& a, hipStream_t st) {
 LgMat lg_mat(const Workspace& w, float* M, int ld, const int32_t* n_arr, const FitShared* fit, int T) {
     LgMat m;
     m.M = M; m.ld = ld; m.n_arr = n_arr; m.fit = fit;
-    m.Dinv = w.lg_Dinv; m.Cbuf = w.lg_C; m.Fbuf = w.lg_F; m.logdet = w.lg_logdet; m.info = w.lg_info;
+    m.Dinv = w.lg_Dinv; m.Cbuf = w.lg_C; m.Fbuf = w.lg_F; m.logdet = w.lg_logdet; m.pext = w.lg_pext; m.info = w.lg_info;
     m.T = T; m.vec = (ld & 3) == 0;
     return m;
 }
@@ -360,7 +361,7 @@ int launch_outer_factor(const OuterArgs& a, const Workspace& w, int nq, hipStrea
         LgColsumArgs cs{a.C, a.tv.ns_ld, (size_t)a.tv.nq_ld * a.tv.ns_ld, a.tv.n_q, a.tv.nq_ld, a.tv.n_s, a.tv.ns_ld,
                         a.vecs + (size_t)V_E * a.tv.vld, (size_t)NVEC * a.tv.vld, a.vecs + (size_t)V_CTE * a.tv.vld, (size_t)NVEC * a.tv.vld};
         k_lg_colsum<<<dim3(ceil_div(a.tv.ns_ld, 64), a.T), 1024, 0, st>>>(cs);
-        LgOuterFin fin{a, w.lg_logdet, w.lg_info};
+        LgOuterFin fin{a, w.lg_logdet, w.lg_info, w.lg_pext};
         k_lg_outer_fin<<<a.T, 64, 0, st>>>(fin);
         LAUNCH_OK();
         return 0;

@@ -31,6 +31,7 @@ struct LgMat {
     float* Cbuf;            // [T, LB, ld]
     float* Fbuf;            // [T, LB, ld]
     float* logdet;          // [T] running log-determinant
+    float* pext;            // [T, 2] smallest / largest pivot so far: the condition estimate that picks the float64 path (refine64.h)
     int32_t* info;          // [T] first non-positive pivot (1-based) or 0
     int T; bool vec;
     __device__ __forceinline__ bool active(int t) const { return !fit || fit[t].phase != PH_DONE; }
@@ -73,10 +74,22 @@ __global__ __launch_bounds__(512) void k_lg_diag(LgMat a, int step) {
         for (int c = 0; c < CB; ++c) neg[c] = -m[r][c];
         store_segment<CB>(Dv + SW::row(r) * LB, SW::col(0), LB, true, true, neg);   // Dinv is [LB, LB] in the 256-byte-aligned workspace
     }
+    // extreme pivots of this block (rows beyond nloc are identity padding: pivot 1, not counted)
+    float plo = INFINITY, phi = 0.f;
+    if ((int)threadIdx.x < nloc) { plo = phi = sm.pivs[threadIdx.x]; }
+    plo = wave_min(plo); phi = wave_max(phi);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sm.red[2 * (threadIdx.x >> 6)] = plo; sm.red[2 * (threadIdx.x >> 6) + 1] = phi; }
+    __syncthreads();
     if (threadIdx.x == 0) {
         a.logdet[t] = (step == 0 ? 0.f : a.logdet[t]) + logdet;
         const int prev = step == 0 ? 0 : a.info[t];
         a.info[t] = prev != 0 ? prev : (info != 0 ? p0 + info : 0);
+        plo = fminf(sm.red[0], sm.red[2]); phi = fmaxf(sm.red[1], sm.red[3]);      // the pivots sit in the first two waves
+        if (a.pext) {
+            a.pext[2 * t] = step == 0 ? plo : fminf(a.pext[2 * t], plo);
+            a.pext[2 * t + 1] = step == 0 ? phi : fmaxf(a.pext[2 * t + 1], phi);
+        }
     }
 }
 
@@ -243,12 +256,14 @@ __global__ __launch_bounds__(256) void k_lg_build(LgInner a) {
 // After the sweep M = -(A^-1): flip the sign in place and reduce tr(Ainv G), alpha^T G alpha, tr(Ainv) per tile.
 __global__ __launch_bounds__(256) void k_lg_traces(LgInner a) {
     __shared__ float red[3 * 4];
+    __shared__ float redmax[4];
     int t, tile;
     if (!task_tile(a.in.T, a.ntiles, t, tile)) return;
     if (!a.mat.active(t)) return;
     const int n = a.mat.n(t), ld = a.in.ld;
     const int m0 = (tile / a.tiles_1d) * GT, n0 = (tile % a.tiles_1d) * GT;
     float acc[3] = {0.f, 0.f, 0.f};
+    float dmax = 0.f;   // largest diagonal entry of A^-1 in this tile: with (s + noise) it is the estimate that picks the float32 refinement of C and alpha
     if (m0 < n && n0 < n) {
         const FitShared& fs = a.fit[t];
         const float os = softplus_f(fs.xe[1]), ls = softplus_f(fs.xe[2]);
@@ -277,14 +292,18 @@ __global__ __launch_bounds__(256) void k_lg_traces(LgInner a) {
                 const float G = os * k1 * u * gl;
                 acc[0] += ai * G;
                 acc[1] += aa[q] * G;
-                if (i == j) acc[2] += ai;
+                if (i == j) { acc[2] += ai; dmax = fmaxf(dmax, ai); }
             }
         }
     }
     block_sum<3, 256>(acc, red);
+    dmax = wave_max(dmax);
+    if ((threadIdx.x & 63) == 0) redmax[threadIdx.x >> 6] = dmax;
+    __syncthreads();
     if (threadIdx.x == 0) {
         float* p = a.part + ((size_t)t * a.ntiles + tile) * 4;
         p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2];
+        p[3] = fmaxf(fmaxf(redmax[0], redmax[1]), fmaxf(redmax[2], redmax[3]));
     }
 }
 
@@ -296,10 +315,13 @@ __global__ __launch_bounds__(64) void k_lg_advance(LgInner a) {
     if (fs.phase == PH_DONE) return;
     const int n = a.mat.n(t);
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float dmax = 0.f;
     for (int q = lane; q < a.ntiles; q += 64) {
         const float* p = a.part + ((size_t)t * a.ntiles + q) * 4;
         acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2];
+        dmax = fmaxf(dmax, p[3]);
     }
+    dmax = wave_max(dmax);
     const float* al = a.in.vecs + ((size_t)t * NVEC + V_ALPHA) * a.in.vld;
     const float* y = a.in.y_s + (size_t)t * a.in.ld;
     for (int i = lane; i < n; i += 64) { const float v = al[i]; acc[3] += v * v; acc[4] += y[i] * v; }
@@ -319,7 +341,14 @@ __global__ __launch_bounds__(64) void k_lg_advance(LgInner a) {
     if (o.g_out) { o.g_out[t * 3 + 0] = g[0]; o.g_out[t * 3 + 1] = g[1]; o.g_out[t * 3 + 2] = g[2]; }
     if (o.gnorm_out) o.gnorm_out[t] = fmaxf(fabsf(g[0]), fmaxf(fabsf(g[1]), fabsf(g[2])));
     if (o.nevals_out) o.nevals_out[t] = fs.evals + 1;
-    if (o.scal) write_inner_scal(o.scal + (size_t)t * NSCAL, xe, f, g, extra);
+    if (o.scal) {
+        float* sc = o.scal + (size_t)t * NSCAL;
+        write_inner_scal(sc, xe, f, g, extra);
+        // the condition estimates of the register path (inner.h), from the blocked sweep: pivot ratio and (s + noise) max diag(A^-1)
+        const float plo = a.mat.pext ? a.mat.pext[2 * t] : 0.f, phi = a.mat.pext ? a.mat.pext[2 * t + 1] : 0.f;
+        sc[S_PIVR_A] = plo > 0.f ? phi / plo : INFINITY;
+        sc[S_CONDA] = (sc[S_OS] + sc[S_NOISE]) * dmax;
+    }
     fs.phase = PH_DONE;
 }
 
@@ -380,7 +409,7 @@ __global__ __launch_bounds__(1024) void k_lg_colsum(LgColsumArgs a) {
 }
 
 // f_out = (r^T e + log|S| + m log 2 pi) / 2  (one wave per task; Cte = C^T e comes from k_lg_colsum)
-struct LgOuterFin { OuterArgs o; const float* logdet; const int32_t* info_s; };
+struct LgOuterFin { OuterArgs o; const float* logdet; const int32_t* info_s; const float* pext; };
 
 __global__ __launch_bounds__(64) void k_lg_outer_fin(LgOuterFin a) {
     const int t = blockIdx.x, lane = threadIdx.x;
@@ -397,6 +426,7 @@ __global__ __launch_bounds__(64) void k_lg_outer_fin(LgOuterFin a) {
         const float f = 0.5f * q + 0.5f * logdet + 0.5f * (float)m * LOG_2PI;
         a.o.scal[(size_t)t * NSCAL + S_FOUT] = f;
         a.o.scal[(size_t)t * NSCAL + S_LOGDETS] = logdet;
+        a.o.scal[(size_t)t * NSCAL + S_PIVR_S] = (a.pext && a.pext[2 * t] > 0.f) ? a.pext[2 * t + 1] / a.pext[2 * t] : INFINITY;
         if (a.o.f_out) a.o.f_out[t] = (info == 0) ? f : NAN;
         if (a.o.reset_info) a.o.info[t] = info != 0 ? 100000 + info : 0;
         else if (info != 0 && a.o.info[t] == 0) a.o.info[t] = 100000 + info;
@@ -522,10 +552,13 @@ __global__ __launch_bounds__(64) void k_lg_wqq_fin(LgWqq a) {
     const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= a.w.T) return;
     float acc[3] = {0.f, 0.f, 0.f};
+    float dmax = 0.f;
     for (int q = lane; q < a.ntiles; q += 64) {
         const float* p = a.part + ((size_t)t * a.ntiles + q) * 4;
         acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2];
+        dmax = fmaxf(dmax, p[3]);
     }
+    dmax = wave_max(dmax);
 #pragma unroll
     for (int k = 0; k < 3; ++k) acc[k] = wave_sum(acc[k]);
     if (lane == 0) {

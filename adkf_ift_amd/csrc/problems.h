@@ -112,7 +112,7 @@ struct ProbCres {
     int n, m; float os, il2, noise; const float *Ci, *Dss, *Dqs; float* Ro; bool vec;
     __device__ bool setup(int t) {
         n = tv.ns(t); m = tv.nq(t); const float* sc = tv.scal + (size_t)t * NSCAL; vec = tv.vec;
-        if (tv.ns_ld <= 128 && !(sc[S_CONDA] > thresh)) return false;
+        if (tv.ns_ld <= 128 && !(sc[S_CONDA] > thresh)) return false;   // (beyond 128 points always: gated by S_CONDA, which large.h writes too, a 256-point task came out at 1.7e-4 on dL/dZ)
         os = sc[S_OS]; il2 = 1.f / (sc[S_LS] * sc[S_LS]); noise = sc[S_NOISE];
         Ci = C + (size_t)t * tv.nq_ld * tv.ns_ld; Dss = D2ss + (size_t)t * tv.ns_ld * tv.ns_ld;
         Dqs = D2qs + (size_t)t * tv.nq_ld * tv.ns_ld; Ro = R + (size_t)t * tv.nq_ld * tv.ns_ld;
@@ -141,7 +141,7 @@ struct ProbCfix {
     int n, m; const float *Ri, *Ai; float* Co; bool vec;
     __device__ bool setup(int t) {
         n = tv.ns(t); m = tv.nq(t); const float* sc = tv.scal + (size_t)t * NSCAL; vec = tv.vec;
-        if (tv.ns_ld <= 128 && !(sc[S_CONDA] > thresh)) return false;
+        if (tv.ns_ld <= 128 && !(sc[S_CONDA] > thresh)) return false;   // (beyond 128 points always: gated by S_CONDA, which large.h writes too, a 256-point task came out at 1.7e-4 on dL/dZ)
         Ri = R + (size_t)t * tv.nq_ld * tv.ns_ld; Ai = Ainv + (size_t)t * tv.ns_ld * tv.ns_ld; Co = C + (size_t)t * tv.nq_ld * tv.ns_ld;
         return n > 0 && m > 0;
     }

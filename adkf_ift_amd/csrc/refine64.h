@@ -195,7 +195,7 @@ __global__ void k_double_path_tasks(const float* scal, int ld, int ldq, float th
     if (t >= T) return;
     const float* sc = scal + (size_t)t * NSCAL;
     const float bound = (sc[S_OS] + sc[S_NOISE]) / sc[S_NOISE];
-    const float ra = ld <= 128 ? sc[S_PIVR_A] : bound, rs = ldq <= 128 ? sc[S_PIVR_S] : bound;
+    const float ra = sc[S_PIVR_A], rs = sc[S_PIVR_S];   // (the blocked path writes both as well: large.h)
     flagged[t] = (ra > thresh || rs > thresh) ? 1 : 0;
 }
 
@@ -212,8 +212,8 @@ __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
     const int kind = a.tv.kind;
     // ---- flagged?
     const float bound = (float)((os + noise) / noise);
-    const float ra = ld <= 128 ? sc[S_PIVR_A] : bound;
-    const float rs = a.want_outer < 2 ? 0.f : (ldq <= 128 ? sc[S_PIVR_S] : bound);
+    const float ra = sc[S_PIVR_A];                 // pivot ratio of the sweep of A: the register path (inner.h) or the blocked one (large.h)
+    const float rs = a.want_outer < 2 ? 0.f : sc[S_PIVR_S];
     if (!(ra > a.thresh || rs > a.thresh)) return;       // uniform over the workgroup
 
     double* W = a.w64 + (size_t)t * a.w64_stride;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(R64_NT) void k_cotangent64(Cot64Args a) {
     const double noise = sc[S_NOISE], os = sc[S_OS], ls = sc[S_LS], il2 = 1.0 / (ls * ls), gl = -2.0 / ls;
     const int kind = a.tv.kind;
     const float bound = (float)((os + noise) / noise);                       // the flag test of k_refine64 (level 2)
-    const float ra = ld <= 128 ? sc[S_PIVR_A] : bound, rs = ldq <= 128 ? sc[S_PIVR_S] : bound;
+    const float ra = sc[S_PIVR_A], rs = sc[S_PIVR_S];   // (the blocked path writes both as well: large.h)
     if (!(ra > a.thresh || rs > a.thresh)) return;
 
     double* W = a.w64 + (size_t)t * a.w64_stride;                            // the layout of k_refine64
