@@ -28,6 +28,8 @@ enum Scal : int {
     S_QQ_TR, S_QQ_K, S_QQ_L,            // reductions of the W_qq kernel: tr(Om), <Om,kappa>, <Om,dK/dl>
     S_PIVR_A, S_PIVR_S,                 // pivot ratio max d_k / min d_k of the sweeps of A and Sigma_q (refine64.h)
     S_CONDA,                            // (s + noise) max_i (A^-1)_ii: who takes the float32 refinement of C and alpha (problems.h ProbCres)
+    S_AREF,                             // 1 once k_alpha_refine has refined THIS alpha (the step must not be applied twice: predict followed by
+                                        // ift_hypergrad on one batch with REUSE_INNER); cleared by whoever writes a new alpha
     S_COUNT_ = 64
 };
 constexpr int NSCAL = 64;

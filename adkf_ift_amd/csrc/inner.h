@@ -444,6 +444,7 @@ __device__ __forceinline__ void write_inner_scal(float* sc, const float* xe, flo
     sc[S_LOGDET] = extra[0]; sc[S_TRAINV] = extra[1]; sc[S_AA] = extra[2]; sc[S_YA] = extra[3];
     sc[S_TRAINVG] = extra[4]; sc[S_AGA] = extra[5];
     sc[S_GT0] = extra[6]; sc[S_GT1] = extra[7]; sc[S_GT2] = extra[8];
+    sc[S_AREF] = 0.f;   // a fresh alpha: not refined yet (k_alpha_refine)
 }
 
 // LOW = true (128 points only; launch_inner_k picks it when the batch has more tasks than the chip has CUs): the fit in <= 128

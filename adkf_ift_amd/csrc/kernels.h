@@ -368,6 +368,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_alpha_refine(AlphaRefineArgs a) {
     const int n = a.tv.ns(t), ld = a.tv.ns_ld, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* sc = a.tv.scal + (size_t)t * NSCAL;
     if (ld > 256 || (ld <= 128 && !(sc[S_CONDA] > a.thresh))) return;     // (uniform; beyond 256 points the blocked path keeps its alpha)
+    if (sc[S_AREF] != 0.f) return;                                         // this alpha has had its step (an earlier call on the same batch with REUSE_INNER)
     const float os = sc[S_OS], noise = sc[S_NOISE], il2 = 1.f / (sc[S_LS] * sc[S_LS]);
     const float* Ai = a.Ainv + (size_t)t * ld * ld;
     const float* D2 = a.D2ss + (size_t)t * ld * ld;
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(SMALL_NT) void k_alpha_refine(AlphaRefineArgs a) {
         s = wave_sum(s);
         if (lane == 0) al[i] += s;
     }
+    if (tid == 0) const_cast<float*>(sc)[S_AREF] = 1.f;
 }
 
 // ---- Stage D core: mu = C y, r = y_q - mu, factor S, e = S^-1 r, f_out, Cte = C^T e --------------------

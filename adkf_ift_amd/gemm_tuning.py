@@ -37,6 +37,12 @@ def use_tuned_gemms(results_file: Optional[str] = None, tune: bool = False) -> s
         os.close(fd)
         shutil.copyfile(path, private)
         path = private
+        import atexit
+        atexit.register(lambda f=private: os.path.exists(f) and os.remove(f))   # one private copy per process, removed with it
+        try:
+            tunable.write_file_on_exit(False)   # nothing is tuned in this mode: there is nothing to write back
+        except Exception:
+            pass
     tunable.enable(True)
     tunable.tuning_enable(bool(tune))
     tunable.set_filename(path, insert_device_ordinal=False)
