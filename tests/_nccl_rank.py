@@ -1,4 +1,4 @@
-"""One rank of tests/test_gpu_nccl.py (started as a FRESH process by the test: the pytest process has already touched the GPU
+"""One rank of tests/test_zz_gpu_nccl.py (started as a FRESH process by the test: the pytest process has already touched the GPU
 and must neither fork nor exec).  Shards the harness fixture's tasks over the ranks, runs trainer.meta_step at the fixture's
 phi through libadkf_gp.so with the gradient all-reduce over RCCL (backend "nccl"), and writes what this rank ended up with.
 

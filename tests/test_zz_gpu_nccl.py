@@ -1,4 +1,7 @@
-"""GPU, two ranks over RCCL (backend "nccl"): the collective of SURVEY section 8(e) on real hardware.  Skipped on a one-GPU
+"""(Named to run LAST: `pytest -x` stops at the first failure, and a multi-GPU rendezvous is the one test here that depends on
+the node around the GPU.)
+
+GPU, two ranks over RCCL (backend "nccl"): the collective of SURVEY section 8(e) on real hardware.  Skipped on a one-GPU
 box (the driver's multi-GPU node runs it).  The ranks are FRESH processes started with subprocess - this pytest process has
 already initialised the GPU and must not fork into, or exec, GPU work.
 
