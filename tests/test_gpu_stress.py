@@ -105,22 +105,21 @@ def test_random_shapes_against_the_oracle(dev, chunk, oracle_pool):
         assert np.abs(phi0_dev - o["p0"]).max() <= 1e-4, desc
         # the optimiser: no worse than the float64 L-BFGS-B optimum (judged on the float64 value AT the device's point)
         assert float(q["f_in"]) <= o["f_star"] + 1e-5 * abs(o["f_star"]) + 2e-6, (desc, t, float(q["f_in"]), got["f_in"], o["f_star"])
-        # Tolerance: 1e-4 (north star) on every output of every case - no allowance for ill-conditioning - or, where the SAME
-        # restatement run in float32 with Cholesky solves on the CPU (what the reference's GPyTorch path does) cannot do
-        # better, 4x that float32 error.  `slack` only accounts for outputs that are themselves sums of cancelling terms:
-        # f_out = (quad + logdet + m log 2pi) / 2 (seen: 0.55 from terms of 58, -114, 57: measured against the size of the
-        # terms); grad_phi f_out, a difference of traces of the size of f_out that nearly cancel for a well-fitted task (seen:
-        # |g| = 0.046 at f_out = 9.9: held to 1e-4 of max(|g_out|, 0.01 |f_out|)); and v = H^-1 g_out (whatever absolute error
-        # g_out is allowed, times |H^-1|_inf).  How many comparisons pass ONLY through the 4 x e32 branch is counted and listed.
+        # Tolerance: 1e-4 (north star) on every output of every case - no allowance for ill-conditioning and, since round 3, no
+        # "4 x what float32 Cholesky solves reach" branch either: the suite counted how many of its 1 620 comparisons needed that
+        # branch - none (worst error / tolerance 0.84) - so it is gone; the float32 restatement's error is still printed.  `slack`
+        # only accounts for outputs that are themselves sums of cancelling terms: f_out = (quad + logdet + m log 2pi) / 2 (seen:
+        # 0.55 from terms of 58, -114, 57: measured against the size of the terms); grad_phi f_out, a difference of traces of the
+        # size of f_out that nearly cancel for a well-fitted task (seen: |g| = 0.046 at f_out = 9.9: held to 1e-4 of
+        # max(|g_out|, 0.01 |f_out|)); and v = H^-1 g_out (whatever absolute error g_out is allowed, times |H^-1|_inf).
         well = o["cond"] <= 100.0
         for k, v in got.items():
             e, e32 = _rel(v, q[k]), o["e32"][k]
-            tol_plain = TOL * o["slack"].get(k, 1.0)
-            tol = max(tol_plain, 4.0 * e32)
+            tol = TOL * o["slack"].get(k, 1.0)
             n_cmp += 1
-            if e > tol_plain and e <= tol:
-                n_e32_branch += 1
-                print("passes through 4 x e32 only (case, task, output, err, e32, cond):", desc["case"], t, k, "%.2e" % e, "%.2e" % e32, "%.1e" % o["cond"])
+            if e > tol and e <= 4.0 * e32:
+                n_e32_branch += 1      # (would have passed under round 2's rule: reported, fails all the same)
+                print("above the tolerance but within 4 x the float32 restatement's error (case, task, output, err, e32, cond):", desc["case"], t, k, "%.2e" % e, "%.2e" % e32, "%.1e" % o["cond"])
             worst[k] = max(worst.get(k, 0.0), e / tol)
             if e > 0.1 * TOL:
                 kk = ("well " if well else "ill ") + k
@@ -129,7 +128,7 @@ def test_random_shapes_against_the_oracle(dev, chunk, oracle_pool):
                 failures.append((desc["case"], t, k, float("%.2e" % e), float("%.2e" % e32), float("%.1e" % o["cond"]), n, m, d, kind))
     print("worst error / tolerance:", {k: float("%.2f" % v) for k, v in worst.items()})
     print("worst relative error by regime (where > 1e-5):", worst32)
-    print("comparisons: %d, of which %d needed the 4 x e32 branch" % (n_cmp, n_e32_branch))
+    print("comparisons: %d, all held to 1e-4 x slack (%d of them would have needed round 2's 4 x e32 branch)" % (n_cmp, n_e32_branch))
     for f_ in failures:
         print("FAIL (case, task, output, err, fp32-autograd err, cond, n, m, d, kind):", f_)
     assert not failures, failures[:5]
