@@ -127,9 +127,12 @@ def time_tasks(tasks, kind: int, inner_evals: int, budget_s: float = 15.0, regre
     Returns (tasks per second, tasks done, OpenMP threads)."""
     Zs, Zq = tasks.features()
     Zs, Zq, ys, yq = (a.numpy() for a in (Zs, Zq, tasks.y_s, tasks.y_q))
-    lib = load()
-    lib.adkf_version.restype = C.c_char_p
-    threads = os.cpu_count() or 1
+    load()
+    # the cores we actually own, like the "port" baseline (oracle/ref_cpu_path.py): a GPU box shows 256 logical CPUs of which a
+    # one-GPU job has about 16
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = min(avail, 16)
+    C.CDLL("libgomp.so.1").omp_set_num_threads(threads)
     done, t_used, chunk = 0, 0.0, min(len(Zs), max(threads, 16))
     while done < len(Zs) and t_used < budget_s:
         sl = slice(done, min(len(Zs), done + chunk))
