@@ -335,8 +335,9 @@ void launch_refine(const TaskView& tv, const adkf_batch_t* b, const Workspace& w
     const float thresh = r64_threshold();
     // up to R64_LDS_POINTS points the float64 inverses run in LDS: 128 KB of dynamic shared memory (one workgroup per CU then; the
     // kernel is a two-scalar test for everybody but the flagged tasks)
-    const bool lds_inv = w.vld <= R64_LDS_POINTS;
-    const size_t lds_bytes = lds_inv ? sizeof(double) * (size_t)w.vld * w.vld : 0;
+    const bool lds_inv = true;   // (beyond R64_LDS_POINTS the diagonal blocks of the blocked inverse live there)
+    const size_t lds_pts = w.vld <= R64_LDS_POINTS ? (size_t)w.vld : (size_t)R64_LDS_POINTS;
+    const size_t lds_bytes = sizeof(double) * lds_pts * lds_pts;
     static const bool attr_set = [] {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_refine64), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(double) * R64_LDS_POINTS * R64_LDS_POINTS));

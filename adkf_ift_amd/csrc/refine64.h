@@ -28,7 +28,8 @@ namespace adkf {
 
 constexpr int R64_NT = 512;
 constexpr int R64_LDS_POINTS = 128;   // r64_inverse works in LDS up to this many points (n^2 doubles of dynamic shared memory)
-constexpr int R64_MAXN = 256;          // float64 region is carved for batches up to this many points
+constexpr int R64_MAXN = 1024;         // float64 region is carved for batches up to this many points (round 3: was 256; beyond R64_LDS_POINTS the
+                                       // inverses run blocked, r64_inverse_blocked)
 constexpr float R64_THRESHOLD = 30.f;
 
 struct Refine64Args {
@@ -46,8 +47,13 @@ struct Refine64Args {
 inline __host__ __device__ size_t r64_dd_offset(int ns, int nq) {
     return 3 * (size_t)ns * ns + 2 * (size_t)nq * ns + 2 * (size_t)nq * nq + 8 * (size_t)(ns > nq ? ns : nq);
 }
+// scratch of the blocked inverse behind the distances: the diagonal block, D^-1 M[K, :] and the new column panel
+inline __host__ __device__ size_t r64_scratch_offset(int ns, int nq) {
+    return r64_dd_offset(ns, nq) + (size_t)ns * ns + (size_t)nq * ns + (size_t)nq * nq;
+}
 inline size_t refine64_doubles(int ns, int nq) {
-    return r64_dd_offset(ns, nq) + (size_t)ns * ns + (size_t)nq * ns + (size_t)nq * nq + 64;
+    const size_t vmax = (size_t)(ns > nq ? ns : nq);
+    return r64_scratch_offset(ns, nq) + (size_t)R64_LDS_POINTS * R64_LDS_POINTS + 2 * (size_t)R64_LDS_POINTS * vmax + 64;
 }
 
 // C(i, j) = sum_k fa(i, k) fb(k, j), delivered element by element to fe(i, j, value): the O(n^3) products of the float64 path on
@@ -188,6 +194,48 @@ __device__ int r64_inverse(double* M, int n, int ld, double& logdet, double* col
     return bad;
 }
 
+// The same for more than R64_LDS_POINTS points: block Gauss-Jordan with 128-pivot blocks - the diagonal block inverted in LDS by
+// r64_inverse, the panel products and the rank-128 update on the FP64 matrix pipe (r64_mm).  `scr`: NB^2 + 2 NB n doubles.
+//   M[K,K] <- D^-1,   M[K,j] <- D^-1 M[K,j],   M[i,K] <- -M[i,K] D^-1,   M[i,j] <- M[i,j] - M[i,K] D^-1 M[K,j]     (i, j outside K)
+__device__ int r64_inverse_blocked(double* M, int n, int ld, double& logdet, double* colv, double* rowv, double* lds, double* scr) {
+    constexpr int NB = R64_LDS_POINTS;
+    const int tid = threadIdx.x;
+    double* Db = scr;                           // [nb][nb]
+    double* F = Db + (size_t)NB * NB;           // [nb][n]
+    double* Tm = F + (size_t)NB * n;            // [n][nb]
+    int bad = 0;
+    double ld_acc = 0.0;
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int nb = n - k0 < NB ? n - k0 : NB;
+        __syncthreads();
+        for (int e = tid; e < nb * nb; e += R64_NT) { const int i = e / nb, j = e - i * nb; Db[e] = M[(size_t)(k0 + i) * ld + k0 + j]; }
+        __syncthreads();
+        double ldp;
+        const int b = r64_inverse(Db, nb, nb, ldp, colv, rowv, lds);
+        if (b && !bad) bad = k0 + b;
+        ld_acc += ldp;
+        r64_mm(nb, n, nb, [=](int i, int k) { return Db[(size_t)i * nb + k]; }, [=](int k, int j) { return M[(size_t)(k0 + k) * ld + j]; },
+               [=](int i, int j, double v) { F[(size_t)i * n + j] = v; });
+        r64_mm(n, nb, nb, [=](int i, int k) { return M[(size_t)i * ld + k0 + k]; }, [=](int k, int j) { return Db[(size_t)k * nb + j]; },
+               [=](int i, int j, double v) { Tm[(size_t)i * nb + j] = -v; });
+        r64_mm(n, n, nb, [=](int i, int k) { return M[(size_t)i * ld + k0 + k]; }, [=](int k, int j) { return F[(size_t)k * n + j]; },
+               [=](int i, int j, double v) {   // (reads columns K and F only, writes outside K: no hazard between the tiles)
+                   if ((i < k0 || i >= k0 + nb) && (j < k0 || j >= k0 + nb)) M[(size_t)i * ld + j] -= v;
+               });
+        for (int e = tid; e < nb * n; e += R64_NT) {
+            const int i = e / n, j = e - i * n;
+            if (j < k0 || j >= k0 + nb) M[(size_t)(k0 + i) * ld + j] = F[e];
+        }
+        for (int e = tid; e < n * nb; e += R64_NT) {
+            const int i = e / nb, j = e - i * nb;
+            M[(size_t)i * ld + k0 + j] = (i >= k0 && i < k0 + nb) ? Db[(size_t)(i - k0) * nb + j] : Tm[e];
+        }
+    }
+    __syncthreads();
+    logdet = ld_acc;
+    return bad;
+}
+
 // Diagnostic (adkf_double_path_tasks): which tasks of the last adkf_ift_hypergrad / adkf_outer_nll_value_grad on this workspace took
 // the float64 path - the same test as in k_refine64 (level 2) below.
 __global__ void k_double_path_tasks(const float* scal, int ld, int ldq, float thresh, int T, int32_t* flagged) {
@@ -249,7 +297,9 @@ __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
         A1[(size_t)i * ld + j] = os * k0 + (i == j ? noise : 0.0);
     }
     double logdetA;
-    const int badA = r64_inverse(A1, n, ld, logdetA, gjc, gjr, a.lds_inverse ? r64_lds : nullptr);
+    double* scr = W + r64_scratch_offset(ld, ldq);
+    const int badA = n <= R64_LDS_POINTS ? r64_inverse(A1, n, ld, logdetA, gjc, gjr, a.lds_inverse ? r64_lds : nullptr)
+                                         : r64_inverse_blocked(A1, n, ld, logdetA, gjc, gjr, r64_lds, scr);
     float* Ai32 = a.Ainv + (size_t)t * ld * ld;
     for (int e = tid; e < n * n; e += R64_NT) { const int i = e / n, j = e % n; Ai32[(size_t)i * ld + j] = (float)A1[(size_t)i * ld + j]; }
     r64_mv(n, n, [=](int i, int k) { return A1[(size_t)i * ld + k]; }, [=](int k) { return (double)ys[k]; },
@@ -376,7 +426,8 @@ __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
                S1[(size_t)i * ldq + j] = sv; S1[(size_t)j * ldq + i] = sv;
            });
     double logdetS;
-    const int badS = r64_inverse(S1, m, ldq, logdetS, gjc, gjr, a.lds_inverse ? r64_lds : nullptr);
+    const int badS = m <= R64_LDS_POINTS ? r64_inverse(S1, m, ldq, logdetS, gjc, gjr, a.lds_inverse ? r64_lds : nullptr)
+                                         : r64_inverse_blocked(S1, m, ldq, logdetS, gjc, gjr, r64_lds, scr);
     if (a.S) {
         float* S32 = a.S + (size_t)t * ldq * ldq;
         for (int e = tid; e < m * m; e += R64_NT) { const int i = e / m, j = e % m; S32[(size_t)i * ldq + j] = (float)S1[(size_t)i * ldq + j]; }

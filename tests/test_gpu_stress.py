@@ -211,3 +211,50 @@ def test_ill_conditioned_regression_task_is_resolved_stably(dev):
     gp_ops.check_info(info2)
     assert _rel(mean2[0].cpu().numpy(), q["pred_mean"]) <= 1e-4
     assert _rel(var2[0].cpu().numpy(), q["pred_var"]) <= 1e-4
+
+
+@pytest.mark.parametrize("N, Nq, n_s, n_q", [(300, 320, [300, 262], [320, 290]), (520, 260, [520], [257])])
+def test_float64_path_beyond_256_points(dev, N, Nq, n_s, n_q, oracle_pool):
+    """Low-dimensional regression tasks (d = 3: ill-conditioned, flagged) with more than 256 support AND query points: the float64
+    path's inverses run blocked there (refine64.h r64_inverse_blocked; up to round 2 such tasks stayed on float32 + refinement).
+    Every output is held to the same 1e-4 x slack as the random sweep, at the device's fitted point."""
+    from adkf_ift_amd import gp_ops
+    from adkf_ift_amd.synthetic import make_tasks
+    from _stress_oracle import oracle_bundle
+
+    T = len(n_s)
+    tasks = make_tasks(T, N, 3, N_q=Nq, regression=True, first_task=4100)
+    Zs, Zq = tasks.features()
+    Zs, Zq, ys, yq = Zs.clone(), Zq.clone(), tasks.y_s.clone(), tasks.y_q.clone()
+    for t in range(T):
+        Zs[t, n_s[t]:] = 7.5; ys[t, n_s[t]:] = -3.0
+        Zq[t, n_q[t]:] = -2.5; yq[t, n_q[t]:] = 9.0
+    b = gp_ops.GPBatch(Zs.to(dev), ys.to(dev), torch.empty(T, 4, device=dev), "matern", Z_q=Zq.to(dev), y_q=yq.to(dev),
+                       n_s=torch.tensor(n_s, dtype=torch.int32), n_q=torch.tensor(n_q, dtype=torch.int32))
+    phi0, _ = gp_ops.init_params_batch(b, True, True)
+    b.flags = gp_ops.REUSE_DIST
+    phi, f_in, _, _, info = gp_ops.fit(b, phi0, 200)
+    gp_ops.check_info(info)
+    b.flags = gp_ops.REUSE_DIST | gp_ops.REUSE_INNER
+    out = gp_ops.ift_hypergrad(b, phi)
+    gp_ops.check_info(out["info"])
+    flagged = gp_ops.double_path_tasks(b).cpu().tolist()
+    print("float64 path:", flagged)
+    assert sum(flagged) >= 1, "the case is meant to exercise the blocked float64 path"
+    mean, var, _, info = gp_ops.predict(b, phi)
+    gp_ops.check_info(info)
+    futs = [oracle_pool.submit(oracle_bundle, (Zs[t, :n_s[t]].clone(), ys[t, :n_s[t]].clone(), Zq[t, :n_q[t]].clone(), yq[t, :n_q[t]].clone(),
+                                               phi[t].cpu().clone(), 1, True)) for t in range(T)]
+    for t in range(T):
+        n, m = n_s[t], n_q[t]
+        o = futs[t].result(timeout=900)
+        q = o["q"]
+        got = {"f_in": f_in[t].item(), "H": out["H"][t].cpu().numpy(), "f_out": out["f_out"][t].item(), "g_out": out["g_phi"][t].cpu().numpy(),
+               "v": out["v"][t].cpu().numpy(), "dZs_total": out["dZ_s"][t, :n].cpu().numpy(), "dZq_total": out["dZ_q"][t, :m].cpu().numpy(),
+               "pred_mean": mean[t, :m].cpu().numpy(), "pred_var": var[t, :m].cpu().numpy()}
+        errs = {k: (_rel(v, q[k]), TOL * o["slack"].get(k, 1.0)) for k, v in got.items()}
+        print("task", t, "flagged", flagged[t], "cond %.1e" % o["cond"], {k: "%.1e/%.1e" % e for k, e in errs.items()})
+        assert float(out["dZ_s"][t, n:].abs().max() if n < N else 0.0) == 0.0
+        assert float(out["dZ_q"][t, m:].abs().max() if m < Nq else 0.0) == 0.0
+        for k, (e, tol) in errs.items():
+            assert e <= tol, (t, k, e, tol, o["cond"])
