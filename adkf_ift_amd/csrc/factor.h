@@ -383,14 +383,17 @@ template <int NMAX, int NT> struct Sweep : SweepBlk<NMAX, NT> {};
 }  // namespace adkf
 
 // 128 points x 512 threads: ADKF_SWEEP_M (default) = rank-4 updates on the matrix pipe (factor_m.h); ADKF_SWEEP_M=0 keeps the
-// VALU variant of factor_w.h, ADKF_SWEEP_M=0 ADKF_SWEEP_W=0 the blocked one above, for A/B measurements.
+// VALU variant of factor_w.h, ADKF_SWEEP_M=0 ADKF_SWEEP_W=0 the blocked one above, ADKF_SWEEP_M=2 the sixteen-pivot experiment of
+// factor_m16.h (slower: see its header), for A/B measurements.
 #ifndef ADKF_SWEEP_M
 #define ADKF_SWEEP_M 1
 #endif
 #ifndef ADKF_SWEEP_W
 #define ADKF_SWEEP_W 1
 #endif
-#if ADKF_SWEEP_M
+#if ADKF_SWEEP_M == 2
+#include "factor_m16.h"
+#elif ADKF_SWEEP_M
 #include "factor_m.h"
 #elif ADKF_SWEEP_W
 #include "factor_w.h"

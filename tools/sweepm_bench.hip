@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
         hipMemcpy(st.data(), daux + (size_t)T * 256, 1024, hipMemcpyDeviceToHost);
         unsigned long long t0 = ~0ull;
         for (int w = 0; w < 8; ++w) if (st[w * 16] && st[w * 16] < t0) t0 = st[w * 16];
-        printf("stamps of step %d (one site per build: 0 after barrier, 1 A operand ready, 2 tile 0 issued (+ piece stored) | chain: 3 GJ half, 4 GJ done, 5 D^-1 stored | 6 end of step, 7 at the next barrier)\n", ADKF_STAMP);
+        printf("stamps of step %d (0 after barrier, 1 A operand ready, 2 piece stored | chain: 3 / 7 / 8 / 4 after its sub-steps, 5 inverse stored | 6 end of step; columns 0 1 2 3 4 5 6 7 8 9)\n", ADKF_STAMP);
         for (int w = 0; w < 8; ++w) { printf("wave %d:", w); for (int k = 0; k < 10; ++k) printf(" %6lld", st[w * 16 + k] >= t0 && st[w*16+k] - t0 < 100000 ? (long long)(st[w * 16 + k] - t0) : -1ll); printf("\n"); }
     }
 #endif
