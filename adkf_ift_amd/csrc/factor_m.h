@@ -34,6 +34,13 @@
 // and LDS offsets are compile-time constants; the first step's "previous" operands are zeros, and the last step's update is
 // flushed after the loop.  Two vector slots: the writers of step s fill slot (s + 1) & 1 while everybody reads slot s & 1,
 // whose previous readers (step s - 1) passed the barrier of step s with their reads complete.
+//
+// Who goes first behind the barrier (round 3, second session).  A SIMD's matrix pipe takes the MFMAs of its two waves in the
+// order they were issued, and the LDS serves reads in the order they arrive: whatever the other waves put in front of the
+// chain wave's three critical reads and its one critical MFMA is what the hand-off waits for.  Only the next owner is on the
+// chain - the others' pieces are not needed before the next barrier, i.e. they have the inversion's ~190 cycles of slack - so
+// every wave but the chain wave sleeps 128 cycles behind the barrier (ADKF_M_SLEEP): 37.2 k -> 35.0 k cycles per sweep; with
+// only the chain wave's SIMD partner (wave + 4) sleeping 35.6 k, i.e. most of it is the partner's early MFMAs.
 #pragma once
 #ifndef ADKF_M_ABLATE
 #define ADKF_M_ABLATE 0   // timing-only ablations for tools/sweepm_bench.hip (2: no inversion, 8: no MFMA at all, 16: one B read instead of eight, 32: no owner work at all, 64: no pieces)
@@ -43,6 +50,12 @@
 #endif
 #ifndef ADKF_M_A128
 #define ADKF_M_A128 1     // 1: the A operand from two 16-byte LDS reads and four FMAs (36.2 k cycles per sweep); 0: from two dword reads, the row swaps of gfx950 and four DPP FMAs (37.9 k: the swap sequence with its hazard waits is on the hand-off chain)
+#endif
+#ifndef ADKF_M_SLEEP
+#define ADKF_M_SLEEP 2    // s_sleep argument (x 64 cycles) of the waves that are NOT on the hand-off chain, right behind the barrier: 37.2 k -> 35.0 k cycles per sweep (1: 37.0 k, 3: 35.8 k)
+#endif
+#ifndef ADKF_M_SLEEP_MODE
+#define ADKF_M_SLEEP_MODE 0   // who sleeps.  0: every wave but the chain wave (35.0 k); 1: only the chain wave's SIMD partner, wave + 4 (35.6 k: most of the gain is there); 2: everybody but the chain wave, behind its LDS reads instead of in front of them (37.0 k: no gain)
 #endif
 #ifndef ADKF_M_MID
 #define ADKF_M_MID 1      // ... and between the critical MFMA and the piece that is read out of its result (they cover its latency)
@@ -234,6 +247,11 @@ template <> struct Sweep<128, 512> {
         const bool is_chain = has_next && w == WN && !(ADKF_M_ABLATE & 32);
         ADKF_MTS(0);
         if (is_chain) __builtin_amdgcn_s_setprio(3);
+#if ADKF_M_SLEEP && ADKF_M_SLEEP_MODE == 0
+        else __builtin_amdgcn_s_sleep(ADKF_M_SLEEP);
+#elif ADKF_M_SLEEP && ADKF_M_SLEEP_MODE == 1
+        else if (w == ((WN + 4) & 7)) __builtin_amdgcn_s_sleep(ADKF_M_SLEEP);   // (experiment: the other waves have the inversion's ~190 cycles of slack - let the chain wave's LDS reads go first)
+#endif
         // the operands of the hand-off chain first: D^-1, the wave's own columns, the critical tile's B; then the other seven
         const float* ctr = &sm.ct[SLOT][0][0];
 #if ADKF_M_A128
@@ -250,6 +268,10 @@ template <> struct Sweep<128, 512> {
         for (int x = 0; x < 8; ++x)
             if (x != WN) cur.b[x] = (ADKF_M_ABLATE & 16) ? cur.b[WN] * (1.f + x) : ctr[ad.b + 64 * x];
         __builtin_amdgcn_sched_barrier(0);   // all ten reads in flight; the matrix pipe gets the previous step's update meanwhile
+#if ADKF_M_SLEEP && ADKF_M_SLEEP_MODE == 2
+        if (!is_chain) __builtin_amdgcn_s_sleep(ADKF_M_SLEEP);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         bulk<WN, 0, ADKF_M_EARLY>(acc, prev);
         __builtin_amdgcn_sched_barrier(0);
 #if ADKF_M_A128
@@ -260,6 +282,7 @@ template <> struct Sweep<128, 512> {
         ADKF_MTS(1);
         mfma<WN>(acc, cur.a, cur.b[WN]);     // this step's update of the tile the next hand-off comes out of
         __builtin_amdgcn_sched_barrier(0);
+
         bulk<WN, ADKF_M_EARLY, ADKF_M_EARLY + ADKF_M_MID>(acc, prev);
         __builtin_amdgcn_sched_barrier(0);
         if (has_next) {

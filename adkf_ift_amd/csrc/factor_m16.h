@@ -34,8 +34,14 @@
 //     sweeps in place (sub_chain) with its own 28 bulk MFMAs riding in the Gauss-Jordan stream and in the LDS waits; its result
 //     -E^-1 stays in the tile (M_PP of the classical sweep), is published, and the tile is left out of that wave's next update.
 #pragma once
+#ifndef ADKF_M16_TURN
+#define ADKF_M16_TURN 0   // (0 is faster: 26.5 k against 31.5 k cycles for the chain alone) 1: D^-1 reaches the other lanes as sixteen v_readlane -> SGPR operands of the A operand's FMAs, the pivot rows' read is issued in front of the Gauss-Jordan stream; 0: both through LDS behind it
+#endif
+#ifndef ADKF_M16_PACE
+#define ADKF_M16_PACE 1   // s_sleep argument between pairs of the chain wave's SIMD partner's bulk MFMAs (0: none)
+#endif
 #ifndef ADKF_M_ABLATE
-#define ADKF_M_ABLATE 0   // timing-only ablations for tools/sweepm_bench.hip (2: no 16 x 16 sweep, 8: no bulk MFMAs)
+#define ADKF_M_ABLATE 0   // timing-only ablations for tools/sweepm_bench.hip (2: no 16 x 16 sweep, 8: no bulk MFMAs, 32: none of the chain wave's own)
 #endif
 
 namespace adkf {
@@ -162,13 +168,19 @@ template <> struct Sweep<128, 512> {
     // is inverted by gj4; the rank-4 update of the whole tile is one MFMA whose operands come off a 320-byte turn-table in LDS
     // that only this wave touches (a wave's LDS instructions execute in order: no barrier, no wait beyond the reads' own).
     template <int SB>
-    __device__ static __forceinline__ void sub_prepare(f32x4_t& t, float (&D)[4], Smem& sm) {
+    __device__ static __forceinline__ void sub_prepare(f32x4_t& t, float (&D)[4], float4& c4, Smem& sm) {
         const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4, a = p & 3;
         const bool rowg = g == SB, dq = rowg && (p >> 2) == SB;
         D[0] = t.x; D[1] = t.y; D[2] = t.z; D[3] = t.w;          // quad lane a: column a of D = row a
         f32x4_t c = t;                                             // C': D - I at the pivot columns
         c.x -= (dq && a == 0) ? 1.f : 0.f; c.y -= (dq && a == 1) ? 1.f : 0.f; c.z -= (dq && a == 2) ? 1.f : 0.f; c.w -= (dq && a == 3) ? 1.f : 0.f;
         if (rowg) *reinterpret_cast<float4*>(&sm.cw[p][0]) = make_float4(c.x, c.y, c.z, c.w);
+#if ADKF_M16_TURN
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        c4 = ld4(&sm.cw[p][0]);
+#endif
         // M_PP := D - 2I
         t.x -= (dq && a == 0) ? 2.f : 0.f; t.y -= (dq && a == 1) ? 2.f : 0.f; t.z -= (dq && a == 2) ? 2.f : 0.f; t.w -= (dq && a == 3) ? 2.f : 0.f;
     }
@@ -177,6 +189,20 @@ template <> struct Sweep<128, 512> {
     __device__ static __forceinline__ void sub_turn(const float (&D)[4], const float (&piv)[4], float4& c4, float4& d4, Smem& sm) {
         const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4, a = p & 3;
         const bool dq = g == SB && (p >> 2) == SB;
+#if ADKF_M16_TURN
+        if (dq && a == 0) *reinterpret_cast<float4*>(&sm.pivs[16 * X + 4 * SB]) = make_float4(piv[0], piv[1], piv[2], piv[3]);
+        // G[j][k] = D[k] of lane 20 SB + j; this lane needs row g: r_j = sum_k G[j][k] c4[k], selected by g
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, D[0]), 20 * SB + j));
+            const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, D[1]), 20 * SB + j));
+            const float g2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, D[2]), 20 * SB + j));
+            const float g3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, D[3]), 20 * SB + j));
+            r[j] = fmaf(g0, c4.x, fmaf(g1, c4.y, fmaf(g2, c4.z, g3 * c4.w)));
+        }
+        d4 = make_float4(r[0], r[1], r[2], r[3]);
+#else
         if (dq) {
             *reinterpret_cast<float4*>(&sm.dw[a][0]) = make_float4(D[0], D[1], D[2], D[3]);
             if (a == 0) *reinterpret_cast<float4*>(&sm.pivs[16 * X + 4 * SB]) = make_float4(piv[0], piv[1], piv[2], piv[3]);
@@ -186,10 +212,15 @@ template <> struct Sweep<128, 512> {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         c4 = ld4(&sm.cw[p][0]);
         d4 = ld4(&sm.dw[g][0]);
+#endif
     }
     __device__ static __forceinline__ void sub_update(f32x4_t& t, const float4& c4, const float4& d4) {
         const int g = (threadIdx.x & 63) >> 4;
+#if ADKF_M16_TURN
+        const float av = -(g == 0 ? d4.x : g == 1 ? d4.y : g == 2 ? d4.z : d4.w);
+#else
         const float av = -fmaf(d4.x, c4.x, fmaf(d4.y, c4.y, fmaf(d4.z, c4.z, d4.w * c4.w)));
+#endif
         const float bv = g == 0 ? c4.x : g == 1 ? c4.y : g == 2 ? c4.z : c4.w;
         t = mfma(av, bv, t);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next sub-step's stores stay behind these reads
@@ -200,7 +231,7 @@ template <> struct Sweep<128, 512> {
     __device__ static __forceinline__ void sub_plain(f32x4_t& t, Smem& sm) {
         float D[4], piv[4];
         float4 c4, d4;
-        sub_prepare<SB>(t, D, sm);
+        sub_prepare<SB>(t, D, c4, sm);
         if (!(ADKF_M_ABLATE & 2)) gj4(D, piv); else { piv[0] = piv[1] = piv[2] = piv[3] = 1.f; }
         sub_turn<SB, X>(D, piv, c4, d4, sm);
         sub_update(t, c4, d4);
@@ -242,27 +273,29 @@ template <> struct Sweep<128, 512> {
         constexpr int NX = (S + 1) & 7, SLOT = S & 1, TG = (NX + 1 + 2 * SB) & 7;
         float D[4], piv[4];
         float4 c4, d4;
-        sub_prepare<SB>(acc[NX], D, sm);
+        sub_prepare<SB>(acc[NX], D, c4, sm);
         __builtin_amdgcn_sched_barrier(0);
 #if (ADKF_M_ABLATE & 2)
         piv[0] = piv[1] = piv[2] = piv[3] = 1.f;
         upd<TG, 0>(acc, nf, b4); upd<TG, 1>(acc, nf, b4); upd<TG, 2>(acc, nf, b4); upd<TG, 3>(acc, nf, b4);
-#elif (ADKF_M_ABLATE & 8)
+#elif (ADKF_M_ABLATE & (8 | 32))
         gj4(D, piv);
 #else
         gj4m(D, piv, acc[TG], nf, b4[TG]);
 #endif
         __builtin_amdgcn_sched_barrier(0);
         sub_turn<SB, NX>(D, piv, c4, d4, sm);
-        if (SB == 0) {   // the B operands of the tiles that have not been fetched yet queue up behind the turn-table reads
+        if (SB == 0 && !(ADKF_M_ABLATE & 32)) {   // the B operands of the tiles that have not been fetched yet queue up behind the turn-table reads
             const float* ctr = &sm.ct[SLOT][0][0];
 #pragma unroll
             for (int i = 3; i <= 7; ++i) b4[(NX + i) & 7] = ld4(ctr + ad.b + 16 * CS * ((NX + i) & 7));
         }
         __builtin_amdgcn_sched_barrier(0);
-        riders<NX, 3 * SB, 3 * SB + 3>(acc, nf, b4);
-        __builtin_amdgcn_sched_barrier(0);
         sub_update(acc[NX], c4, d4);
+        __builtin_amdgcn_sched_barrier(0);
+        // three more MFMAs BEHIND the tile's own: the matrix pipe takes a SIMD's MFMAs in the order they were issued, so
+        // whatever goes in first is what the chain waits for
+        if (!(ADKF_M_ABLATE & 32)) riders<NX, 3 * SB, 3 * SB + 3>(acc, nf, b4);
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -327,8 +360,12 @@ template <> struct Sweep<128, 512> {
             for (int i = 3; i <= 7; ++i) b4[(NX + i) & 7] = ld4(ctr + ad.b + 16 * CS * ((NX + i) & 7));
             __builtin_amdgcn_sched_barrier(0);
             // seven tiles, chunk-major (consecutive MFMAs independent); tile S of wave S holds -E^-1 already
-#define ADKF_M16_BULK(Y) do { upd<(NX + 1) & 7, Y>(acc, nf, b4); upd<(NX + 2) & 7, Y>(acc, nf, b4); upd<(NX + 3) & 7, Y>(acc, nf, b4); upd<(NX + 4) & 7, Y>(acc, nf, b4); \
-                              upd<(NX + 5) & 7, Y>(acc, nf, b4); upd<(NX + 6) & 7, Y>(acc, nf, b4); if (w != S) upd<S, Y>(acc, nf, b4); } while (0)
+            // (the chain wave's SIMD partner - waves w and w + 4 share a SIMD - spaces its MFMAs out: a SIMD's matrix pipe takes
+            // MFMAs in issue order, and 28 of them issued back to back are 900 cycles the chain wave's own would queue behind)
+            const bool paced = ADKF_M16_PACE && w == ((NX + 4) & 7);
+#define ADKF_M16_GAP() do { __builtin_amdgcn_sched_barrier(0); if (paced) __builtin_amdgcn_s_sleep(ADKF_M16_PACE); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ADKF_M16_BULK(Y) do { upd<(NX + 1) & 7, Y>(acc, nf, b4); upd<(NX + 2) & 7, Y>(acc, nf, b4); ADKF_M16_GAP(); upd<(NX + 3) & 7, Y>(acc, nf, b4); upd<(NX + 4) & 7, Y>(acc, nf, b4); ADKF_M16_GAP(); \
+                              upd<(NX + 5) & 7, Y>(acc, nf, b4); upd<(NX + 6) & 7, Y>(acc, nf, b4); ADKF_M16_GAP(); if (w != S) upd<S, Y>(acc, nf, b4); } while (0)
             ADKF_M16_BULK(0); ADKF_M16_BULK(1); ADKF_M16_BULK(2); ADKF_M16_BULK(3);
         }
         ADKF_MTS(6);
