@@ -375,17 +375,6 @@ int launch_outer_factor(const OuterArgs& a, const Workspace& w, int nq, hipStrea
     return 0;
 }
 
-void launch_rowsums(const RowsumArgs& ra, const Workspace& w, hipStream_t st) {
-    const TaskView& tv = ra.tv;
-    if (w.vld <= REG_POINTS) { k_rowsums<<<grid_for(ra.T, 1), SMALL_NT, 0, st>>>(ra); return; }
-    if (ra.Wqs) {
-        LgColsumArgs cs{ra.Wqs, tv.ns_ld, (size_t)tv.nq_ld * tv.ns_ld, tv.n_q, tv.nq_ld, tv.n_s, tv.ns_ld, nullptr, 0,
-                        ra.vecs + (size_t)V_CS_QS * tv.vld, (size_t)NVEC * tv.vld};
-        k_lg_colsum<<<dim3(ceil_div(tv.ns_ld, 64), ra.T), 1024, 0, st>>>(cs);
-    }
-    const int rows = tv.ns_ld > tv.nq_ld ? tv.ns_ld : tv.nq_ld;
-    k_lg_rowsums<<<dim3(ceil_div(rows, 4), ra.T), 256, 0, st>>>(ra);
-}
 
 InnerArgs inner_args(const adkf_batch_t* b, const Workspace& w, float* phi, int32_t* info) {
     InnerArgs a{};
@@ -457,17 +446,18 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         launch_gemm(px, T, ns, ns, st);
     }
     if (dZ_s || dZ_q) {
-        RowsumArgs ra{tv, w.Wss, w.Wqs, w.Wqq, w.vecs, T};
-        launch_rowsums(ra, w, st);
-        if (dZ_s) {
-            if (b->n_s) hipMemsetAsync(dZ_s, 0, (size_t)T * ns * d * sizeof(float), st);   // padded rows only exist in ragged batches
-            ProbDZ<false> pz; pz.tv = tv; pz.Wss = w.Wss; pz.Wqs = w.Wqs; pz.Wqq = w.Wqq; pz.Zs = b->Z_s; pz.Zq = b->Z_q; pz.dZ = dZ_s; pz.d = d;
-            launch_gemm(pz, T, ns, d, st);
-        }
-        if (dZ_q) {
-            if (b->n_q) hipMemsetAsync(dZ_q, 0, (size_t)T * nq * d * sizeof(float), st);
-            ProbDZ<true> pz; pz.tv = tv; pz.Wss = w.Wss; pz.Wqs = w.Wqs; pz.Wqq = w.Wqq; pz.Zs = b->Z_s; pz.Zq = b->Z_q; pz.dZ = dZ_q; pz.d = d;
-            launch_gemm(pz, T, nq, d, st);
+        if (dZ_s && b->n_s) hipMemsetAsync(dZ_s, 0, (size_t)T * ns * d * sizeof(float), st);   // padded rows only exist in ragged batches
+        if (dZ_q && b->n_q) hipMemsetAsync(dZ_q, 0, (size_t)T * nq * d * sizeof(float), st);
+        ProbDZ<false> pzs; pzs.tv = tv; pzs.Wss = w.Wss; pzs.Wqs = w.Wqs; pzs.Wqq = w.Wqq; pzs.Zs = b->Z_s; pzs.Zq = b->Z_q; pzs.dZ = dZ_s; pzs.d = d;
+        ProbDZ<true> pzq; pzq.tv = tv; pzq.Wss = w.Wss; pzq.Wqs = w.Wqs; pzq.Wqq = w.Wqq; pzq.Zs = b->Z_s; pzq.Zq = b->Z_q; pzq.dZ = dZ_q; pzq.d = d;
+        if (dZ_s && dZ_q) {   // both cotangents in one launch
+            ProbDZBoth pb; pb.s = pzs; pb.q = pzq; pb.tn = ceil_div(d, GT); pb.end0 = ceil_div(ns, GT) * pb.tn; pb.query = false;
+            const int total = pb.end0 + ceil_div(nq, GT) * pb.tn;
+            k_bgemm<ProbDZBoth, GT><<<grid_for(T, total), 256, 0, st>>>(pb, T, 1, total);
+        } else if (dZ_s) {
+            launch_gemm(pzs, T, ns, d, st);
+        } else {
+            launch_gemm(pzq, T, nq, d, st);
         }
     }
     if (w.w64) {   // flagged (ill-conditioned) tasks: the cotangent algebra and dL/dZ once more, in float64, over what the kernels above wrote
@@ -543,8 +533,6 @@ int ard_setup(const adkf_batch_t* b, void* ws, size_t ws_bytes, hipStream_t st, 
 void ard_dz_support(ArdCtx& c, const float* W, float* out, const int32_t* n_override = nullptr) {
     TaskView tv = make_tv(&c.bt, c.w, false);
     if (n_override) tv.n_s = n_override;
-    RowsumArgs ra{tv, W, nullptr, nullptr, c.w.vecs, c.T};
-    launch_rowsums(ra, c.w, c.st);
     ProbDZ<false> pz; pz.tv = tv; pz.Wss = W; pz.Wqs = nullptr; pz.Wqq = nullptr; pz.Zs = c.a.Zt_s; pz.Zq = nullptr; pz.dZ = out; pz.d = c.d;
     launch_gemm(pz, c.T, c.ns, c.d, c.st);
 }
@@ -840,8 +828,6 @@ int adkf_mll_value_grad(const adkf_batch_t* b, const float* phi, float* f_in, fl
         const int win_tiles = std::max(1, std::min(64, b->ns_max * b->ns_max / 2048));
         WinArgs wa{tv, w.Ainv, w.D2ss, w.Wss, w.scal, b->T, win_tiles};
         k_win<<<grid_for(b->T, win_tiles), 256, 0, st>>>(wa);
-        RowsumArgs ra{tv, w.Wss, nullptr, nullptr, w.vecs, b->T};
-        launch_rowsums(ra, w, st);
         hipMemsetAsync(dZ_s, 0, (size_t)b->T * b->ns_max * b->d * sizeof(float), st);
         ProbDZ<false> pz; pz.tv = tv; pz.Wss = w.Wss; pz.Wqs = nullptr; pz.Wqq = nullptr; pz.Zs = b->Z_s; pz.Zq = nullptr; pz.dZ = dZ_s; pz.d = b->d;
         launch_gemm(pz, b->T, b->ns_max, b->d, st);

@@ -35,7 +35,7 @@ enum Scal : int {
 constexpr int NSCAL = 64;
 
 // per-task vector slots (each nvec_ld floats)
-enum Vec : int { V_ALPHA = 0, V_BETA, V_GAMMA, V_DELTA, V_W, V_R, V_E, V_CTE, V_MU, V_RS_SS, V_CS_QS, V_RS_QS, V_RS_QQ, V_COUNT_ = 16 };
+enum Vec : int { V_ALPHA = 0, V_BETA, V_GAMMA, V_DELTA, V_W, V_R, V_E, V_CTE, V_MU, V_COUNT_ = 16 };
 constexpr int NVEC = 16;
 
 // ---------------------------------------------------------------------------------------------------

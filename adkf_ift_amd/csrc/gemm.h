@@ -72,6 +72,8 @@ template <class P> struct has_epi4<P, std::void_t<decltype(&P::epi4)>> : std::tr
 
 template <class P, class = void> struct has_rowsq : std::false_type {};
 template <class P> struct has_rowsq<P, std::void_t<decltype(&P::set_rowsq)>> : std::true_type {};
+template <class P, class = void> struct has_rowsum : std::false_type {};
+template <class P> struct has_rowsum<P, std::void_t<decltype(&P::set_rowsum)>> : std::true_type {};
 template <class P, class = void> struct has_raw : std::false_type {};
 template <class P> struct has_raw<P, std::void_t<decltype(P::A_NRAW)>> : std::true_type {};
 
@@ -115,7 +117,9 @@ __device__ __forceinline__ void gemm_fetch(const P& p, float (&reg)[GemmCfg<TM>:
     }
 }
 
-template <bool KC, int TM, bool SQ = false>
+// SQ: what rides the staging of a K-contiguous operand - 0 nothing, 1 the row sums of squares (ProbDist's norms), 2 the plain
+// row sums (ProbDZ's coefficient vectors: coef_i = sum_k a(i, k), so no separate pass over the weight matrices)
+template <bool KC, int TM, int SQ = 0>
 __device__ __forceinline__ void gemm_stage(float* S, const float (&reg)[GemmCfg<TM>::GPT], float* sq = nullptr) {
     using C = GemmCfg<TM>;
     const int tid = threadIdx.x;
@@ -125,7 +129,8 @@ __device__ __forceinline__ void gemm_stage(float* S, const float (&reg)[GemmCfg<
         for (int x = 0; x < 4; ++x) {
             if (KC) S[((tid >> 3) + ps * 32) * LD_MN + (tid & 7) * 4 + x] = reg[ps * 4 + x];
             else S[((tid / C::MNQ) + ps * C::KSTEP) * C::LD_K + (tid % C::MNQ) * 4 + x] = reg[ps * 4 + x];
-            if constexpr (SQ) sq[ps] = fmaf(reg[ps * 4 + x], reg[ps * 4 + x], sq[ps]);   // row (tid >> 3) + 32 ps, this thread's k group
+            if constexpr (SQ == 1) sq[ps] = fmaf(reg[ps * 4 + x], reg[ps * 4 + x], sq[ps]);   // row (tid >> 3) + 32 ps, this thread's k group
+            if constexpr (SQ == 2) sq[ps] += reg[ps * 4 + x];
         }
     }
 }
@@ -154,7 +159,7 @@ __device__ __forceinline__ void gemm_fetch_raw(const P& p, float4 (&raw)[GemmCfg
     }
 }
 
-template <class P, bool IS_A, int TM, int NR, bool SQ = false>
+template <class P, bool IS_A, int TM, int NR, int SQ = 0>
 __device__ __forceinline__ void gemm_stage_raw(const P& p, float* S, const float4 (&raw)[GemmCfg<TM>::GPT / 4][NR], int base, int k0, float* sq = nullptr) {
     using C = GemmCfg<TM>;
     constexpr bool KC = IS_A ? P::A_KCONTIG : P::B_KCONTIG;
@@ -169,7 +174,8 @@ __device__ __forceinline__ void gemm_stage_raw(const P& p, float* S, const float
         for (int x = 0; x < 4; ++x) {
             if (KC) S[((tid >> 3) + ps * 32) * LD_MN + (tid & 7) * 4 + x] = v[x];
             else S[((tid / C::MNQ) + ps * C::KSTEP) * C::LD_K + (tid % C::MNQ) * 4 + x] = v[x];
-            if constexpr (SQ) sq[ps] = fmaf(v[x], v[x], sq[ps]);
+            if constexpr (SQ == 1) sq[ps] = fmaf(v[x], v[x], sq[ps]);
+            if constexpr (SQ == 2) sq[ps] += v[x];
         }
     }
 }
@@ -248,7 +254,9 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
         }
     };
     constexpr bool SQ = has_rowsq<P>::value;
+    constexpr int SQA = has_rowsq<P>::value ? 1 : has_rowsum<P>::value ? 2 : 0, SQB = has_rowsq<P>::value ? 1 : 0;
     static_assert(!SQ || (P::A_KCONTIG && P::B_KCONTIG), "row sums of squares ride the K-contiguous staging map");
+    static_assert(SQA != 2 || P::A_KCONTIG, "row sums ride the K-contiguous staging map");
     float sqa[GPT / 4], sqb[GPT / 4];
 #pragma unroll
     for (int ps = 0; ps < GPT / 4; ++ps) { sqa[ps] = 0.f; sqb[ps] = 0.f; }
@@ -261,8 +269,8 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
             gemm_fetch_raw<P, true, TM, P::A_NRAW>(p, qa, m0, 0);
             gemm_fetch_raw<P, false, TM, P::B_NRAW>(p, qb, n0, 0);
             for (int k0 = 0; k0 < K; k0 += GK) {
-                gemm_stage_raw<P, true, TM, P::A_NRAW, SQ>(p, As, qa, m0, k0, sqa);
-                gemm_stage_raw<P, false, TM, P::B_NRAW, SQ>(p, Bs, qb, n0, k0, sqb);
+                gemm_stage_raw<P, true, TM, P::A_NRAW, SQA>(p, As, qa, m0, k0, sqa);
+                gemm_stage_raw<P, false, TM, P::B_NRAW, SQB>(p, Bs, qb, n0, k0, sqb);
                 ADKF_GEMM_SYNC();
                 if (k0 + GK < K && !(ADKF_GEMM_ABLATE & 4)) {
                     gemm_fetch_raw<P, true, TM, P::A_NRAW>(p, qa, m0, k0 + GK);
@@ -280,8 +288,8 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
         gemm_fetch<P, true, TM>(p, ra, m0, 0, M, K);
         gemm_fetch<P, false, TM>(p, rb, n0, 0, N, K);
         for (int k0 = 0; k0 < K; k0 += GK) {
-            gemm_stage<P::A_KCONTIG, TM, SQ>(As, ra, sqa);
-            gemm_stage<P::B_KCONTIG, TM, SQ>(Bs, rb, sqb);
+            gemm_stage<P::A_KCONTIG, TM, SQA>(As, ra, sqa);
+            gemm_stage<P::B_KCONTIG, TM, SQB>(Bs, rb, sqb);
             __syncthreads();
             if (k0 + GK < K) {  // next chunk's loads fly while this chunk is multiplied
                 gemm_fetch<P, true, TM>(p, ra, m0, k0 + GK, M, K);
@@ -304,6 +312,18 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
         }
         __syncthreads();
         p.set_rowsq(&rowsq[0][0], &rowsq[1][0], m0, n0);
+    }
+
+    if constexpr (SQA == 2) {   // the plain row sums of A, same lane arithmetic
+        __shared__ float rowsum[TM];
+#pragma unroll
+        for (int ps = 0; ps < GPT / 4; ++ps) {
+            float a = sqa[ps];
+            a += dpp_f<DPP_XOR1>(a); a += dpp_f<DPP_XOR2>(a); a += dpp_f<DPP_HALF_MIRROR>(a);
+            if ((tid & 7) == 0) rowsum[(tid >> 3) + ps * 32] = a;
+        }
+        __syncthreads();
+        p.set_rowsum(&rowsum[0], m0);
     }
 
     // ---- epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg ----

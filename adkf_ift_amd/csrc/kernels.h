@@ -660,90 +660,6 @@ __global__ __launch_bounds__(SMALL_NT) void k_wqq(WqqArgs a) {
     }
 }
 
-// ---- row/column sums of the weight matrices -> the diagonal coefficients of the dZ GEMMs -----------------
-// coef_s[i] = 2 (2 rowsum(W_ss)[i] + colsum(W_qs)[i]);  coef_q[i] = 2 (rowsum(W_qs)[i] + 2 rowsum(W_qq)[i])
-struct RowsumArgs { TaskView tv; const float* Wss; const float* Wqs; const float* Wqq; float* vecs; int T; };
-
-__global__ __launch_bounds__(SMALL_NT) void k_rowsums(RowsumArgs a) {
-    constexpr int NT = SMALL_NT, NW = NT / 64;
-    int t, tile;
-    if (!task_tile(a.T, 1, t, tile)) return;
-    const int n = a.tv.ns(t), m = a.Wqs ? a.tv.nq(t) : 0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const float* Wss = a.Wss + (size_t)t * a.tv.ns_ld * a.tv.ns_ld;
-    const float* Wqs = a.Wqs ? a.Wqs + (size_t)t * a.tv.nq_ld * a.tv.ns_ld : nullptr;
-    const float* Wqq = a.Wqq ? a.Wqq + (size_t)t * a.tv.nq_ld * a.tv.nq_ld : nullptr;
-    float* vb = a.vecs + (size_t)t * NVEC * a.tv.vld;
-    // column sums of W_qs: every wave sums its share of the rows for all columns (coalesced), partials meet in LDS
-    constexpr int CMAX = 128;  // larger sets take k_lg_colsum / k_lg_rowsums (large.h)
-    __shared__ float cpart[NW][CMAX];
-    // (every pass keeps RF rows per wave in flight: a row at a time is a chain of L2 round trips, 27 us at 128 points)
-    constexpr int RF = 8;
-    if (m > 0) {
-        for (int j = lane; j < n; j += 64) {
-            float s = 0.f;
-            for (int i0 = wv; i0 < m; i0 += RF * NW) {
-                float v[RF];
-#pragma unroll
-                for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; v[q] = Wqs[(size_t)(i < m ? i : m - 1) * a.tv.ns_ld + j]; if (i >= m) v[q] = 0.f; }
-#pragma unroll
-                for (int q = 0; q < RF; ++q) s += v[q];
-            }
-            cpart[wv][j] = s;
-        }
-    }
-    __syncthreads();
-    for (int i0 = wv; i0 < n; i0 += RF * NW) {
-        float s[RF];
-#pragma unroll
-        for (int q = 0; q < RF; ++q) s[q] = 0.f;
-        for (int j = lane; j < n; j += 64) {
-            float v[RF];
-#pragma unroll
-            for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; v[q] = Wss[(size_t)(i < n ? i : n - 1) * a.tv.ns_ld + j]; }   // clamped, discarded below
-#pragma unroll
-            for (int q = 0; q < RF; ++q) s[q] += (i0 + q * NW < n) ? v[q] : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < RF; ++q) {
-            const int i = i0 + q * NW;
-            const float t_ = wave_sum(s[q]);
-            if (lane == 0 && i < n) {
-                float cs = 0.f;
-                if (m > 0)
-                    for (int w = 0; w < NW; ++w) cs += cpart[w][i];
-                vb[V_RS_SS * a.tv.vld + i] = 4.f * t_ + 2.f * cs;
-            }
-        }
-    }
-    if (m > 0) {
-        for (int i0 = wv; i0 < m; i0 += RF * NW) {
-            float s1[RF], s2[RF];
-#pragma unroll
-            for (int q = 0; q < RF; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
-            for (int j = lane; j < n; j += 64) {
-                float v[RF];
-#pragma unroll
-                for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; v[q] = Wqs[(size_t)(i < m ? i : m - 1) * a.tv.ns_ld + j]; }
-#pragma unroll
-                for (int q = 0; q < RF; ++q) s1[q] += (i0 + q * NW < m) ? v[q] : 0.f;
-            }
-            for (int j = lane; j < m; j += 64) {
-                float v[RF];
-#pragma unroll
-                for (int q = 0; q < RF; ++q) { const int i = i0 + q * NW; v[q] = Wqq[(size_t)(i < m ? i : m - 1) * a.tv.nq_ld + j]; }
-#pragma unroll
-                for (int q = 0; q < RF; ++q) s2[q] += (i0 + q * NW < m) ? v[q] : 0.f;
-            }
-#pragma unroll
-            for (int q = 0; q < RF; ++q) {
-                const int i = i0 + q * NW;
-                const float t1 = wave_sum(s1[q]), t2 = wave_sum(s2[q]);
-                if (lane == 0 && i < m) vb[V_RS_QS * a.tv.vld + i] = 2.f * t1 + 4.f * t2;
-            }
-        }
-    }
-}
-
 // ---- predictive variance diag: var_i = s - sum_j C_ij Kqs_ij + noise;  mean_i = sum_j C_ij y_j ------------
 struct PredArgs { TaskView tv; const float* C; const float* D2qs; const float* y_s; float* mean; float* var; const float* scal; int T; };
 

@@ -567,29 +567,6 @@ __global__ __launch_bounds__(64) void k_lg_wqq_fin(LgWqq a) {
     }
 }
 
-// k_rowsums per row (wave per row; grid: ceil(max(ns_ld, nq_ld) / 4) x T); V_CS_QS must already hold colsum(W_qs)
-__global__ __launch_bounds__(256) void k_lg_rowsums(RowsumArgs a) {
-    const int t = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int n = a.tv.ns(t), m = a.Wqs ? a.tv.nq(t) : 0;
-    float* vb = a.vecs + (size_t)t * NVEC * a.tv.vld;
-    if (i < n) {
-        const float* row = a.Wss + ((size_t)t * a.tv.ns_ld + i) * a.tv.ns_ld;
-        float s = 0.f;
-        for (int j = lane; j < n; j += 64) s += row[j];
-        s = wave_sum(s);
-        if (lane == 0) vb[V_RS_SS * a.tv.vld + i] = 4.f * s + (m > 0 ? 2.f * vb[V_CS_QS * a.tv.vld + i] : 0.f);
-    }
-    if (i < m) {
-        const float* r1 = a.Wqs + ((size_t)t * a.tv.nq_ld + i) * a.tv.ns_ld;
-        const float* r2 = a.Wqq + ((size_t)t * a.tv.nq_ld + i) * a.tv.nq_ld;
-        float s1 = 0.f, s2 = 0.f;
-        for (int j = lane; j < n; j += 64) s1 += r1[j];
-        for (int j = lane; j < m; j += 64) s2 += r2[j];
-        s1 = wave_sum(s1); s2 = wave_sum(s2);
-        if (lane == 0) vb[V_RS_QS * a.tv.vld + i] = 2.f * s1 + 4.f * s2;
-    }
-}
-
 // ---- median heuristic for many points: 4 passes of an 8-bit radix select over the float bit patterns ------------------
 // k_lg_med_hist: histogram of the current digit over the candidates that match the prefix found so far
 //                (grid: rows are dealt to gridDim.x workgroups; LDS histogram, then integer atomics: deterministic)

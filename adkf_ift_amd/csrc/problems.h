@@ -341,7 +341,7 @@ struct ProbDZ {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = false;
     static constexpr int NRED = 0;
     TaskView tv; const float* Wss; const float* Wqs; const float* Wqq; const float* Zs; const float* Zq; float* dZ; int d;
-    int n, m; const float *Wssi, *Wqsi, *Wqqi, *Zsi, *Zqi, *coef; float* dZo; bool vec;
+    int n, m, rs_base; const float *Wssi, *Wqsi, *Wqqi, *Zsi, *Zqi, *rs; float* dZo; bool vec;
     __device__ bool setup(int t) {
         n = tv.ns(t); m = Wqs ? tv.nq(t) : 0; vec = tv.vec;
         Wssi = Wss ? Wss + (size_t)t * tv.ns_ld * tv.ns_ld : nullptr;
@@ -349,7 +349,7 @@ struct ProbDZ {
         Wqqi = Wqq ? Wqq + (size_t)t * tv.nq_ld * tv.nq_ld : nullptr;
         Zsi = Zs + (size_t)t * tv.ns_ld * d; Zqi = Zq ? Zq + (size_t)t * tv.nq_ld * d : nullptr;
         dZo = dZ + (size_t)t * (QUERY ? tv.nq_ld : tv.ns_ld) * d;
-        coef = tv.vec_ptr(t, QUERY ? V_RS_QS : V_RS_SS);  // coefficient vectors prepared by k_rowsums
+        rs = nullptr; rs_base = 0;
         return QUERY ? (m > 0) : (n > 0);
     }
     __device__ int M() const { return QUERY ? m : n; } __device__ int N() const { return d; } __device__ int K() const { return n + m; }
@@ -393,10 +393,41 @@ struct ProbDZ {
     }
     __device__ void b_raw(int k, int j, float4 (&r)[1]) const { r[0] = ldq((k < n ? Zsi + (size_t)k * d : Zqi + (size_t)(k - n) * d) + j); }
     __device__ void b_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
+    // coef_i = sum_k a(i, k): summed by the GEMM kernel itself while it stages this tile's A operand (gemm.h: set_rowsum) - the
+    // separate row / column sum kernels over W_ss, W_qs, W_qq and their coefficient vectors are gone
+    __device__ void set_rowsum(const float* a, int m0) { rs = a; rs_base = m0; }
     __device__ void epi(int i, int j, float acc, float*) const {
         const float z = QUERY ? Zqi[(size_t)i * d + j] : Zsi[(size_t)i * d + j];
-        dZo[(size_t)i * d + j] = coef[i] * z - acc;
+        dZo[(size_t)i * d + j] = rs[i - rs_base] * z - acc;
     }
+    __device__ void store_red(int, const float*) const {}
+};
+
+// Both cotangents in ONE launch (gemm.h's select() hook, as ProbDistMulti): tiles [0, end0) are the support rows, the rest the
+// query rows.  Two launches of 2 x 4 tiles per task each left a tail of half-empty rounds and a launch boundary in between.
+struct ProbDZBoth {
+    static constexpr bool A_KCONTIG = true, B_KCONTIG = false;
+    static constexpr int NRED = 0;
+    ProbDZ<false> s; ProbDZ<true> q; int end0, tn; bool query, vec;
+    __device__ void select(int& tile, int& tiles_n) {
+        tiles_n = tn;
+        query = tile >= end0;
+        if (query) tile -= end0;
+    }
+    __device__ bool setup(int t) { const bool ok = query ? q.setup(t) : s.setup(t); vec = query ? q.vec : s.vec; return ok; }
+    __device__ int M() const { return query ? q.M() : s.M(); } __device__ int N() const { return s.d; } __device__ int K() const { return query ? q.K() : s.K(); }
+    __device__ float a(int i, int k) const { return query ? q.a(i, k) : s.a(i, k); }
+    __device__ float b(int k, int j) const { return query ? q.b(k, j) : s.b(k, j); }
+    __device__ void a4(int i, int k, float (&v)[4]) const { if (query) q.a4(i, k, v); else s.a4(i, k, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const { if (query) q.b4(k, j, v); else s.b4(k, j, v); }
+    static constexpr int A_NRAW = 1, B_NRAW = 1;
+    __device__ bool raw_ok() const { return query ? q.raw_ok() : s.raw_ok(); }
+    __device__ void a_raw(int i, int k, float4 (&r)[1]) const { if (query) q.a_raw(i, k, r); else s.a_raw(i, k, r); }
+    __device__ void a_fin(int i, int k, const float4 (&r)[1], float (&v)[4]) const { if (query) q.a_fin(i, k, r, v); else s.a_fin(i, k, r, v); }
+    __device__ void b_raw(int k, int j, float4 (&r)[1]) const { if (query) q.b_raw(k, j, r); else s.b_raw(k, j, r); }
+    __device__ void b_fin(int k, int j, const float4 (&r)[1], float (&v)[4]) const { if (query) q.b_fin(k, j, r, v); else s.b_fin(k, j, r, v); }
+    __device__ void set_rowsum(const float* a, int m0) { if (query) q.set_rowsum(a, m0); else s.set_rowsum(a, m0); }
+    __device__ void epi(int i, int j, float acc, float* red) const { if (query) q.epi(i, j, acc, red); else s.epi(i, j, acc, red); }
     __device__ void store_red(int, const float*) const {}
 };
 

@@ -233,11 +233,16 @@ def mll_value_grad(b: GPBatch, phi: torch.Tensor, want_grad_phi=True, want_dZ=Fa
 
 
 def fit(b: GPBatch, phi0: torch.Tensor, max_evals: int = 200, gtol: float = 1e-5, ftol: float = FTOL_DEFAULT,
-        exact_evals: bool = False, events: Optional[Tuple[torch.cuda.Event, torch.cuda.Event]] = None):
+        exact_evals: bool = False, events: Optional[Tuple[torch.cuda.Event, torch.cuda.Event]] = None,
+        inplace: bool = False):
     """Batched inner optimisation; returns (phi*, f_final, gnorm, n_evals, info).  ``events`` = a pair of
-    already-created timing events recorded right around the optimiser kernel (bench.py's roofline clock)."""
+    already-created timing events recorded right around the optimiser kernel (bench.py's roofline clock).
+    ``inplace``: the library optimises ``phi0`` where it lies (the meta-step's freshly initialised parameters have no
+    other reader: one copy kernel less per step); otherwise ``phi0`` is left untouched."""
     lib = _lib.load()
-    phi = b.check_phi(phi0, "phi0").clone()
+    phi = b.check_phi(phi0, "phi0")
+    if not inplace:
+        phi = phi.clone()
     f, gn = _new(b, b.T), _new(b, b.T)
     ne, info = _new(b, b.T, dtype=torch.int32), _new(b, b.T, dtype=torch.int32)
     opt = FitOptions(int(max_evals), int(exact_evals), float(gtol), float(ftol),

@@ -67,14 +67,16 @@ def make_tasks(T: int, N: int, d: int, N_q: Optional[int] = None, regression: bo
 
 
 class _ChunkedLinear(torch.autograd.Function):
-    """Z = X (W c).  Backward dW = c X^T dZ has a 256 x 256 output and a reduction over all T*(N+Nq) rows: as one
-    GEMM it leaves most CUs idle (measured 265 us on MI355X at C2), as a 32-way chunked bmm + sum it takes 140 us."""
+    """Z = X W for rows X that already carry the 1 / sqrt(d) of the feature map (the inputs are constants: scaling them once
+    replaces an element-wise pass over W before the forward product and one over dW behind the backward one, two launches
+    per meta-step).  Backward dW = X^T dZ has a 256 x 256 output and a reduction over all T*(N+Nq) rows: as one GEMM it
+    leaves most CUs idle (measured 265 us on MI355X at C2), as a 32-way chunked bmm + sum it takes 140 us."""
 
     @staticmethod
-    def forward(ctx, X2, W, c, chunks):
+    def forward(ctx, X2, W, chunks):
         ctx.save_for_backward(X2)
-        ctx.c, ctx.chunks = c, chunks
-        return X2 @ (W * c)
+        ctx.chunks = chunks
+        return X2 @ W
 
     @staticmethod
     def backward(ctx, g):
@@ -82,14 +84,14 @@ class _ChunkedLinear(torch.autograd.Function):
         ch = ctx.chunks
         R, d = X2.shape
         g = g.reshape(R, -1)
-        if R % ch:
-            return None, (X2.t() @ g) * ctx.c, None, None
+        if R % ch or ch == 1:
+            return None, X2.t() @ g, None
         part = torch.bmm(X2.view(ch, R // ch, d).transpose(1, 2), g.view(ch, R // ch, -1))
-        return None, part.sum(0) * ctx.c, None, None
+        return None, part.sum(0), None
 
 
 class LinearFeatureMap:
-    """The synthetic stand-in for the GNN + fc head: Z = X W / sqrt(d) for support and query rows in ONE matmul.
+    """The synthetic stand-in for the GNN + fc head: Z = (X / sqrt(d)) W for support and query rows in ONE matmul.
     ``__call__()`` returns the stacked features ``[2, T, N, d]`` (support, query) when N == Nq, else a pair."""
 
     def __init__(self, X_s: torch.Tensor, X_q: torch.Tensor, W: torch.Tensor, chunks: int = 32):
@@ -97,12 +99,12 @@ class LinearFeatureMap:
         self.c = 1.0 / math.sqrt(W.shape[0])
         self.same = X_s.shape == X_q.shape
         if self.same:
-            self.X = torch.stack([X_s, X_q]).contiguous()
+            self.X = (torch.stack([X_s, X_q]) * self.c).contiguous()
         else:
             self.X_s, self.X_q = X_s, X_q
 
     def __call__(self):
         if self.same:
             sh = self.X.shape
-            return _ChunkedLinear.apply(self.X.view(-1, sh[-1]), self.W, self.c, self.chunks).view(sh[0], sh[1], sh[2], -1)
+            return _ChunkedLinear.apply(self.X.view(-1, sh[-1]), self.W, self.chunks).view(sh[0], sh[1], sh[2], -1)
         return (self.X_s @ self.W) * self.c, (self.X_q @ self.W) * self.c

@@ -51,7 +51,7 @@ class HipGPBackend:
         phi0, _ = gp_ops.init_params_batch(b, cfg.use_numeric_labels, cfg.use_lengthscale_prior)
         b.flags = gp_ops.REUSE_DIST
         phi, f_in, gnorm, nev, info_fit = gp_ops.fit(b, phi0, cfg.inner_max_evals, cfg.inner_gtol, cfg.inner_ftol,
-                                                     cfg.inner_exact_evals, events=fit_events)
+                                                     cfg.inner_exact_evals, events=fit_events, inplace=True)
         b.flags = gp_ops.REUSE_DIST | gp_ops.REUSE_INNER
         out = gp_ops.ift_hypergrad(b, phi, ignore_grad_correction=cfg.ignore_grad_correction, out_dZ=out_dZ)
         return phi, out["f_out"], out["dZ_s"], out["dZ_q"], info_fit, out["info"]
