@@ -403,32 +403,4 @@ struct ProbDZ {
     __device__ void store_red(int, const float*) const {}
 };
 
-// Both cotangents in ONE launch (gemm.h's select() hook, as ProbDistMulti): tiles [0, end0) are the support rows, the rest the
-// query rows.  Two launches of 2 x 4 tiles per task each left a tail of half-empty rounds and a launch boundary in between.
-struct ProbDZBoth {
-    static constexpr bool A_KCONTIG = true, B_KCONTIG = false;
-    static constexpr int NRED = 0;
-    ProbDZ<false> s; ProbDZ<true> q; int end0, tn; bool query, vec;
-    __device__ void select(int& tile, int& tiles_n) {
-        tiles_n = tn;
-        query = tile >= end0;
-        if (query) tile -= end0;
-    }
-    __device__ bool setup(int t) { const bool ok = query ? q.setup(t) : s.setup(t); vec = query ? q.vec : s.vec; return ok; }
-    __device__ int M() const { return query ? q.M() : s.M(); } __device__ int N() const { return s.d; } __device__ int K() const { return query ? q.K() : s.K(); }
-    __device__ float a(int i, int k) const { return query ? q.a(i, k) : s.a(i, k); }
-    __device__ float b(int k, int j) const { return query ? q.b(k, j) : s.b(k, j); }
-    __device__ void a4(int i, int k, float (&v)[4]) const { if (query) q.a4(i, k, v); else s.a4(i, k, v); }
-    __device__ void b4(int k, int j, float (&v)[4]) const { if (query) q.b4(k, j, v); else s.b4(k, j, v); }
-    static constexpr int A_NRAW = 1, B_NRAW = 1;
-    __device__ bool raw_ok() const { return query ? q.raw_ok() : s.raw_ok(); }
-    __device__ void a_raw(int i, int k, float4 (&r)[1]) const { if (query) q.a_raw(i, k, r); else s.a_raw(i, k, r); }
-    __device__ void a_fin(int i, int k, const float4 (&r)[1], float (&v)[4]) const { if (query) q.a_fin(i, k, r, v); else s.a_fin(i, k, r, v); }
-    __device__ void b_raw(int k, int j, float4 (&r)[1]) const { if (query) q.b_raw(k, j, r); else s.b_raw(k, j, r); }
-    __device__ void b_fin(int k, int j, const float4 (&r)[1], float (&v)[4]) const { if (query) q.b_fin(k, j, r, v); else s.b_fin(k, j, r, v); }
-    __device__ void set_rowsum(const float* a, int m0) { if (query) q.set_rowsum(a, m0); else s.set_rowsum(a, m0); }
-    __device__ void epi(int i, int j, float acc, float* red) const { if (query) q.epi(i, j, acc, red); else s.epi(i, j, acc, red); }
-    __device__ void store_red(int, const float*) const {}
-};
-
 }  // namespace adkf
