@@ -324,3 +324,26 @@ def test_two_tasks_per_cu_fit_equals_the_resident_one(dev, kernel):
     assert (f_all - f_c).abs().max().item() <= 1e-6 * f_c.abs().max().item(), (f_all - f_c).abs().max().item()
     assert (phi_all - phi_c).abs().max().item() <= 1e-5, (phi_all - phi_c).abs().max().item()
     print("two-tasks-per-CU fit vs resident: max |d f| %.2e, max |d phi| %.2e" % ((f_all - f_c).abs().max().item(), (phi_all - phi_c).abs().max().item()))
+
+
+def test_fit_in_place_is_the_same_fit(dev):
+    """``gp_ops.fit(..., inplace=True)`` (what the meta-step uses for its freshly initialised parameters: one copy kernel
+    less per step) runs the same optimisation as the copying default and leaves the result in ``phi0`` itself."""
+    from adkf_ift_amd import gp_ops
+    from adkf_ift_amd.synthetic import make_tasks
+
+    T, N, d = 8, 48, 24
+    tasks = make_tasks(T, N, d, first_task=90)
+    Zs, _ = tasks.features()
+    pri = torch.empty(T, 4, device=dev)
+    b = gp_ops.GPBatch(Zs.to(dev), tasks.y_s.to(dev), pri, "rbf")
+    phi0, _ = gp_ops.init_params_batch(b)
+    b.flags = gp_ops.REUSE_DIST
+    keep = phi0.clone()
+    phi_a, f_a, _, ne_a, info = gp_ops.fit(b, phi0, max_evals=40)
+    gp_ops.check_info(info)
+    assert torch.equal(phi0, keep) and phi_a.data_ptr() != phi0.data_ptr()
+    phi_b, f_b, _, ne_b, info = gp_ops.fit(b, phi0, max_evals=40, inplace=True)
+    gp_ops.check_info(info)
+    assert phi_b.data_ptr() == phi0.data_ptr()
+    assert torch.equal(phi_a, phi_b) and torch.equal(f_a, f_b) and torch.equal(ne_a, ne_b)
