@@ -250,7 +250,7 @@ template <> struct Sweep<128, 512> {
 #if ADKF_M_SLEEP && ADKF_M_SLEEP_MODE == 0
         else __builtin_amdgcn_s_sleep(ADKF_M_SLEEP);
 #elif ADKF_M_SLEEP && ADKF_M_SLEEP_MODE == 1
-        else if (w == ((WN + 4) & 7)) __builtin_amdgcn_s_sleep(ADKF_M_SLEEP);   // (experiment: the other waves have the inversion's ~190 cycles of slack - let the chain wave's LDS reads go first)
+        else if (w == ((WN + 4) & 7)) __builtin_amdgcn_s_sleep(ADKF_M_SLEEP);
 #endif
         // the operands of the hand-off chain first: D^-1, the wave's own columns, the critical tile's B; then the other seven
         const float* ctr = &sm.ct[SLOT][0][0];
@@ -282,7 +282,6 @@ template <> struct Sweep<128, 512> {
         ADKF_MTS(1);
         mfma<WN>(acc, cur.a, cur.b[WN]);     // this step's update of the tile the next hand-off comes out of
         __builtin_amdgcn_sched_barrier(0);
-
         bulk<WN, ADKF_M_EARLY, ADKF_M_EARLY + ADKF_M_MID>(acc, prev);
         __builtin_amdgcn_sched_barrier(0);
         if (has_next) {
