@@ -58,8 +58,14 @@ SIGNATURES = {
     "adkf_workspace_bytes_ard": (C.c_size_t, [C.c_int32] * 4),
     "adkf_msg_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int64, C.c_void_p, C.c_void_p]),
+    "adkf_msg_backward_scratch_bytes": (C.c_size_t, [C.c_int32] * 4),
     "adkf_msg_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-                                    C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                    C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    C.c_void_p]),
+    "adkf_msg_dx_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_void_p, C.c_void_p]),
+    "adkf_readout_pool": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p] * 7),
+    "adkf_readout_pool_backward": (C.c_int, [C.c_void_p] * 10 + [C.c_int32] * 5 + [C.c_void_p] * 6),
     "adkf_pna_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "adkf_pna_aggregate_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

@@ -7,6 +7,7 @@
 #include "../../include/adkf_gp.h"
 #include "ard.h"
 #include "pna.h"
+#include "readout.h"
 #include "outer_step.h"
 #include "refine64.h"
 
@@ -953,21 +954,84 @@ int adkf_msg_forward(const float* x, const int64_t* src, const int64_t* tgt, con
     return 0;
 }
 
+size_t adkf_msg_backward_scratch_bytes(int32_t E, int32_t H, int32_t in, int32_t out) {
+    if (E <= 0 || H <= 0 || in <= 0 || out <= 0) return 0;
+    return sizeof(float) * (size_t)msg_nsplit(E) * msg_part_stride(H, in, out);
+}
+
 int adkf_msg_backward(const float* x, const int64_t* src, const int64_t* tgt, const float* W, const float* msgs, const float* d_msgs,
-                      int32_t E, int32_t H, int32_t in, int32_t out, int64_t e_off, float* dx, float* dW, float* db, void* stream) {
+                      int32_t E, int32_t H, int32_t in, int32_t out, int64_t e_off, float* dcat, float* dW, float* db, void* scratch,
+                      size_t scratch_bytes, void* stream) {
     (void)hipGetLastError();
-    if (!x || !W || !msgs || !d_msgs || !dx || !dW || !db || E < 0 || H <= 0 || in <= 0 || out <= 0 || (E > 0 && (!src || !tgt))) return ADKF_E_BADARG;
-    if (E == 0) return 0;
+    if (!x || !W || !msgs || !d_msgs || !dcat || !dW || !db || E < 0 || H <= 0 || in <= 0 || out <= 0 || (E > 0 && (!src || !tgt))) return ADKF_E_BADARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (E == 0) {   // an edge type without edges: its parameters get exact zeros
+        if (hipMemsetAsync(dW, 0, sizeof(float) * (size_t)H * 2 * in * out, st) != hipSuccess) return ADKF_E_LAUNCH;
+        if (hipMemsetAsync(db, 0, sizeof(float) * (size_t)H * out, st) != hipSuccess) return ADKF_E_LAUNCH;
+        return 0;
+    }
+    if (!scratch || scratch_bytes < adkf_msg_backward_scratch_bytes(E, H, in, out)) return ADKF_E_WORKSPACE;
     MsgArgs m{};
-    m.x = x; m.src = src; m.tgt = tgt; m.W = W; m.msgs = const_cast<float*>(msgs); m.d_msgs = d_msgs; m.dx = dx; m.dW = dW;
-    m.E = E; m.H = H; m.in = in; m.out = out; m.e_off = e_off; m.chunk = 512;
+    m.x = x; m.src = src; m.tgt = tgt; m.W = W; m.msgs = const_cast<float*>(msgs); m.d_msgs = d_msgs; m.dcat = dcat;
+    m.part = static_cast<float*>(scratch);
+    m.E = E; m.H = H; m.in = in; m.out = out; m.e_off = e_off; m.chunk = msg_chunk(E);
     m.vec = (in % 4 == 0) && (out % 4 == 0) && aligned16(x) && aligned16(W) && aligned16(msgs) && aligned16(d_msgs);
+    const int nsplit = msg_nsplit(E);
     ProbMsgBwdX px; px.m = m;
     launch_gemm(px, H, E, 2 * in, st);
-    ProbMsgBwdW pw; pw.m = m; pw.nsplit = ceil_div(E, m.chunk);
-    launch_gemm(pw, H * pw.nsplit, 2 * in, out, st);
-    k_msg_dbias<<<dim3(ceil_div(H * out, 64), ceil_div(E, DB_ROWS)), 256, 0, st>>>(m, db);
+    ProbMsgBwdW pw; pw.m = m; pw.nsplit = nsplit;
+    launch_gemm(pw, H * nsplit, 2 * in, out, st);
+    k_msg_dbias<<<dim3(ceil_div(H * out, 64), nsplit), 256, 0, st>>>(m);
+    const int n_w = H * 2 * in * out, n_b = H * out;
+    k_msg_reduce<<<ceil_div(n_w + n_b, 256), 256, 0, st>>>(m.part, nsplit, msg_part_stride(H, in, out), n_w, n_b, dW, db);
+    LAUNCH_OK();
+    return 0;
+}
+
+int adkf_msg_dx_gather(const float* dcat, const int64_t* perm_src, const int64_t* rowptr_src, const int64_t* perm_tgt,
+                       const int64_t* rowptr_tgt, int32_t V, int32_t H, int32_t in, float* dx, void* stream) {
+    (void)hipGetLastError();
+    if (!dcat || !perm_src || !rowptr_src || !perm_tgt || !rowptr_tgt || !dx || V <= 0 || H <= 0 || in <= 0) return ADKF_E_BADARG;
+    MsgDxArgs a{dcat, perm_src, rowptr_src, perm_tgt, rowptr_tgt, dx, V, H, in};
+    const long n = (long)V * H * in;
+    k_msg_dx<<<(unsigned)((n + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(a);
+    LAUNCH_OK();
+    return 0;
+}
+
+int adkf_readout_pool(const float* s_mean, const float* v_mean, const float* s_sum, const float* v_sum, const float* emb,
+                      const int64_t* perm, const int64_t* rowptr, int32_t V, int32_t G, int32_t nh, int32_t hd, int32_t D,
+                      float* w_mean, float* w_sum, float* g_mean, float* g_sum, float* g_max, int32_t* argmax, void* stream) {
+    (void)hipGetLastError();
+    if (!s_mean || !v_mean || !s_sum || !v_sum || !emb || !perm || !rowptr || !w_mean || !w_sum || !g_mean || !g_sum || !g_max || !argmax)
+        return ADKF_E_BADARG;
+    if (V < 0 || G <= 0 || nh <= 0 || nh > READOUT_MAX_HEADS || hd <= 0 || D <= 0) return ADKF_E_BADARG;
+    ReadoutArgs a{};
+    a.s_mean = s_mean; a.v_mean = v_mean; a.s_sum = s_sum; a.v_sum = v_sum; a.emb = emb; a.perm = perm; a.rowptr = rowptr;
+    a.w_mean = w_mean; a.w_sum = w_sum; a.g_mean = g_mean; a.g_sum = g_sum; a.g_max = g_max; a.argmax = argmax;
+    a.V = V; a.G = G; a.nh = nh; a.hd = hd; a.D = D;
+    k_readout_fwd<<<G, 256, 0, static_cast<hipStream_t>(stream)>>>(a);
+    LAUNCH_OK();
+    return 0;
+}
+
+int adkf_readout_pool_backward(const float* v_mean, const float* v_sum, const float* w_mean, const float* w_sum, const float* g_mean,
+                               const int32_t* argmax, const int64_t* node_to_graph, const float* dg_mean, const float* dg_sum,
+                               const float* dg_max, int32_t V, int32_t G, int32_t nh, int32_t hd, int32_t D, float* d_s_mean,
+                               float* d_v_mean, float* d_s_sum, float* d_v_sum, float* d_emb, void* stream) {
+    (void)hipGetLastError();
+    if (!v_mean || !v_sum || !w_mean || !w_sum || !g_mean || !argmax || !node_to_graph || !dg_mean || !dg_sum || !dg_max || !d_s_mean ||
+        !d_v_mean || !d_s_sum || !d_v_sum || !d_emb)
+        return ADKF_E_BADARG;
+    if (V < 0 || G <= 0 || nh <= 0 || hd <= 0 || D <= 0) return ADKF_E_BADARG;
+    if (V == 0) return 0;
+    ReadoutArgs a{};
+    a.v_mean = v_mean; a.v_sum = v_sum; a.w_mean = const_cast<float*>(w_mean); a.w_sum = const_cast<float*>(w_sum);
+    a.g_mean = const_cast<float*>(g_mean); a.argmax = const_cast<int32_t*>(argmax); a.n2g = node_to_graph;
+    a.dg_mean = dg_mean; a.dg_sum = dg_sum; a.dg_max = dg_max;
+    a.d_s_mean = d_s_mean; a.d_v_mean = d_v_mean; a.d_s_sum = d_s_sum; a.d_v_sum = d_v_sum; a.d_emb = d_emb;
+    a.V = V; a.G = G; a.nh = nh; a.hd = hd; a.D = D;
+    k_readout_bwd<<<V, 256, 0, static_cast<hipStream_t>(stream)>>>(a);
     LAUNCH_OK();
     return 0;
 }

@@ -104,10 +104,15 @@ __global__ __launch_bounds__(256) void k_pna_bwd(PnaArgs a) {
 // Message functions of one edge type for all towers (fs_mol/modules/gnn.py:95-148, depth-1 message MLP):
 //     msgs[e, h, :] = relu( cat(x[src_e, h, :], x[tgt_e, h, :]) W[h] + b[h] )
 // as ONE batched MFMA GEMM whose A operand is gathered on the fly (no [E, H, 2 in] concatenation, no separate bias /
-// ReLU passes), and the two backward products with the ReLU mask fused into their operand loads:
-//     d x[src_e / tgt_e, h, :] += (d msgs . [msgs > 0]) W[h]^T          (atomic scatter-add in the epilogue)
-//     d W[h] += cat(x)^T (d msgs . [msgs > 0])                          (split over chunks of edges, atomic accumulate)
-// "task" of k_bgemm = tower (forward, d x) or (tower, edge chunk) (d W).
+// ReLU passes), and the two backward products with the ReLU mask fused into their operand loads.  The backward is
+// REPRODUCIBLE to the bit (no floating-point atomics; round 4 - the reference's own scatter_add is not, which is why two
+// runs of a float32 inner fit on "identical" features used to differ by 1e-4):
+//     d cat[e, h, :] = (d msgs . [msgs > 0]) W[h]^T        written once per edge ([E_all, H, 2 in]); d x[v] is then GATHERED
+//                                                          over v's outgoing (first half) and incoming (second half) edges in
+//                                                          CSR order by k_msg_dx - every element of d x written exactly once
+//     d W[h]  = sum over fixed chunks of edges of cat(x)^T (d msgs . [msgs > 0]): one partial per chunk, summed IN ORDER by
+//     d b[h]    k_msg_reduce (the same for the bias partials of k_msg_dbias); the chunking depends on E alone
+// "task" of k_bgemm = tower (forward, d cat) or (tower, edge chunk) (d W).
 // ---------------------------------------------------------------------------------------------------------------------
 #include "problems.h"
 namespace adkf {
@@ -119,20 +124,30 @@ struct MsgArgs {
     const float* bias;         // [H, out]
     float* msgs;               // [E_all, H, out] (this edge type starts at row e_off)
     const float* d_msgs;       // backward
-    float* dx;                 // [V, H, in]   (zero-initialised by the caller, accumulated atomically)
-    float* dW;                 // [H, 2 in, out]
-    int E, H, in, out, chunk;  // chunk: edges per split of the d W product
+    float* dcat;               // [E_all, H, 2 in] (this edge type starts at row e_off)
+    float* part;               // [nsplit, H * 2 in * out + H * out]: per-chunk partials of d W | d b
+    int E, H, in, out, chunk;  // chunk: edges per split of the d W / d b products
     int64_t e_off;
     bool vec;
 };
 
-// d bias[h, j] += sum_e (d msgs . [msgs > 0])[e, h, j]: 64 columns x 4 row groups per workgroup over a chunk of 256 rows
-// (grid: ceil(H * out / 64) x ceil(E / 256)), eight loads in flight per thread, atomically accumulated
-constexpr int DB_ROWS = 256;
-__global__ __launch_bounds__(256) void k_msg_dbias(MsgArgs m, float* db) {
+// Edges per split of the d W / d b products: a function of E ALONE (at most MSG_SPLITS partials, at least 512 edges each,
+// a multiple of the GEMM's K chunk), so the summation order - hence the bits - does not depend on anything else.
+constexpr int MSG_SPLITS = 64;
+inline int msg_chunk(int E) {
+    const int c = (E + MSG_SPLITS - 1) / MSG_SPLITS;
+    const int r = ((c + 31) / 32) * 32;
+    return r < 512 ? 512 : r;
+}
+inline int msg_nsplit(int E) { const int c = msg_chunk(E); return (E + c - 1) / c; }
+__host__ __device__ inline size_t msg_part_stride(int H, int in, int out) { return (size_t)H * 2 * in * out + (size_t)H * out; }
+
+// d bias partial of one chunk: 64 columns x 4 row groups per workgroup (grid: ceil(H * out / 64) x nsplit), eight loads in
+// flight per thread; the four row-group sums are combined in a fixed order
+__global__ __launch_bounds__(256) void k_msg_dbias(MsgArgs m) {
     __shared__ float part[4][64];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, width = m.H * m.out;
-    const int e0 = blockIdx.y * DB_ROWS, e1 = min(m.E, e0 + DB_ROWS);
+    const int e0 = blockIdx.y * m.chunk, e1 = min(m.E, e0 + m.chunk);
     float s = 0.f;
     if (c < width) {
         int e = e0 + g;
@@ -153,7 +168,45 @@ __global__ __launch_bounds__(256) void k_msg_dbias(MsgArgs m, float* db) {
     }
     part[g][cl] = s;
     __syncthreads();
-    if (g == 0 && c < width) atomicAdd(db + c, (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]));
+    if (g == 0 && c < width)
+        m.part[(size_t)blockIdx.y * msg_part_stride(m.H, m.in, m.out) + (size_t)m.H * 2 * m.in * m.out + c] =
+            (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+}
+
+// out[i] = part[0][i] + part[1][i] + ... (in this order) for the n_w elements of d W and the n_b of d b
+__global__ __launch_bounds__(256) void k_msg_reduce(const float* part, int nsplit, size_t stride, int n_w, int n_b, float* dW, float* db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_w + n_b) return;
+    float s = 0.f;
+    int p = 0;
+    for (; p + 8 <= nsplit; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(p + u) * stride + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < nsplit; ++p) s += part[(size_t)p * stride + i];
+    if (i < n_w) dW[i] = s; else db[i - n_w] = s;
+}
+
+// d x[v, h, :] = sum over v's outgoing edges of d cat[e, h, 0:in]  +  sum over its incoming edges of d cat[e, h, in:2 in],
+// each list in CSR order (perm_s / rowptr_s by source, perm_t / rowptr_t by target, over the concatenated edge list of all
+// edge types).  One thread per (node, column); a workgroup covers 256 / (H in) nodes.
+struct MsgDxArgs {
+    const float* dcat; const int64_t *perm_s, *rowptr_s, *perm_t, *rowptr_t; float* dx; int V, H, in;
+};
+__global__ __launch_bounds__(256) void k_msg_dx(MsgDxArgs a) {
+    const int width = a.H * a.in;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long v = gid / width;
+    if (v >= a.V) return;
+    const int c = (int)(gid - v * width), h = c / a.in, f = c - h * a.in;
+    const size_t col = (size_t)h * 2 * a.in + f, ld = (size_t)a.H * 2 * a.in;
+    float s = 0.f;
+    for (int64_t p = a.rowptr_s[v], p1 = a.rowptr_s[v + 1]; p < p1; ++p) s += a.dcat[(size_t)a.perm_s[p] * ld + col];
+    for (int64_t p = a.rowptr_t[v], p1 = a.rowptr_t[v + 1]; p < p1; ++p) s += a.dcat[(size_t)a.perm_t[p] * ld + col + a.in];
+    a.dx[(size_t)v * width + c] = s;
 }
 
 struct ProbMsgFwd {
@@ -196,8 +249,7 @@ struct ProbMsgBwdX {
     }
     __device__ void b4(int k, int j, float (&v)[4]) const { ld4(m.W + ((size_t)h * 2 * m.in + j) * m.out + k, v); }
     __device__ void epi(int i, int j, float acc, float*) const {
-        const int64_t node = j < m.in ? m.src[i] : m.tgt[i];
-        atomicAdd(m.dx + ((size_t)node * m.H + h) * m.in + (j < m.in ? j : j - m.in), acc);
+        m.dcat[((size_t)(m.e_off + i) * m.H + h) * 2 * m.in + j] = acc;
     }
     __device__ void store_red(int, const float*) const {}
 };
@@ -205,9 +257,9 @@ struct ProbMsgBwdX {
 struct ProbMsgBwdW {
     static constexpr bool A_KCONTIG = false, B_KCONTIG = false;
     static constexpr int NRED = 0;
-    MsgArgs m; int nsplit; int h, e0, len; bool vec;
+    MsgArgs m; int nsplit; int h, sp, e0, len; bool vec;
     __device__ bool setup(int t) {
-        h = t / nsplit; e0 = (t % nsplit) * m.chunk; len = min(m.chunk, m.E - e0); vec = m.vec;
+        h = t / nsplit; sp = t % nsplit; e0 = sp * m.chunk; len = min(m.chunk, m.E - e0); vec = m.vec;
         return len > 0;
     }
     __device__ int M() const { return 2 * m.in; } __device__ int N() const { return m.out; } __device__ int K() const { return len; }
@@ -228,7 +280,9 @@ struct ProbMsgBwdW {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = ms[q] > 0.f ? v[q] : 0.f;
     }
-    __device__ void epi(int i, int j, float acc, float*) const { atomicAdd(m.dW + ((size_t)h * 2 * m.in + i) * m.out + j, acc); }
+    __device__ void epi(int i, int j, float acc, float*) const {
+        m.part[(size_t)sp * msg_part_stride(m.H, m.in, m.out) + ((size_t)h * 2 * m.in + i) * m.out + j] = acc;
+    }
     __device__ void store_red(int, const float*) const {}
 };
 

@@ -115,6 +115,12 @@ class _GraphPlan:
         # segments of the concatenated message list by target node, for the fused aggregation kernel (csrc/pna.h)
         self.perm = torch.argsort(self.all_tgts, stable=True)
         self.rowptr = torch.cat((counts.new_zeros(1), torch.cumsum(counts, 0)))
+        # ... and by SOURCE node: the backward of the message functions gathers d x over each node's outgoing and incoming
+        # edges in these two fixed orders instead of scatter-adding atomically (bit-reproducible gradients)
+        all_srcs = torch.cat(self.srcs) if self.srcs else torch.zeros(0, dtype=torch.long)
+        out_counts = torch.bincount(all_srcs, minlength=num_nodes)
+        self.perm_src = torch.argsort(all_srcs, stable=True)
+        self.rowptr_src = torch.cat((out_counts.new_zeros(1), torch.cumsum(out_counts, 0)))
         if pna:
             log_deg = torch.log(deg + 1.0)
             self.amplify = (log_deg / PNA_DELTA).unsqueeze(-1)                      # gnn.py:241
@@ -138,6 +144,7 @@ class TowerMessagePassing(nn.Module):
         self.weights = nn.ParameterList()   # [edge_type][layer] -> [H, in, out]
         self.biases = nn.ParameterList()
         self.depth = config.message_function_depth
+        self.capture: Optional[list] = None   # diagnostics: a list here receives the post-ReLU messages [E_all, H, out] of each forward
         for _ in range(config.num_edge_types):
             for l in range(self.depth):
                 w = torch.empty(H, dims[l], dims[l + 1])
@@ -163,6 +170,8 @@ class TowerMessagePassing(nn.Module):
             # GPU fast path (csrc/pna.h): per edge type ONE batched MFMA GEMM that gathers source / target states on the fly
             # and applies bias + ReLU in its epilogue, then ONE aggregation kernel; no fallback here - a missing library raises
             msgs = _MessageFunction.apply(x.contiguous(), plan, H, self.in_dim, self.out_msg, *self.weights, *self.biases)
+            if self.capture is not None:
+                self.capture.append(msgs.detach())
             agg = _PNAAggregate.apply(msgs, plan.perm, plan.rowptr, V)
             if self.kind == "pna" and scale:
                 amp, att = plan.amplify.unsqueeze(-1).to(x.dtype), plan.attenuate.unsqueeze(-1).to(x.dtype)
@@ -178,6 +187,8 @@ class TowerMessagePassing(nn.Module):
                     h = F.relu(h)
             msgs.append(F.relu(h))                                             # gnn.py:141
         msgs = torch.cat(msgs, dim=0)                                          # [E_all, H, out_msg]
+        if self.capture is not None:
+            self.capture.append(msgs.detach())
         tg = plan.all_tgts
         if self.kind == "plain":
             return x.new_zeros(V, H, m).index_add_(0, tg, msgs).reshape(V, -1)
@@ -239,23 +250,33 @@ class _MessageFunction(torch.autograd.Function):
         x, msgs, *weights = ctx.saved_tensors
         plan, (H, in_dim, out_dim), n_et = ctx.plan, ctx.dims, ctx.n_et
         d_msgs = d_msgs.contiguous()
-        dx = torch.zeros_like(x)
-        st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        db_all = torch.zeros(n_et, H, out_dim, dtype=torch.float32, device=x.device)   # one fill for all edge types
-        dWs, dbs, off = [], [], 0
+        dev = x.device
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        E_all = int(plan.all_tgts.shape[0])
+        # no floating-point atomics anywhere (csrc/pna.h): d cat is written once per edge and d x gathered over each node's
+        # edge lists; d W / d b are per-chunk partials summed in a fixed order - every output element is written, none pre-filled
+        dcat = torch.empty(E_all, H, 2 * in_dim, dtype=torch.float32, device=dev)
+        dW_all = [torch.empty_like(w) for w in weights]
+        db_all = torch.empty(n_et, H, out_dim, dtype=torch.float32, device=dev)
+        need = max((int(lib.adkf_msg_backward_scratch_bytes(int(plan.srcs[et].shape[0]), H, in_dim, out_dim)) for et in range(n_et)), default=0)
+        scratch = torch.empty(max(need, 4) // 4, dtype=torch.float32, device=dev)
+        dbs, off = [], 0
         for et in range(n_et):
             E = int(plan.srcs[et].shape[0])
             w = weights[et].contiguous()
-            dW = torch.zeros_like(w)
-            db = db_all[et]
-            _lib.check(lib.adkf_msg_backward(C.c_void_p(x.data_ptr()), C.c_void_p(plan.srcs[et].data_ptr()), C.c_void_p(plan.tgts[et].data_ptr()),
-                                             C.c_void_p(w.data_ptr()), C.c_void_p(msgs.data_ptr()), C.c_void_p(d_msgs.data_ptr()), E, H, in_dim,
-                                             out_dim, off, C.c_void_p(dx.data_ptr()), C.c_void_p(dW.data_ptr()), C.c_void_p(db.data_ptr()), st),
+            _lib.check(lib.adkf_msg_backward(ptr(x), ptr(plan.srcs[et]), ptr(plan.tgts[et]), ptr(w), ptr(msgs), ptr(d_msgs), E, H, in_dim,
+                                             out_dim, off, ptr(dcat), ptr(dW_all[et]), ptr(db_all[et]), ptr(scratch), scratch.numel() * 4, st),
                        "adkf_msg_backward")
-            dbs.append(db)
-            dWs.append(dW)
+            dbs.append(db_all[et])
             off += E
-        return (dx, None, None, None, None, *dWs, *dbs)
+        dx = torch.empty_like(x)
+        if E_all > 0:
+            _lib.check(lib.adkf_msg_dx_gather(ptr(dcat), ptr(plan.perm_src), ptr(plan.rowptr_src), ptr(plan.perm), ptr(plan.rowptr),
+                                              x.shape[0], H, in_dim, ptr(dx), st), "adkf_msg_dx_gather")
+        else:
+            dx.zero_()
+        return (dx, None, None, None, None, *dW_all, *dbs)
 
 
 class _PNAAggregate(torch.autograd.Function):
@@ -371,6 +392,57 @@ def _segment_softmax(scores: torch.Tensor, index: torch.Tensor, num_segments: in
     return ex / den[index]
 
 
+class _ReadoutPool(torch.autograd.Function):
+    """Per-graph pooling of the combined read-out on the GPU (``adkf_readout_pool`` / ``_backward``, csrc/readout.h): segment
+    softmax + weighted mean, sigmoid-weighted sum and max in ONE kernel, each per-graph sum in the fixed order of the graph's
+    node list; the backward writes every element once.  Bit-reproducible, unlike ``index_add_`` and the backward of a gather."""
+
+    @staticmethod
+    def forward(ctx, s_mean, v_mean, s_sum, v_sum, emb, node_to_graph, num_graphs, nh, hd):
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        dev = emb.device
+        V, D, G = emb.shape[0], emb.shape[1], int(num_graphs)
+        s_mean, v_mean, s_sum, v_sum, emb = (t.contiguous() for t in (s_mean, v_mean, s_sum, v_sum, emb))
+        n2g = node_to_graph.contiguous()
+        counts = torch.bincount(n2g, minlength=G)
+        perm = torch.argsort(n2g, stable=True)
+        rowptr = torch.cat((counts.new_zeros(1), torch.cumsum(counts, 0)))
+        f32 = dict(dtype=torch.float32, device=dev)
+        w_mean, w_sum = torch.empty(V, nh, **f32), torch.empty(V, nh, **f32)
+        g_mean, g_sum, g_max = torch.empty(G, nh * hd, **f32), torch.empty(G, nh * hd, **f32), torch.empty(G, D, **f32)
+        argmax = torch.empty(G, D, dtype=torch.int32, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(lib.adkf_readout_pool(ptr(s_mean), ptr(v_mean), ptr(s_sum), ptr(v_sum), ptr(emb), ptr(perm), ptr(rowptr), V, G, nh, hd, D,
+                                         ptr(w_mean), ptr(w_sum), ptr(g_mean), ptr(g_sum), ptr(g_max), ptr(argmax), st), "adkf_readout_pool")
+        ctx.save_for_backward(v_mean, v_sum, w_mean, w_sum, g_mean, argmax, n2g)
+        ctx.dims = (V, G, nh, hd, D)
+        return g_mean, g_sum, g_max
+
+    @staticmethod
+    def backward(ctx, dg_mean, dg_sum, dg_max):
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        v_mean, v_sum, w_mean, w_sum, g_mean, argmax, n2g = ctx.saved_tensors
+        V, G, nh, hd, D = ctx.dims
+        dev = v_mean.device
+        dg_mean, dg_sum, dg_max = dg_mean.contiguous(), dg_sum.contiguous(), dg_max.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_s_mean, d_s_sum = torch.empty(V, nh, **f32), torch.empty(V, nh, **f32)
+        d_v_mean, d_v_sum, d_emb = torch.empty(V, nh * hd, **f32), torch.empty(V, nh * hd, **f32), torch.empty(V, D, **f32)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(lib.adkf_readout_pool_backward(ptr(v_mean), ptr(v_sum), ptr(w_mean), ptr(w_sum), ptr(g_mean), ptr(argmax), ptr(n2g),
+                                                  ptr(dg_mean), ptr(dg_sum), ptr(dg_max), V, G, nh, hd, D, ptr(d_s_mean), ptr(d_v_mean),
+                                                  ptr(d_s_sum), ptr(d_v_sum), ptr(d_emb), st), "adkf_readout_pool_backward")
+        return d_s_mean, d_v_mean, d_s_sum, d_v_sum, d_emb, None, None, None, None
+
+
 class CombinedGraphReadout(nn.Module):
     """weighted-mean + weighted-sum (multi-head) + max pooling, then Linear(ReLU(cat))  (graph_readout.py:119-296).
     The two scoring MLPs and two value MLPs share their input, so their first layers run as one GEMM."""
@@ -393,16 +465,22 @@ class CombinedGraphReadout(nn.Module):
         V, hid = node_embeddings.shape[0], self.nh * self.hd
         h = F.relu(self.first(node_embeddings))
         h_ms, h_mv, h_ss, h_sv = h.split(hid, dim=1)
-        w_mean = _segment_softmax(self.mean_score_out(h_ms), node_to_graph_id, num_graphs)      # [V, heads]
-        w_sum = torch.sigmoid(self.sum_score_out(h_ss))
-        v_mean = self.mean_value_out(h_mv).view(V, self.nh, self.hd)
-        v_sum = self.sum_value_out(h_sv).view(V, self.nh, self.hd)
-        zeros = node_embeddings.new_zeros(num_graphs, hid)
-        g_mean = zeros.index_add(0, node_to_graph_id, (w_mean.unsqueeze(-1) * v_mean).reshape(V, hid))
-        g_sum = zeros.index_add(0, node_to_graph_id, (w_sum.unsqueeze(-1) * v_sum).reshape(V, hid))
-        idx = node_to_graph_id.view(-1, 1).expand_as(node_embeddings)
-        g_max = node_embeddings.new_zeros(num_graphs, node_embeddings.shape[1]).scatter_reduce_(
-            0, idx, node_embeddings, reduce="amax", include_self=False)
+        if node_embeddings.is_cuda and node_embeddings.dtype == torch.float32:
+            # GPU: one fused, order-fixed pooling kernel (no fallback: a missing library raises)
+            g_mean, g_sum, g_max = _ReadoutPool.apply(self.mean_score_out(h_ms), self.mean_value_out(h_mv), self.sum_score_out(h_ss),
+                                                      self.sum_value_out(h_sv), node_embeddings, node_to_graph_id, num_graphs,
+                                                      self.nh, self.hd)
+        else:
+            w_mean = _segment_softmax(self.mean_score_out(h_ms), node_to_graph_id, num_graphs)      # [V, heads]
+            w_sum = torch.sigmoid(self.sum_score_out(h_ss))
+            v_mean = self.mean_value_out(h_mv).view(V, self.nh, self.hd)
+            v_sum = self.sum_value_out(h_sv).view(V, self.nh, self.hd)
+            zeros = node_embeddings.new_zeros(num_graphs, hid)
+            g_mean = zeros.index_add(0, node_to_graph_id, (w_mean.unsqueeze(-1) * v_mean).reshape(V, hid))
+            g_sum = zeros.index_add(0, node_to_graph_id, (w_sum.unsqueeze(-1) * v_sum).reshape(V, hid))
+            idx = node_to_graph_id.view(-1, 1).expand_as(node_embeddings)
+            g_max = node_embeddings.new_zeros(num_graphs, node_embeddings.shape[1]).scatter_reduce_(
+                0, idx, node_embeddings, reduce="amax", include_self=False)
         raw = torch.cat((self.mean_combination(g_mean), self.sum_combination(g_sum), self.max_combination(g_max)), dim=1)
         return self.combination_layer(F.relu(raw))
 

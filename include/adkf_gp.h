@@ -175,13 +175,38 @@ int adkf_ift_hypergrad_cg(const adkf_batch_t* b, const float* phi, int32_t flags
 /* a1 (message functions of RelationalMP, fs_mol/modules/gnn.py:95-148, for the default depth-1 message MLP): all towers of
  * one edge type in one batched GEMM with the source / target node states gathered on the fly:
  *   msgs[e_off + e, h, :] = relu(cat(x[src_e, h, :], x[tgt_e, h, :]) W[h] + bias[h]),
- * x [V, H, in], W [H, 2 in, out], bias [H, out], msgs [E_all, H, out].  The backward accumulates ATOMICALLY into dx
- * [V, H, in], dW [H, 2 in, out] and db [H, out] (all three must be initialised by the caller). */
+ * x [V, H, in], W [H, 2 in, out], bias [H, out], msgs [E_all, H, out].
+ * The backward is reproducible to the bit - no floating-point atomics (the reference's scatter ops and PyTorch's index_add_
+ * are, on a GPU): adkf_msg_backward writes d cat[e_off + e, h, :] = (d msgs . [msgs > 0]) W[h]^T into dcat [E_all, H, 2 in]
+ * and the complete dW [H, 2 in, out], db [H, out] of this edge type (per-chunk partials in `scratch`, at least
+ * adkf_msg_backward_scratch_bytes(E, H, in, out) bytes, summed in a fixed order; nothing needs initialising; E = 0 zero-fills
+ * dW and db).  After all edge types, ONE adkf_msg_dx_gather forms dx [V, H, in]: the sum over each node's outgoing edges of
+ * the first half of d cat and over its incoming edges of the second half, in the order of the two CSR lists (perm_*: edge
+ * ids of the concatenated edge list sorted stably by source / target node, rowptr_* [V + 1]). */
 int adkf_msg_forward(const float* x, const int64_t* src, const int64_t* tgt, const float* W, const float* bias, int32_t E,
                      int32_t H, int32_t in, int32_t out, int64_t e_off, float* msgs, void* stream);
+size_t adkf_msg_backward_scratch_bytes(int32_t E, int32_t H, int32_t in, int32_t out);
 int adkf_msg_backward(const float* x, const int64_t* src, const int64_t* tgt, const float* W, const float* msgs,
-                      const float* d_msgs, int32_t E, int32_t H, int32_t in, int32_t out, int64_t e_off, float* dx,
-                      float* dW, float* db, void* stream);
+                      const float* d_msgs, int32_t E, int32_t H, int32_t in, int32_t out, int64_t e_off, float* dcat,
+                      float* dW, float* db, void* scratch, size_t scratch_bytes, void* stream);
+int adkf_msg_dx_gather(const float* dcat, const int64_t* perm_src, const int64_t* rowptr_src, const int64_t* perm_tgt,
+                       const int64_t* rowptr_tgt, int32_t V, int32_t H, int32_t in, float* dx, void* stream);
+
+/* a1 (per-graph pooling of CombinedGraphReadout, fs_mol/modules/graph_readout.py:119-177: the weighted-mean head's
+ * scatter_softmax + index_add_ :238-252, the weighted-sum head's sigmoid weights :236, the max pooler's scatter :289) between
+ * the node-level MLPs and the combination layers, every per-graph sum in the fixed order of the graph's node list:
+ *   w_mean = segment-softmax(s_mean), g_mean[g] = sum_v w_mean[v] v_mean[v];  w_sum = sigmoid(s_sum), g_sum likewise;
+ *   g_max[g] = max_v emb[v] (0 and argmax -1 for a graph without nodes; first maximum in list order).
+ * s_* [V, nh], v_* [V, nh, hd], emb [V, D]; perm [V] node ids sorted stably by graph, rowptr [G + 1]; nh <= 64.  Outputs w_*
+ * [V, nh] (kept for the backward), g_mean / g_sum [G, nh hd], g_max / argmax [G, D].  The backward writes every element of
+ * d_s_* [V, nh], d_v_* [V, nh hd], d_emb [V, D] exactly once (no scatter). */
+int adkf_readout_pool(const float* s_mean, const float* v_mean, const float* s_sum, const float* v_sum, const float* emb,
+                      const int64_t* perm, const int64_t* rowptr, int32_t V, int32_t G, int32_t nh, int32_t hd, int32_t D,
+                      float* w_mean, float* w_sum, float* g_mean, float* g_sum, float* g_max, int32_t* argmax, void* stream);
+int adkf_readout_pool_backward(const float* v_mean, const float* v_sum, const float* w_mean, const float* w_sum,
+                               const float* g_mean, const int32_t* argmax, const int64_t* node_to_graph, const float* dg_mean,
+                               const float* dg_sum, const float* dg_max, int32_t V, int32_t G, int32_t nh, int32_t hd, int32_t D,
+                               float* d_s_mean, float* d_v_mean, float* d_s_sum, float* d_v_sum, float* d_emb, void* stream);
 
 /* a1 (aggregation inside RelationalMultiAggrMP._aggregate_messages, fs_mol/modules/gnn.py:197-265; torch_scatter's
  * scatter_sum / scatter_mean / scatter_max there): SUM | MEAN | STD | MAX of the incoming messages of every target

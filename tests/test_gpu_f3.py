@@ -2,10 +2,10 @@
 
 (1) numpy ``DKTBatch`` / ``FSMolBatch``-shaped objects (the field layout of fs_mol/data/dkt.py:25-46 and
     fs_mol/data/fsmol_batcher.py:22-94, restated in tests/test_meta_batch.py) -> ``dkt_batch_from_fsmol`` ->
-    ``collate_meta_batch`` -> ``model_meta_step`` give, bit for bit, what the torch-built batch of the same molecules gives.
+    ``collate_meta_batch`` -> ``model_meta_step`` give, BIT FOR BIT, what the torch-built batch of the same molecules gives.
 (2) a checkpoint with the reference's names (``save_model``, fs_mol/utils/adaptive_dkt_utils.py:221-259; loaded as
     :305-327 does) written by checkpoint.py, reloaded through ``load_reference_checkpoint`` into an ``ADKTModel``:
-    ``evaluate.meta_test`` predictions are unchanged.
+    ``evaluate.meta_test`` predictions are unchanged, bit for bit.
 Every number comes from libadkf_gp.so + the fused extractor kernels; nothing here reads /root/reference."""
 from dataclasses import dataclass
 from typing import List
@@ -97,18 +97,16 @@ def test_reference_numpy_batches_through_the_device_meta_step():
                         [p.grad.detach().cpu().clone() for p in model.feature_extractor_params() if p.grad is not None]))
     (la, pa, ga), (lb, pb, gb) = results
     assert torch.isfinite(la).all() and la.shape == (3,)
-    # The adapter only changes the container, so both runs are the same arithmetic on the same numbers - but not to the bit: the
-    # extractor's scatter-adds (torch index_add_ forward, the fused kernels' atomic accumulation backward, csrc/pna.h) sum in
-    # whatever order the waves arrive, and the inner fit amplifies that rounding noise.  Held to the north-star 1e-4 (max-norm
-    # against the largest entry), far below anything a mis-mapped field would cause.
-    def rel(a, b):
-        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
-    assert rel(la, lb) <= 1e-4, rel(la, lb)
+    # The adapter only changes the container, so both runs are the same arithmetic on the same numbers - and, since round 4, to
+    # the bit: the extractor's per-graph and per-node sums run in a fixed order (csrc/readout.h, csrc/pna.h: no floating-point
+    # atomics), so the inner fit sees identical features and stops at the identical point.
+    assert torch.equal(la, lb), (la, lb)
     assert len(ga) == len(gb) > 0
-    gmax = max(float(g.abs().max()) for g in gb)
-    assert gmax > 0.0                                                # a step was taken
-    assert max(float((x - y).abs().max()) for x, y in zip(ga, gb)) <= 1e-4 * gmax
-    assert max(float((x - y).abs().max()) for x, y in zip(pa, pb)) <= 1e-4 * 0.1 * gmax + 1e-7      # theta_new = theta - 0.1 grad
+    assert max(float(g.abs().max()) for g in gb) > 0.0              # a step was taken
+    for x, y in zip(ga, gb):
+        assert torch.equal(x, y)
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y)
 
 
 def test_reference_named_checkpoint_through_meta_test(tmp_path):
@@ -132,15 +130,14 @@ def test_reference_named_checkpoint_through_meta_test(tmp_path):
     model2 = model2.to(dev)
     preds1, var1, phi1, _ = E.meta_test(model2, mb, want_var=True)
     torch.cuda.synchronize()
-    # the same weights under the reference's names and back: the same extractor (features to float32 rounding of the scatter-adds'
-    # summation order, see above), hence the same fitted GP and predictions
+    # the same weights under the reference's names and back: the same extractor to the bit, hence the same fitted GP and the
+    # same predictions to the bit (the path has no floating-point atomics since round 4)
     from adkf_ift_amd.meta_batch import meta_features
     with torch.no_grad():
         f0, f1 = meta_features(model.eval(), mb), meta_features(model2.eval(), mb)
     for a, b in zip(f0, f1):
-        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
-    # (2e-3: the bound of the other fitted comparisons, tests/test_gpu_reference_pins.py - each meta_test runs its own inner
-    # fit, which stops somewhere along the flat lengthscale valley depending on the rounding noise of its features)
+        assert torch.equal(a, b)
+    assert torch.equal(phi0, phi1)
     for a, b in ((preds0, preds1), (var0, var1)):
-        assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max()), float((a - b).abs().max())
+        assert torch.equal(torch.as_tensor(a), torch.as_tensor(b))
     assert ((preds0 >= 0) & (preds0 <= 1)).all()

@@ -68,6 +68,44 @@ def test_default_width_extractor_forward_and_gradients_vs_oracle(dev):
           "(float32 PyTorch on the CPU: %.2e)" % (err, worst, e32))
 
 
+@pytest.mark.parametrize("kind,empty_type", [("PNA", None), ("PNA", 1), ("MultiAggr", 2)])
+def test_fused_kernels_on_odd_shapes_vs_cpu_float64(dev, kind, empty_type):
+    """The order-fixed kernels of round 4 (message-function backward: d cat + CSR gather, chunk partials for d W / d b,
+    csrc/pna.h; read-out pooling forward / backward, csrc/readout.h) on sizes that are a multiple of nothing - 4 towers x 6-wide
+    messages, 3 read-out heads x 5, isolated nodes, a single-atom graph, an edge type without edges - against the SAME module
+    evaluated in float64 on the CPU through PyTorch's own index_add_ / scatter_reduce_ / autograd
+    (fs_mol/modules/gnn.py:203-244, fs_mol/modules/graph_readout.py:236-252,289)."""
+    from adkf_ift_amd.gnn import GraphFeatureExtractor
+    from test_gnn import random_graphs, small_cfg
+
+    cfg = small_cfg(kind)
+    batch = random_graphs(11, seed=17, empty_type=empty_type)
+    torch.manual_seed(9)
+    ref = GraphFeatureExtractor(cfg).double()
+    with torch.no_grad():
+        for blk in ref.gnn.gnn_blocks:
+            blk.alpha.fill_(0.6)
+    got = GraphFeatureExtractor(cfg)
+    got.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    got = got.to(dev)
+    b32 = batch.to(dev)
+    b32.node_features = b32.node_features.float()
+    want = ref(batch)
+    z = got(b32)
+    w = torch.randn(want.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(2))
+    (want * w).sum().backward()
+    (z * w.float().to(dev)).sum().backward()
+    assert (z.double().cpu() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    named = dict(got.named_parameters())
+    scale = max(p.grad.abs().max().item() for p in ref.parameters() if p.grad is not None)
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            assert named[n].grad is None, n
+            continue
+        e = (named[n].grad.double().cpu() - p.grad).abs().max().item() / scale
+        assert e <= 5e-5, (n, e)
+
+
 def _molecules(n, seed):
     from adkf_ift_amd.meta_batch import MoleculeFeatures
     from test_gnn import random_graphs
@@ -131,13 +169,13 @@ def test_c3_default_model_meta_step_vs_per_task_oracle_loop(dev):
         torch.autograd.backward([Zs, Zq], [torch.tensor(q["dZs_total"]) / T, torch.tensor(q["dZq_total"]) / T])
     assert np.abs(losses.cpu().numpy() - np.array(want_losses)).max() <= 1e-4 * np.abs(want_losses).max()
     mine = grads_under_reference_names(model.graph_feature_extractor)
-    # Bound: 1e-3 of the largest gradient entry.  The extractor alone is at 2.9e-4 (test above, reproducible); through the whole
-    # step the same quantity came out at 2.9e-4 and at 7.4e-4 in two runs of round 3 (4.75e-4 in round 2) - the std aggregation's
-    # gradient is DISCONTINUOUS in its inputs (the indicator [b_e^2 > mean^2] of fs_mol/modules/gnn.py:231-240, times a slope of
-    # up to 1581), so which side a handful of (node, feature) pairs fall on differs between a float32 forward and the float64
-    # oracle, and between runs that differ in the summation order of the atomic scatter-adds in front of it.  5e-4 was a bound
-    # with 5 % margin on one observation (round 2 verdict) and has now been seen exceeded.
-    C3_TOL = 1e-3
+    # Bound: 9e-4 of the largest gradient entry, set from the REPRODUCIBLE value of this test: 7.38e-4 (round 4: the extractor has
+    # no floating-point atomics any more, tests/test_gpu_determinism.py, so the number no longer moves between runs - round 3 saw
+    # 2.9e-4 and 7.4e-4 on the same tree and asserted 1e-3).  The extractor alone is at 2.9e-4 (test above).  What is left is the
+    # std aggregation of the reference, whose gradient is DISCONTINUOUS in its inputs (the indicator [b_e^2 > mean^2] of
+    # fs_mol/modules/gnn.py:231-240, times a slope of up to 1581): the (layer, node, tower, feature) entries where the float32
+    # forward and the float64 oracle fall on different sides are counted and printed below.
+    C3_TOL = 9e-4
     scale = max(max(v.grad.abs().max().item() for v in sd64.values() if v.grad is not None), max(p.grad.abs().max().item() for p in fc))
     worst = 0.0
     for k, v in sd64.items():
@@ -151,3 +189,31 @@ def test_c3_default_model_meta_step_vs_per_task_oracle_loop(dev):
         worst = max(worst, e)
         assert e <= C3_TOL, e
     print("C3 default model: worst theta.grad error %.2e of the largest entry" % worst)
+    # ---- which indicators of the std aggregation differ between the float32 device forward and a float64 forward ----
+    from adkf_ift_amd.gnn import GraphFeatureExtractor
+    twin = GraphFeatureExtractor(gcfg).double()
+    twin.load_reference_state_dict(sd)
+    caps64, caps32 = [], []
+    for blk64, blk32 in zip(twin.gnn.gnn_blocks, model.graph_feature_extractor.gnn.gnn_blocks):
+        blk64.mp.capture, blk32.mp.capture = caps64, caps32
+    mols = mb.molecules
+    with torch.no_grad():
+        g64 = mols.graph().to("cpu")
+        g64.node_features = g64.node_features.double()
+        twin(g64)
+        model.graph_feature_extractor(mols.graph())
+    for blk in model.graph_feature_extractor.gnn.gnn_blocks:
+        blk.mp.capture = None
+    adj = [torch.cat((a, a.flip(1)), 0) for a in g64.adjacency_lists]
+    tg = torch.cat([a[:, 1] for a in adj])
+    V, m = g64.node_features.shape[0], gcfg.gnn_config.per_head_dim
+    cnt = torch.bincount(tg, minlength=V).clamp(min=1).double().view(V, 1, 1)
+
+    def indicator(msgs):
+        b = msgs.double().cpu()[..., m:2 * m]
+        mean = torch.zeros(V, *b.shape[1:], dtype=torch.float64).index_add_(0, tg, b) / cnt
+        return b.pow(2) > mean[tg].pow(2)
+    flips = [int((indicator(a) != indicator(b)).sum()) for a, b in zip(caps64, caps32)]
+    total = caps64[0][..., m:2 * m].numel()
+    print("C3 default model: std-aggregation indicators that differ between the float32 device forward and a float64 forward, "
+          "per layer (of %d each): %s" % (total, flips))
