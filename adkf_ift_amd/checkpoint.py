@@ -9,6 +9,11 @@
   through ``GraphFeatureExtractor.load_reference_state_dict`` (per-tower Linear layers -> the fused parameters here).
 * ``reference_state_dict`` / ``save_model`` write the reference's parameter names and shapes, with the configuration as a
   plain dict (a file the reference can consume with ``load_model_weights`` after building its model from its own config).
+* ``load_model_weights`` (:240-258) additionally restores the optimiser state - written by this package (fused parameters) or by
+  the reference (one Adam slot per tower / edge-type ``nn.Linear``: mapped through the same name mapping as the weights).
+* ``load_model_gnn_weights`` (:261-303): warm start of the GNN part only from a pre-trained extractor checkpoint, an optimiser
+  with the loaded group at learning_rate / 10, and the 100-step linear warm-up of that group (``linear_warmup``,
+  fs_mol/models/abstract_torch_fsmol_model.py:169-172).
 """
 from __future__ import annotations
 
@@ -169,3 +174,110 @@ def save_model(model: ADKTModel, path: str, optimizer: Optional[torch.optim.Opti
     if epoch is not None:
         data["epoch"] = epoch
     torch.save(data, path)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# optimiser state (fs_mol/utils/adaptive_dkt_utils.py:255-258) and the GNN warm start (:261-303)
+# ----------------------------------------------------------------------------------------------------------------------
+def linear_warmup(cur_step: int, warmup_steps: int = 0) -> float:
+    """fs_mol/models/abstract_torch_fsmol_model.py:169-172."""
+    if cur_step >= warmup_steps:
+        return 1.0
+    return cur_step / warmup_steps
+
+
+def _reference_param_names(ref_sd: Dict[str, torch.Tensor]):
+    """Names of what the reference's ``feature_extractor_params()`` yields (fs_mol/models/adaptive_dkt.py:74-79: every
+    parameter whose name does not start with ``gp_``), in registration order - the order of the Adam slots.  A state dict lists
+    buffers as well: BatchNorm statistics are the only ones outside the GP tail."""
+    skip = ("running_mean", "running_var", "num_batches_tracked")
+    return [k for k in ref_sd if not k.startswith("gp_") and not k.startswith("mll.") and not k.endswith(skip)]
+
+
+def restore_optimizer_state(model: ADKTModel, optimizer: torch.optim.Optimizer, opt_sd: Dict[str, Any],
+                            ref_model_sd: Optional[Dict[str, torch.Tensor]] = None) -> str:
+    """``load_model_weights``' second half (adaptive_dkt_utils.py:255-258).  Two layouts are understood:
+
+    * "own": written by ``save_model`` of this package - one slot per (fused) parameter of ``feature_extractor_params()``:
+      ``optimizer.load_state_dict``;
+    * "reference": one slot per reference parameter (per-tower, per-edge-type Linear layers; separate read-out MLPs).  The
+      ``exp_avg`` / ``exp_avg_sq`` tensors are arranged as state dicts under the reference's names (``ref_model_sd`` gives the
+      slot order) and sent through the SAME mapping as the weights, which yields the moments of the fused parameters; ``step``
+      and the hyper-parameters of the first group carry over.
+    Returns which layout was found."""
+    ours = [p for g in optimizer.param_groups for p in g["params"]]
+    n_saved = sum(len(g["params"]) for g in opt_sd["param_groups"])
+    state = opt_sd["state"]
+    if n_saved == len(ours) and all(tuple(state[i]["exp_avg"].shape) == tuple(p.shape) for i, p in enumerate(ours) if i in state):
+        optimizer.load_state_dict(opt_sd)
+        return "own"
+    if ref_model_sd is None:
+        raise ValueError("optimizer state with the reference's parameter layout needs the checkpoint's model_state_dict for the slot order")
+    names = _reference_param_names(ref_model_sd)
+    if len(names) != n_saved:
+        raise ValueError(f"optimizer state has {n_saved} slots, the checkpoint lists {len(names)} feature-extractor parameters")
+    order = [i for g in opt_sd["param_groups"] for i in g["params"]]
+    moments = {}
+    for key in ("exp_avg", "exp_avg_sq"):
+        as_sd = {}
+        for slot, name in zip(order, names):
+            ref_t = ref_model_sd[name]
+            as_sd[name] = state[slot][key].reshape(ref_t.shape) if slot in state else torch.zeros_like(ref_t)
+        scratch = ADKTModel(model.config)
+        load_reference_state_dict(scratch, as_sd)
+        moments[key] = dict(scratch.named_parameters())
+    steps = [state[s]["step"] for s in order if s in state]
+    step = steps[0] if steps else torch.tensor(0.0)
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    for p in ours:
+        n = name_of[id(p)]
+        optimizer.state[p] = {"step": torch.as_tensor(float(step)), "exp_avg": moments["exp_avg"][n].detach().to(p).clone(),
+                              "exp_avg_sq": moments["exp_avg_sq"][n].detach().to(p).clone()}
+    g0 = opt_sd["param_groups"][0]
+    for g in optimizer.param_groups:
+        for k in ("lr", "betas", "eps", "weight_decay", "amsgrad"):
+            if k in g0 and k in g:
+                g[k] = g0[k]
+    return "reference"
+
+
+def load_model_weights(model: ADKTModel, path: str, optimizer: Optional[torch.optim.Optimizer] = None,
+                       device: Optional[torch.device] = None) -> Dict[str, Any]:
+    """``ADKTModelTrainer.load_model_weights`` (adaptive_dkt_utils.py:240-258): weights into an EXISTING model, optimiser state
+    into ``optimizer`` when the file carries one.  Returns the checkpoint dict."""
+    ckpt = torch.load(path, map_location=device, pickle_module=_tolerant_pickle, weights_only=False)
+    load_reference_state_dict(model, ckpt["model_state_dict"])
+    if optimizer is not None and ckpt.get("optimizer_state_dict") is not None:
+        restore_optimizer_state(model, optimizer, ckpt["optimizer_state_dict"], ckpt["model_state_dict"])
+    return ckpt
+
+
+def load_model_gnn_weights(model: ADKTModel, path: str, learning_rate: float, device: Optional[torch.device] = None):
+    """``ADKTModelTrainer.load_model_gnn_weights`` (adaptive_dkt_utils.py:261-303): the graph feature extractor - everything
+    but ``final_norm_layer`` - is loaded from a pre-trained extractor checkpoint whose ``model_state_dict`` names it WITHOUT the
+    ``graph_feature_extractor.`` prefix (``readout_layer.`` of older files reads as ``readout.``); the rest of the model keeps
+    its initialisation.  Returns ``(optimizer, lr_scheduler)``: Adam with two groups - everything else at ``learning_rate``, the
+    loaded parameters at ``learning_rate / 10`` - and a ``LambdaLR`` that leaves the first group alone and ramps the loaded
+    group up linearly over its first 100 steps.  Step the scheduler after every optimiser step (:412-413;
+    ``model_meta_step(..., lr_scheduler=...)`` does)."""
+    from functools import partial
+
+    ckpt = torch.load(path, map_location=device, pickle_module=_tolerant_pickle, weights_only=False)
+    pre = {k: (v.data if isinstance(v, torch.nn.Parameter) else v) for k, v in ckpt["model_state_dict"].items()}
+    gfe = model.graph_feature_extractor
+    ref = {}
+    for name, value in pre.items():
+        generic = "readout" + name[len("readout_layer"):] if name.startswith("readout_layer.") else name
+        if "final_norm_layer" not in generic:
+            ref["graph_feature_extractor." + generic] = value
+    for k, v in gfe.state_dict().items():                 # not loaded (:272): the model's own output norm stays as it is
+        if k.startswith("final_norm_layer."):
+            ref["graph_feature_extractor." + k] = v.detach().clone()
+    gfe.load_reference_state_dict(ref, prefix="graph_feature_extractor.")
+    gnn_params = [p for n, p in gfe.named_parameters() if "final_norm_layer" not in n]
+    loaded = {id(p) for p in gnn_params}
+    other_params = [p for p in model.feature_extractor_params() if id(p) not in loaded]
+    optimizer = torch.optim.Adam([{"params": other_params, "lr": learning_rate}, {"params": gnn_params, "lr": learning_rate / 10}])
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=[partial(linear_warmup, warmup_steps=0),
+                                                                        partial(linear_warmup, warmup_steps=100)])
+    return optimizer, scheduler

@@ -382,9 +382,9 @@ template <int NMAX, int NT> struct Sweep : SweepBlk<NMAX, NT> {};
 
 }  // namespace adkf
 
-// 128 points x 512 threads: ADKF_SWEEP_M (default) = rank-4 updates on the matrix pipe (factor_m.h); ADKF_SWEEP_M=0 keeps the
-// VALU variant of factor_w.h, ADKF_SWEEP_M=0 ADKF_SWEEP_W=0 the blocked one above, ADKF_SWEEP_M=2 the sixteen-pivot experiment of
-// factor_m16.h (slower: see its header), for A/B measurements.
+// 128 points x 512 threads: rank-4 updates on the matrix pipe (factor_m.h) - the only variant the shipped library compiles.  The
+// A/B builds of tools/ (-DADKF_SWEEP_M=0: the VALU variant, -DADKF_SWEEP_M=0 -DADKF_SWEEP_W=0: the blocked sweep above at 128
+// points, -DADKF_SWEEP_M=2: the sixteen-pivot experiment, measured slower) take their sweeps from tools/variants/.
 #ifndef ADKF_SWEEP_M
 #define ADKF_SWEEP_M 1
 #endif
@@ -392,9 +392,9 @@ template <int NMAX, int NT> struct Sweep : SweepBlk<NMAX, NT> {};
 #define ADKF_SWEEP_W 1
 #endif
 #if ADKF_SWEEP_M == 2
-#include "factor_m16.h"
+#include "../../tools/variants/factor_m16.h"   // A/B experiment only (measured slower); not part of the shipped library
 #elif ADKF_SWEEP_M
 #include "factor_m.h"
 #elif ADKF_SWEEP_W
-#include "factor_w.h"
+#include "../../tools/variants/factor_w.h"     // A/B experiment only (the VALU sweep of round 2)
 #endif

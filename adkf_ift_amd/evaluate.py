@@ -11,6 +11,9 @@ Two entry points:
 * ``meta_test``           - every task of a ``MetaBatch`` at once: ONE feature-extractor forward (no grad), then
                             ``adkf_init_params -> adkf_fit -> adkf_predict`` on the whole batch (the fit's A^-1, alpha
                             are reused by the prediction).  No hypergradient is involved.
+* ``adapt_and_test``      - MoleculeNet's test protocol (MoleculeNet/chem_lib/models/adkfift_trainer.py:222-283): per test task,
+                            ``update_step_test`` hypergradient steps on the task's adaptation batches from the saved weights,
+                            then the final fit on the support set and the prediction of the query loader.
 """
 from __future__ import annotations
 
@@ -181,3 +184,44 @@ def evaluate_tasks(model, tasks: Sequence[DKTBatch], names: Optional[Sequence[st
             lab = task.query_numeric_labels if model.config.use_numeric_labels else task.query_labels
             out[names[lo + k]] = _score(model, preds[k, :nq], lab.detach().cpu().numpy())
     return out
+
+
+def adapt_and_test(model, optimizer, saved_state_dict, adapt_data, eval_data, update_step_test: int = 1, clip_value: float = 1.0):
+    """One test task of ``Meta_Trainer.test_step`` (MoleculeNet/chem_lib/models/adkfift_trainer.py:225-283) for an ``ADKFModel``.
+
+    ``adapt_data`` / ``eval_data``: dicts with ``s_data``, ``s_label`` and ``data_loader`` (an iterable of query batches with
+    ``.to(device)`` and ``.y``), as ``get_data_sample(task_id, train=False)`` builds them.  From ``saved_state_dict`` (:226), for the
+    first ``update_step_test`` batches of the adaptation loader (:229-271): re-initialise and fit the GP tail on the support set,
+    IFT hypergradient of the predictive loss of the batch (fused HIP path: ONE extractor backward), clip-by-global-norm
+    ``clip_value``, ``optimizer.step()``.  Then (:273-281) fit on the evaluation support set and return
+    ``(sigmoid(posterior mean), labels)`` over the evaluation loader, plus the per-step outer losses."""
+    from .hypergradient import cauchy_hypergradient
+    from .models import fit_gpytorch_scipy
+
+    model.load_state_dict(saved_state_dict)
+    dev = model.device
+    losses = []
+    if update_step_test > 0:
+        for i, batch in enumerate(adapt_data["data_loader"]):
+            optimizer.zero_grad()
+            batch = batch.to(dev) or batch          # torch_geometric's Batch.to returns the moved batch; stand-ins may move in place
+            model.train()
+            model(s_data=adapt_data["s_data"], q_data=None, s_label=adapt_data["s_label"], train_loss=True)      # a3/a4
+            fit_gpytorch_scipy(model.mll)                                                                         # a7
+            model.train()
+            f_outer, f_inner = model.task_losses((adapt_data["s_data"], batch, adapt_data["s_label"]))
+            loss = cauchy_hypergradient(f_outer, f_inner, tuple(model.feature_extractor_params()), tuple(model.gp_params()), dev,
+                                        ignore_grad_correction=False)                                             # a9
+            torch.nn.utils.clip_grad_norm_(model.feature_extractor_params(), clip_value)
+            optimizer.step()
+            losses.append(float(loss))
+            if i >= update_step_test - 1:
+                break
+    model.train()
+    model(s_data=eval_data["s_data"], q_data=None, s_label=eval_data["s_label"], train_loss=True)
+    fit_gpytorch_scipy(model.mll)
+    model.eval()
+    with torch.no_grad():
+        q_preds, q_labels = model.forward_query_loader(eval_data["s_data"], eval_data["data_loader"], train_loss=None,
+                                                       s_label=eval_data["s_label"])
+    return q_preds, q_labels, losses

@@ -210,9 +210,10 @@ def meta_features(model, mb: MetaBatch):
 
 
 def model_meta_step(model, optimizer, mb: MetaBatch, cfg=None, distributed: bool = False, check: bool = False,
-                    uneven_shards: bool = False):
+                    uneven_shards: bool = False, lr_scheduler=None):
     """The batched counterpart of one iteration of ``ADKTModelTrainer.train_loop``
-    (fs_mol/utils/adaptive_dkt_utils.py:352-413) for an ``ADKTModel``: returns per-task per-sample losses."""
+    (fs_mol/utils/adaptive_dkt_utils.py:352-413) for an ``ADKTModel``: returns per-task per-sample losses.
+    ``lr_scheduler`` (e.g. the warm-up of ``checkpoint.load_model_gnn_weights``) is stepped after the optimiser (:412-413)."""
     from .trainer import MetaStepConfig, meta_step
 
     if cfg is None:
@@ -221,5 +222,8 @@ def model_meta_step(model, optimizer, mb: MetaBatch, cfg=None, distributed: bool
                              use_lengthscale_prior=c.use_lengthscale_prior, ignore_grad_correction=c.ignore_grad_correction,
                              uneven_shards=uneven_shards)
     y_s, y_q = mb.labels(cfg.use_numeric_labels)
-    return meta_step(lambda: meta_features(model, mb), list(model.feature_extractor_params()), optimizer, y_s, y_q, cfg,
-                     n_s=mb.n_s, n_q=mb.n_q, distributed=distributed, check=check)
+    out = meta_step(lambda: meta_features(model, mb), list(model.feature_extractor_params()), optimizer, y_s, y_q, cfg,
+                    n_s=mb.n_s, n_q=mb.n_q, distributed=distributed, check=check)
+    if lr_scheduler is not None:
+        lr_scheduler.step()
+    return out

@@ -108,3 +108,49 @@ class LinearFeatureMap:
             sh = self.X.shape
             return _ChunkedLinear.apply(self.X.view(-1, sh[-1]), self.W, self.chunks).view(sh[0], sh[1], sh[2], -1)
         return (self.X_s @ self.W) * self.c, (self.X_q @ self.W) * self.c
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Synthetic MOLECULAR tasks (config C3 and the meta-test protocol): random graphs in the FSMolBatch layout
+# (fs_mol/data/fsmol_batcher.py:22-54: 32 node features, 3 edge types) + count fingerprints + descriptors.  FS-Mol itself is
+# not available offline; these have its shapes (15-35 heavy atoms, a backbone of single bonds plus a few other bonds).
+# ---------------------------------------------------------------------------------------------------------------------
+def random_molecules(n: int, gen: torch.Generator, nodes=(15, 35)):
+    from .meta_batch import MoleculeFeatures
+
+    sizes = torch.randint(nodes[0], nodes[1], (n,), generator=gen)
+    feats, n2g, adj = [], [], [[], [], []]
+    v0 = 0
+    for gi in range(n):
+        k = int(sizes[gi])
+        n2g += [gi] * k
+        adj[0].append(torch.stack([torch.arange(k - 1), torch.arange(1, k)], 1) + v0)          # a backbone of single bonds
+        for t in (1, 2):
+            e = int(torch.randint(0, 4, (1,), generator=gen))
+            if e:
+                adj[t].append(torch.randint(0, k, (e, 2), generator=gen) + v0)
+        v0 += k
+    feats = torch.randn(v0, 32, generator=gen)
+    adj = [torch.cat(a) if a else torch.zeros(0, 2, dtype=torch.long) for a in adj]
+    return MoleculeFeatures(feats, adj, torch.tensor(n2g), n, torch.poisson(torch.full((n, 2048), 0.03), generator=gen),
+                            torch.randn(n, 42, generator=gen))
+
+
+def molecular_task(support: int, query: int, gen: torch.Generator):
+    from .meta_batch import DKTBatch
+
+    s, q = random_molecules(support, gen), random_molecules(query, gen)
+    return DKTBatch(s, torch.rand(support, generator=gen) > 0.5, torch.randn(support, generator=gen),
+                    q, torch.rand(query, generator=gen) > 0.5, torch.randn(query, generator=gen))
+
+
+def meta_test_tasks(n_tasks: int = 157, support: int = 64, seed: int = 0):
+    """Tasks of the shape of the reference's only published wall-clock protocol (fs_mol/adaptive_dkt_walltime.py:100-115,
+    fs_mol/utils/test_utils.py:236-350: every FS-Mol test task - 157 - at support size 64, every remaining molecule as
+    query): query sizes from a seeded log-normal (median 200, clipped to [32, 2000] - FS-Mol test tasks are of this order)."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    sizes = np.clip(np.exp(rng.normal(np.log(200.0), 0.9, n_tasks)), 32, 2000).astype(int)
+    gen = torch.Generator().manual_seed(seed)
+    return [molecular_task(support, int(q), gen) for q in sizes], sizes

@@ -106,3 +106,101 @@ def test_loader_refuses_globals_a_checkpoint_has_no_reason_to_contain(tmp_path):
     torch.save({"model_config": Evil(), "model_state_dict": {}}, path)
     with pytest.raises(pickle.UnpicklingError):
         CK.load_reference_checkpoint(path)
+
+
+def _small_adkt():
+    from test_meta_batch import small_model
+
+    torch.manual_seed(11)
+    return ADKTModel(small_model())
+
+
+def test_linear_warmup_is_the_reference_schedule():
+    """fs_mol/models/abstract_torch_fsmol_model.py:169-172."""
+    assert CK.linear_warmup(0, 0) == 1.0 and CK.linear_warmup(5, 0) == 1.0
+    assert CK.linear_warmup(0, 100) == 0.0 and CK.linear_warmup(37, 100) == 0.37 and CK.linear_warmup(100, 100) == 1.0
+
+
+def test_gnn_warm_start_groups_and_warm_up(tmp_path):
+    """``load_model_gnn_weights`` (fs_mol/utils/adaptive_dkt_utils.py:261-303): the extractor (minus final_norm_layer) comes from a
+    pre-trained file that names it without the ``graph_feature_extractor.`` prefix, everything else keeps its initialisation; two
+    Adam groups (lr, lr / 10) and a 100-step linear warm-up of the loaded group only."""
+    model = _small_adkt()
+    gcfg = model.config.graph_feature_extractor_config
+    pre = GO.random_reference_state_dict(gcfg, seed=21, dtype=torch.float32)     # keys: graph_feature_extractor.*
+    generic = {k[len("graph_feature_extractor."):]: v for k, v in pre.items()}
+    generic = {("readout_layer" + k[len("readout"):] if k.startswith("readout.") else k): v for k, v in generic.items()}   # an older file's name
+    path = str(tmp_path / "pretrained_gnn.pt")
+    torch.save({"model_state_dict": generic}, path)
+    fc_before = [p.detach().clone() for p in model.fc.parameters()]
+    opt, sched = CK.load_model_gnn_weights(model, path, learning_rate=1e-3)
+    # weights: the extractor now equals the pre-trained one, the head is untouched
+    back = model.graph_feature_extractor.reference_state_dict("graph_feature_extractor.")
+    for k, v in pre.items():
+        assert torch.equal(back[k], v), k
+    for a, b in zip(fc_before, model.fc.parameters()):
+        assert torch.equal(a, b)
+    # groups
+    g_other, g_gnn = opt.param_groups
+    gnn_ids = {id(p) for p in model.graph_feature_extractor.parameters()}
+    assert {id(p) for p in g_gnn["params"]} == gnn_ids
+    assert {id(p) for p in g_other["params"]} == {id(p) for p in model.fc.parameters()}
+    assert g_other["initial_lr"] == 1e-3 and g_gnn["initial_lr"] == 1e-4
+    # schedule: the loaded group ramps 0 -> lr / 10 over 100 steps, the other group stays at lr (LambdaLR applies step 0 at once)
+    assert g_other["lr"] == 1e-3 and g_gnn["lr"] == 0.0
+    for _ in range(50):
+        opt.step()
+        sched.step()
+    assert g_other["lr"] == 1e-3 and abs(g_gnn["lr"] - 0.5e-4) < 1e-12
+    for _ in range(70):
+        opt.step()
+        sched.step()
+    assert abs(g_gnn["lr"] - 1e-4) < 1e-12
+
+
+def test_optimizer_state_restore_own_and_reference_layouts(tmp_path):
+    """``load_model_weights`` (adaptive_dkt_utils.py:240-258) restores the optimiser too.  (a) a file of this package: Adam's
+    moments come back bit for bit; (b) a state with the REFERENCE's layout - one slot per tower / edge-type Linear, in the order
+    of the reference's ``feature_extractor_params()`` - lands in the fused parameters' slots."""
+    model = _small_adkt()
+    params = list(model.feature_extractor_params())
+    opt = torch.optim.Adam(params, 1e-3)
+    g = torch.Generator().manual_seed(2)
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=g)
+    opt.step()
+    path = str(tmp_path / "own.pt")
+    CK.save_model(model, path, optimizer=opt, epoch=1)
+    model2 = _small_adkt()
+    opt2 = torch.optim.Adam(model2.feature_extractor_params(), 5e-2)
+    ck = CK.load_model_weights(model2, path, optimizer=opt2)
+    assert ck["epoch"] == 1 and opt2.param_groups[0]["lr"] == 1e-3
+    for p, q in zip(params, model2.feature_extractor_params()):
+        assert torch.equal(p, q)
+        assert torch.equal(opt.state[p]["exp_avg"], opt2.state[q]["exp_avg"]) and torch.equal(opt.state[p]["exp_avg_sq"], opt2.state[q]["exp_avg_sq"])
+    # (b) the reference's layout, built from the reference-named state dict of the same model
+    ref_sd = CK.reference_state_dict(model)
+    names = CK._reference_param_names(ref_sd)
+    assert len(names) > len(params)                      # per-tower layers: more slots than fused parameters
+    state = {i: {"step": torch.tensor(3.0), "exp_avg": torch.randn(ref_sd[n].shape, generator=g),
+                 "exp_avg_sq": torch.rand(ref_sd[n].shape, generator=g)} for i, n in enumerate(names)}
+    ref_opt_sd = {"state": state, "param_groups": [{"lr": 2e-4, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                                                   "params": list(range(len(names)))}]}
+    path_b = str(tmp_path / "ref_layout.pt")
+    torch.save({"model_config": CK.config_dict(model.config), "model_state_dict": ref_sd, "optimizer_state_dict": ref_opt_sd}, path_b)
+    model3 = _small_adkt()
+    opt3 = torch.optim.Adam(model3.feature_extractor_params(), 1e-1)
+    CK.load_model_weights(model3, path_b, optimizer=opt3)
+    assert opt3.param_groups[0]["lr"] == 2e-4
+    by_name = dict(model3.named_parameters())
+    # tower 2 of edge type 1 in block 0: reference Linear weight [out, in] -> slice [2] of the fused [H, in, out] tensor, transposed
+    ref_name = "graph_feature_extractor.gnn.gnn_blocks.0.mp_layers.2.message_fns.1._layers.0.weight"
+    fused = by_name["graph_feature_extractor.gnn.gnn_blocks.0.mp.weights.1"]
+    assert torch.equal(opt3.state[fused]["exp_avg"][2], state[names.index(ref_name)]["exp_avg"].t())
+    assert torch.equal(opt3.state[fused]["exp_avg_sq"][2], state[names.index(ref_name)]["exp_avg_sq"].t())
+    assert float(opt3.state[fused]["step"]) == 3.0
+    w = by_name["fc.0.weight"]
+    assert torch.equal(opt3.state[w]["exp_avg"], state[names.index("fc.0.weight")]["exp_avg"])
+    for p in model3.feature_extractor_params():          # every trainable tensor has its moments
+        assert p in opt3.state and opt3.state[p]["exp_avg"].shape == p.shape
+    opt3.step() if all(p.grad is not None for p in model3.feature_extractor_params()) else None

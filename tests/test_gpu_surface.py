@@ -293,6 +293,90 @@ def test_moleculenet_adkf_model_fused_hypergradient(dev):
     assert probs.shape == (32,) and labels.shape == (32,) and ((probs > 0) & (probs < 1)).all()
 
 
+def test_moleculenet_test_time_adaptation_vs_per_step_oracle(dev):
+    """MoleculeNet/chem_lib/models/adkfift_trainer.py:225-283 (``update_step_test`` hypergradient steps per test task before the
+    final fit) through ``evaluate.adapt_and_test``, against the per-step float64 oracle loop evaluated AT THE DEVICE'S fitted phi:
+    step k: theta_k -> (device: reinit, fit -> phi_k) -> oracle dense IFT hypergradient at (theta_k^oracle, phi_k) -> clip 1.0 ->
+    SGD step; finally the oracle's predictive mean at the device's last phi."""
+    from types import SimpleNamespace
+    from adkf_ift_amd import evaluate as E
+    from adkf_ift_amd.models import ADKFModel
+    from oracle import gp_oracle as O
+    from oracle.hypergrad_oracle import dense_ift_hypergradient
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1, self.l2 = torch.nn.Linear(10, 16), torch.nn.Linear(16, 6)
+        def forward(self, x, edge_index, edge_attr, batch):
+            return self.l2(torch.tanh(self.l1(x))), None
+
+    torch.manual_seed(8)
+    g = torch.Generator().manual_seed(8)
+    def data(n):
+        d = SimpleNamespace(x=torch.randn(n, 10, generator=g).to(dev), edge_index=None, edge_attr=None, batch=None,
+                            y=(torch.rand(n, generator=g) > 0.5).to(dev))
+        d.to = lambda device: d
+        return d
+    s_data = data(20)
+    adapt_loader = [data(24), data(16), data(32)]        # the third batch must not be used (update_step_test = 2)
+    eval_loader = [data(12), data(9)]
+    model = ADKFModel(Enc(), 6, "matern").to(dev)
+    saved = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    lr = 0.05
+    opt = torch.optim.SGD(model.feature_extractor_params(), lr=lr)
+    # record the phi the device fits in every adaptation step (the oracle is evaluated there) through the public surface
+    phis = []
+    from adkf_ift_amd import models as M
+    orig_fit = M.fit_gpytorch_scipy
+    def spy(mll, *a, **k):
+        out = orig_fit(mll, *a, **k)
+        phis.append(torch.cat([p.detach().reshape(-1) for p in mll.raw_params()]).double().cpu())
+        return out
+    M.fit_gpytorch_scipy = spy
+    try:
+        adapt = {"s_data": s_data, "s_label": s_data.y, "data_loader": adapt_loader}
+        evald = {"s_data": s_data, "s_label": s_data.y, "data_loader": eval_loader}
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)                               # must be undone by load_state_dict(saved_state_dict) (:226)
+        preds, labels, losses = E.adapt_and_test(model, opt, saved, adapt, evald, update_step_test=2)
+    finally:
+        M.fit_gpytorch_scipy = orig_fit
+    assert len(phis) == 3 and len(losses) == 2            # two adaptation fits + the final one
+    assert preds.shape == (21,) and labels.shape == (21,)
+    # ---- oracle loop (float64, CPU) ----
+    enc64 = Enc().double()
+    enc64.load_state_dict({k[len("mol_encoder."):]: v.double().cpu() for k, v in saved.items() if k.startswith("mol_encoder.")})
+    names = [n for n, _ in enc64.named_parameters()]
+    from torch.func import functional_call as fc
+    feats = lambda p, X: fc(enc64, dict(zip(names, p)), (X, None, None, None))[0]
+    Xs, ys = s_data.x.double().cpu(), (s_data.y.double().cpu() - 0.5) * 2
+    theta = [p.detach().clone() for p in enc64.parameters()]
+    for k in range(2):
+        Xq, yq = adapt_loader[k].x.double().cpu(), (adapt_loader[k].y.double().cpu() - 0.5) * 2
+        with torch.no_grad():
+            _, pri = O.init_phi(feats(tuple(theta), Xs), False, True)
+        fin = lambda p, q: O.f_inner(feats(p, Xs), ys, torch.cat([t.reshape(-1) for t in q]), pri, 1)
+        fout = lambda p, q: O.f_outer(feats(p, Xs), ys, feats(p, Xq), yq, torch.cat([t.reshape(-1) for t in q]), 1)
+        p64 = tuple(t.clone().requires_grad_() for t in theta)
+        q64 = (phis[k][0:1].clone().requires_grad_(), phis[k][1].clone().requires_grad_(), phis[k][2:3].reshape(1, 1).clone().requires_grad_())
+        val = dense_ift_hypergradient(fout, fin, p64, q64)
+        assert abs(losses[k] - val.item()) <= 2e-4 * abs(val.item()), (k, losses[k], val.item())
+        total = torch.sqrt(sum((q.grad ** 2).sum() for q in p64))
+        coef = min(1.0, 1.0 / (float(total) + 1e-6))      # torch.nn.utils.clip_grad_norm_(..., 1.0)
+        theta = [t - lr * coef * q.grad for t, q in zip(theta, p64)]
+    scale = max(float((t - s.double().cpu()).abs().max()) for t, s in zip(theta, (saved["mol_encoder." + n] for n in names)))
+    assert scale > 0.0
+    for t, n in zip(theta, names):                         # the adapted weights: 2e-4 of the largest movement
+        got = dict(model.mol_encoder.named_parameters())[n].detach().double().cpu()
+        assert float((got - t).abs().max()) <= 2e-4 * scale, n
+    with torch.no_grad():
+        Zs = feats(tuple(theta), Xs)
+        want = torch.cat([torch.sigmoid(O.predict(Zs, ys, feats(tuple(theta), q.x.double().cpu()), phis[2], 1)[0]) for q in eval_loader])
+    assert float((preds.double().cpu() - want).abs().max()) <= 2e-4
+
+
 def test_bayes_opt_gp_ei_loop(dev):
     """bayes_opt/bo_utils.py create_gp + EI: the fitted GP's latent posterior and EI values against the oracle, and
     a short BO run on a toy objective whose minimiser must be found."""

@@ -11,23 +11,7 @@ from adkf_ift_amd.models import ADKTModel, ADKTModelConfig
 from adkf_ift_amd.trainer import MetaStepConfig
 
 
-def random_molecules(n, gen, nodes=(15, 35)):
-    feats, n2g, adj = [], [], [[], [], []]
-    v0 = 0
-    for gi in range(n):
-        k = int(torch.randint(nodes[0], nodes[1], (1,), generator=gen))
-        feats.append(torch.randn(k, 32, generator=gen))
-        n2g += [gi] * k
-        chain = torch.stack([torch.arange(k - 1), torch.arange(1, k)], 1) + v0          # a backbone of single bonds
-        adj[0].append(chain)
-        for t in (1, 2):
-            e = int(torch.randint(0, 4, (1,), generator=gen))
-            if e:
-                adj[t].append(torch.randint(0, k, (e, 2), generator=gen) + v0)
-        v0 += k
-    adj = [torch.cat(a) if a else torch.zeros(0, 2, dtype=torch.long) for a in adj]
-    return MoleculeFeatures(torch.cat(feats), adj, torch.tensor(n2g), n, torch.poisson(torch.full((n, 2048), 0.03), generator=gen),
-                            torch.randn(n, 42, generator=gen))
+from adkf_ift_amd.synthetic import random_molecules  # noqa: E402,F401  (kept importable from here: tools/determinism_probe.py)
 
 
 def main():

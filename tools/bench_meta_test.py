@@ -13,7 +13,6 @@ import torch
 from adkf_ift_amd import evaluate as E
 from adkf_ift_amd.meta_batch import DKTBatch
 from adkf_ift_amd.models import ADKTModel, ADKTModelConfig
-from bench_c3 import random_molecules
 
 
 def main():
@@ -23,16 +22,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=16, help="tasks per library call / extractor forward")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    gen = torch.Generator().manual_seed(0)
-    rng = np.random.default_rng(0)
-    sizes = np.clip(np.exp(rng.normal(np.log(200.0), 0.9, a.tasks)), 32, 2000).astype(int)
+    from adkf_ift_amd.synthetic import meta_test_tasks
     t0 = time.perf_counter()
-    tasks = []
-    for q in sizes:
-        q = int(q)
-        s_, q_ = random_molecules(a.support, gen), random_molecules(q, gen)
-        tasks.append(DKTBatch(s_, torch.rand(a.support, generator=gen) > 0.5, torch.randn(a.support, generator=gen),
-                              q_, torch.rand(q, generator=gen) > 0.5, torch.randn(q, generator=gen)))
+    tasks, sizes = meta_test_tasks(a.tasks, a.support)
     t_gen = time.perf_counter() - t0
     model = ADKTModel(ADKTModelConfig()).to(dev)
     E.evaluate_tasks(model, tasks[:4], tasks_per_call=4)   # warm-up (first-touch of the library and the allocator)
