@@ -10,6 +10,7 @@
 #include "readout.h"
 #include "outer_step.h"
 #include "refine64.h"
+#include "hyper.h"
 
 using namespace adkf;
 
@@ -294,6 +295,17 @@ int launch_inner(InnerArgs a, const Workspace& w, hipStream_t st) {
     return 0;
 }
 
+// ADKF_R64_THRESHOLD (read once) moves the switch-over for experiments: 0 sends every task through float64, a huge value none
+float r64_threshold() {
+    static const float thresh = [] {
+        const char* e = getenv("ADKF_R64_THRESHOLD");
+        return e ? (float)atof(e) : R64_THRESHOLD;
+    }();
+    return thresh;
+}
+
+// Ill-conditioned tasks redo the factorisation-type stages in float64 (refine64.h); everybody else leaves the kernel after
+// reading two scalars.  level: 0 = inner quantities (A^-1, alpha, scalars), 1 = + C, mu (prediction), 2 = + S^-1, e, f_out.
 // (s + noise) max_i (A^-1)_ii above which C and alpha get one step of float32 iterative refinement (ADKF_REFINE32_THRESHOLD moves it)
 float refine32_threshold() {
     static const float thresh = [] {
@@ -319,36 +331,53 @@ void launch_c(const TaskView& tv, const adkf_batch_t* b, const Workspace& w, hip
     launch_gemm(pf, T, nq, ns, st);
 }
 
-// ADKF_R64_THRESHOLD (read once) moves the switch-over for experiments: 0 sends every task through float64, a huge value none
-float r64_threshold() {
-    static const float thresh = [] {
-        const char* e = getenv("ADKF_R64_THRESHOLD");
-        return e ? (float)atof(e) : R64_THRESHOLD;
+bool refine64_lds_optin() {
+    // up to R64_LDS_POINTS points the float64 inverses run in LDS: 128 KB of dynamic shared memory (one workgroup per CU then; the
+    // kernels are a two-scalar test for everybody but the flagged tasks).  Without the opt-in the inverses work in global memory.
+    static const bool ok = [] {
+        const int bytes = (int)(sizeof(double) * R64_LDS_POINTS * R64_LDS_POINTS);
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_refine64), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail64), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();
-    return thresh;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+
+Refine64Args refine_args(const TaskView& tv, const adkf_batch_t* b, const Workspace& w, bool with_hessian, int level, float* f_out,
+                         int32_t* info, float* f_in, float* g_in, float* gnorm, size_t& lds_bytes) {
+    const bool lds_inv = refine64_lds_optin();   // (beyond R64_LDS_POINTS the diagonal blocks of the blocked inverse live there)
+    const size_t lds_pts = w.vld <= R64_LDS_POINTS ? (size_t)w.vld : (size_t)R64_LDS_POINTS;
+    lds_bytes = lds_inv ? sizeof(double) * lds_pts * lds_pts : 0;
+    return Refine64Args{tv, b->Z_s, b->Z_q, b->d, b->y_s, b->y_q, b->priors, w.Ainv, with_hessian ? w.P : nullptr, level >= 1 ? w.C : nullptr,
+                        level >= 2 ? w.S : nullptr, w.vecs, w.scal, f_out, info, f_in, g_in, gnorm, w.w64, w.w64_stride, r64_threshold(), b->T,
+                        with_hessian ? 1 : 0, level, lds_inv ? 1 : 0};
 }
 
 // Ill-conditioned tasks redo the factorisation-type stages in float64 (refine64.h); everybody else leaves the kernel after
-// reading two scalars.  level: 0 = inner quantities (A^-1, alpha, scalars), 1 = + C, mu (prediction), 2 = + S^-1, e, f_out.
+// reading two scalars.  level: 0 = inner quantities (A^-1, alpha, scalars), 1 = + C, mu (prediction).  (Level 2 - + S^-1, e, f_out -
+// runs inside k_tail64 at the end of the hypergradient pipeline.)
 void launch_refine(const TaskView& tv, const adkf_batch_t* b, const Workspace& w, bool with_hessian, int level, float* f_out,
                    int32_t* info, hipStream_t st, float* f_in = nullptr, float* g_in = nullptr, float* gnorm = nullptr) {
     if (!w.w64) return;
-    const float thresh = r64_threshold();
-    // up to R64_LDS_POINTS points the float64 inverses run in LDS: 128 KB of dynamic shared memory (one workgroup per CU then; the
-    // kernel is a two-scalar test for everybody but the flagged tasks)
-    const bool lds_inv = true;   // (beyond R64_LDS_POINTS the diagonal blocks of the blocked inverse live there)
-    const size_t lds_pts = w.vld <= R64_LDS_POINTS ? (size_t)w.vld : (size_t)R64_LDS_POINTS;
-    const size_t lds_bytes = sizeof(double) * lds_pts * lds_pts;
-    static const bool attr_set = [] {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_refine64), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(double) * R64_LDS_POINTS * R64_LDS_POINTS));
-        return true;
-    }();
-    (void)attr_set;
-    Refine64Args ra{tv, b->Z_s, b->Z_q, b->d, b->y_s, b->y_q, b->priors, w.Ainv, with_hessian ? w.P : nullptr, level >= 1 ? w.C : nullptr,
-                    level >= 2 ? w.S : nullptr, w.vecs, w.scal, f_out, info, f_in, g_in, gnorm, w.w64, w.w64_stride, thresh, b->T, with_hessian ? 1 : 0, level,
-                    lds_inv ? 1 : 0};
+    size_t lds_bytes;
+    const Refine64Args ra = refine_args(tv, b, w, with_hessian, level, f_out, info, f_in, g_in, gnorm, lds_bytes);
     k_refine64<<<b->T, R64_NT, lds_bytes, st>>>(ra);
+}
+
+// 64 < max(support, query) <= 128: the outer / hypergradient stage of a task runs as ONE workgroup (hyper.h).  ADKF_FUSED_OUTER=0
+// (read once) keeps the sixteen-launch pipeline for A/B measurements.
+bool use_fused_outer(int ns, int nq) {
+    static const bool enabled = [] { const char* e = getenv("ADKF_FUSED_OUTER"); return !e || atoi(e) != 0; }();
+    static const bool optin = [] {
+        bool ok = true;
+        for (const void* f : {reinterpret_cast<const void*>(&k_hyper<true, 0>), reinterpret_cast<const void*>(&k_hyper<true, 1>),
+                              reinterpret_cast<const void*>(&k_hyper<false, 0>), reinterpret_cast<const void*>(&k_hyper<false, 1>)})
+            ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HY_LDS_BYTES) == hipSuccess;
+        return ok;
+    }();
+    if (!optin) (void)hipGetLastError();
+    const int hi = ns > nq ? ns : nq;
+    return enabled && optin && hi > 64 && hi <= HY_N;
 }
 
 int launch_outer_factor(const OuterArgs& a, const Workspace& w, int nq, hipStream_t st) {
@@ -399,10 +428,22 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         if (rc) return rc;
     }
     TaskView tv = make_tv(b, w, true);
-    launch_alpha_refine(tv, b, w, st);
     const int tms = ceil_div(ns, GT), tmq = ceil_div(nq, GT);
     const float dirscale = (flags & ADKF_IGNORE_DIRECT_GRAD) ? 0.f : 1.f;
     const float corrscale = (with_hessian && !(flags & ADKF_IGNORE_GRAD_CORRECTION)) ? 1.f : 0.f;
+    if (use_fused_outer(ns, nq)) {
+        // (reused inner stage: A^-1, alpha and the scalars of phi are in the workspace, info[] is written by this kernel)
+        HyperArgs ha{tv, w.Ainv, w.D2ss, w.D2qs, w.D2qq, b->y_s, b->y_q, b->priors, w.Wss, w.Wqs, w.Wqq, w.P, w.OC, w.S, w.vecs, w.scal, f_out, info,
+                     g_phi_out, v_out, H_out, T, reuse_inner ? 1 : 0, with_hessian ? 1 : 0, flags, dirscale, corrscale, refine32_threshold()};
+        // FULL: every task has exactly 128 support and 128 query points in 16-byte aligned rows (affine addresses, no clamps)
+        const bool full = ns == HY_N && nq == HY_N && !b->n_s && !b->n_q && tv.vec;
+        const bool rbf = b->kernel == ADKF_KERNEL_RBF;
+        if (full && rbf) k_hyper<true, 0><<<grid_for(T, 1), HY_NT, HY_LDS_BYTES, st>>>(ha);
+        else if (full) k_hyper<true, 1><<<grid_for(T, 1), HY_NT, HY_LDS_BYTES, st>>>(ha);
+        else if (rbf) k_hyper<false, 0><<<grid_for(T, 1), HY_NT, HY_LDS_BYTES, st>>>(ha);
+        else k_hyper<false, 1><<<grid_for(T, 1), HY_NT, HY_LDS_BYTES, st>>>(ha);
+    } else {
+    launch_alpha_refine(tv, b, w, st);
     if (with_hessian) {
         ProbP pp; pp.tv = tv; pp.Ainv = w.Ainv; pp.D2ss = w.D2ss; pp.P = w.P;
         launch_gemm(pp, T, ns, ns, st);
@@ -426,7 +467,6 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
     OuterArgs oa{tv, w.C, w.S, b->y_s, b->y_q, w.vecs, w.scal, f_out, info, T, reuse_inner ? 1 : 0};
     rc = launch_outer_factor(oa, w, nq, st);
     if (rc) return rc;
-    launch_refine(tv, b, w, with_hessian, 2, f_out, info, st);
     ProbOC po; po.tv = tv; po.Sinv = w.S; po.C = w.C; po.D2qs = w.D2qs; po.OC = w.OC; po.Wqs = w.Wqs; po.part = w.part_oc; po.ntiles = w.nt_oc; po.dirscale = dirscale;
     launch_gemm(po, T, nq, ns, st);
     ProbMA pm; pm.tv = tv; pm.C = w.C; pm.OC = w.OC; pm.D2ss = w.D2ss; pm.Wss = w.Wss; pm.part = w.part_ma; pm.ntiles = w.nt_ma; pm.dirscale = dirscale;
@@ -446,6 +486,7 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         ProbMixed px; px.tv = tv; px.Ainv = w.Ainv; px.P = w.P; px.D2ss = w.D2ss; px.Wss = w.Wss; px.corrscale = corrscale;
         launch_gemm(px, T, ns, ns, st);
     }
+    }
     if (dZ_s || dZ_q) {
         if (dZ_s && b->n_s) hipMemsetAsync(dZ_s, 0, (size_t)T * ns * d * sizeof(float), st);   // padded rows only exist in ragged batches
         if (dZ_q && b->n_q) hipMemsetAsync(dZ_q, 0, (size_t)T * nq * d * sizeof(float), st);
@@ -456,10 +497,14 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         if (dZ_s) launch_gemm(pzs, T, ns, d, st);
         if (dZ_q) launch_gemm(pzq, T, nq, d, st);
     }
-    if (w.w64) {   // flagged (ill-conditioned) tasks: the cotangent algebra and dL/dZ once more, in float64, over what the kernels above wrote
+    if (w.w64) {
+        // flagged (ill-conditioned) tasks, ONE launch at the very end: the factorisation-type stages (A^-1, alpha, P, the Hessian, C,
+        // Sigma_q^-1, e, f_out) and then the cotangent algebra and dL/dZ, in float64, over what the kernels above wrote for them
+        size_t lds_bytes;
+        const Refine64Args ra = refine_args(tv, b, w, with_hessian, 2, f_out, info, nullptr, nullptr, nullptr, lds_bytes);
         Cot64Args ca{tv, b->Z_s, b->Z_q, dZ_s, dZ_q, d, w.vecs, w.scal, w.w64, w.w64_stride, r64_threshold(), T,
-                     with_hessian ? 1 : 0, flags, dirscale, corrscale, g_phi_out, v_out};
-        k_cotangent64<<<T, R64_NT, 0, st>>>(ca);
+                     with_hessian ? 1 : 0, flags, dirscale, corrscale, g_phi_out, v_out, H_out};
+        k_tail64<<<T, R64_NT, lds_bytes, st>>>(ra, ca);
     }
     LAUNCH_OK();
     return 0;
@@ -850,7 +895,8 @@ int adkf_fit(const adkf_batch_t* b, float* phi, const adkf_fit_options_t* opt, f
     rc = launch_inner(ia, w, st);
     if (opt->ev_stop && hipEventRecord(static_cast<hipEvent_t>(opt->ev_stop), st) != hipSuccess) return ADKF_E_LAUNCH;
     if (rc) return rc;
-    launch_refine(make_tv(b, w, false), b, w, false, 0, nullptr, info, st, f_final, nullptr, gnorm);   // ill-conditioned tasks: float64 value at phi*
+    // ill-conditioned tasks: float64 value at phi* - unless the caller says that the next call on this workspace redoes it anyway
+    if (!(b->flags & ADKF_BATCH_DEFER_REFINE)) launch_refine(make_tv(b, w, false), b, w, false, 0, nullptr, info, st, f_final, nullptr, gnorm);
     LAUNCH_OK();
     return 0;
 }

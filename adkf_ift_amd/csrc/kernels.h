@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NT) void k_median(const float* D2ss, const int32_t*
 }
 
 #if ADKF_STAMP_SMALL   // tools/small_bench.hip: s_memtime of the phases of the per-task kernels (workgroup 3, thread 0)
-__device__ unsigned long long g_small_stamps[16];
+__device__ unsigned long long g_small_stamps[32];
 #define ADKF_SST(k_) do { if (blockIdx.x == 3 && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_small_stamps[k_] = t_; } } while (0)
 #else
 #define ADKF_SST(k_) do {} while (0)

@@ -247,10 +247,12 @@ __global__ void k_double_path_tasks(const float* scal, int ld, int ldq, float th
     flagged[t] = (ra > thresh || rs > thresh) ? 1 : 0;
 }
 
-__global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
+extern __shared__ double r64_lds[];                     // R64_LDS_POINTS^2 doubles when the batch has at most that many points, else nothing
+
+// The body of k_refine64 for the task of this workgroup (all threads call; returns early - uniformly - for unflagged tasks).
+__device__ __forceinline__ void refine64_task(const Refine64Args& a) {
     __shared__ double red[R64_NT / 64];
     __shared__ double gjc[R64_MAXN], gjr[R64_MAXN];   // pivot column / scaled pivot row of r64_inverse
-    extern __shared__ double r64_lds[];                 // R64_LDS_POINTS^2 doubles when the batch has at most that many points, else nothing
     const int t = blockIdx.x, tid = threadIdx.x;
     if (t >= a.T) return;
     const int n = a.tv.ns(t), m = a.want_outer ? a.tv.nq(t) : 0, ld = a.tv.ns_ld, ldq = a.tv.nq_ld, vld = a.tv.vld;
@@ -452,6 +454,8 @@ __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
     }
 }
 
+__global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) { refine64_task(a); }
+
 // k_cotangent64: the cotangent stage of the SAME flagged tasks, after the float32 kernels have written theirs.
 //
 // With A^-1, C, Sigma_q^-1 and e computed in float64 the remaining error of flagged tasks (cond 2e3 .. 5e3) sat in the float32
@@ -468,9 +472,10 @@ __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) {
 struct Cot64Args {
     TaskView tv; const float *Zs, *Zq; float *dZs, *dZq; int d; float* vecs; float* scal;
     double* w64; size_t w64_stride; float thresh; int T, with_hessian, flags; float dirscale, corrscale; float *g_phi_out, *v_out;
+    float* H_out;   // [T, 9] or null: the float64 path's Hessian (k_refine64 leaves it in the scalars) for the caller
 };
 
-__global__ __launch_bounds__(R64_NT) void k_cotangent64(Cot64Args a) {
+__device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
     __shared__ double red[R64_NT / 64];
     __shared__ double coef[4];
     const int t = blockIdx.x, tid = threadIdx.x;
@@ -564,6 +569,7 @@ __global__ __launch_bounds__(R64_NT) void k_cotangent64(Cot64Args a) {
         for (int q = 0; q < 3; ++q) { sc[S_GOUT0 + q] = (float)g[q]; sc[S_V0 + q] = (float)vd[q]; }
         if (a.g_phi_out) for (int q = 0; q < 3; ++q) a.g_phi_out[t * 3 + q] = (float)g[q];
         if (a.v_out) for (int q = 0; q < 3; ++q) a.v_out[t * 3 + q] = (float)vd[q];
+        if (a.H_out && a.with_hessian) for (int q = 0; q < 9; ++q) a.H_out[t * 9 + q] = sc[S_H0 + q];
         coef[0] = vd[0] * d1[0]; coef[1] = vd[1] * d1[1] / os; coef[2] = vd[2] * d1[2];
         sc[S_CN] = (float)coef[0]; sc[S_CS] = (float)coef[1]; sc[S_CL] = (float)coef[2];
     }
@@ -628,6 +634,16 @@ __global__ __launch_bounds__(R64_NT) void k_cotangent64(Cot64Args a) {
                [=](int k, int c) { return k < n ? (double)Zs[(size_t)k * d + c] : (double)Zq[(size_t)(k - n) * d + c]; },
                [=](int i, int c, double v) { out[(size_t)i * d + c] = (float)((2.0 * rs_qs_row[i] + 4.0 * rs_qq[i]) * (double)Zq[(size_t)i * d + c] - v); });
     }
+}
+
+// The float64 path of the hypergradient call as ONE launch at the very end of the pipeline (round 4; it used to be k_refine64 in
+// the middle - its float32 roundings fed the float32 cotangent kernels of the flagged tasks - and k_cotangent64 at the end, which
+// overwrote what those kernels had produced for exactly these tasks: dead work and a second launch that every unflagged batch
+// paid ~5 us for).  Everybody else leaves after the flag test, once.
+__global__ __launch_bounds__(R64_NT) void k_tail64(Refine64Args ra, Cot64Args ca) {
+    refine64_task(ra);
+    __syncthreads();
+    cotangent64_task(ca);
 }
 
 }  // namespace adkf

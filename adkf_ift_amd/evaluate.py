@@ -155,7 +155,7 @@ def meta_test(model, mb: MetaBatch, max_evals: int = 200, gtol: float = 1e-5, ft
     b = gp_ops.GPBatch(Z_s.float().contiguous(), y_s.to(dev).float().contiguous(), priors, cfg.gp_kernel,
                        Z_q=Z_q.float().contiguous(), n_s=mb.n_s, n_q=mb.n_q, ard=cfg.use_ard)
     phi0, _ = gp_ops.init_params_batch(b, cfg.use_numeric_labels, cfg.use_lengthscale_prior)
-    b.flags = gp_ops.REUSE_DIST
+    b.flags = gp_ops.REUSE_DIST | gp_ops.DEFER_REFINE     # (the prediction redoes ill-conditioned tasks in float64 itself)
     phi, _, _, n_evals, info = gp_ops.fit(b, phi0, max_evals, gtol, ftol)
     gp_ops.check_info(info, "meta-test inner fit")
     b.flags = gp_ops.REUSE_DIST | gp_ops.REUSE_INNER

@@ -49,7 +49,8 @@ class HipGPBackend:
         priors = torch.empty(Z_s.shape[0], 4, dtype=torch.float32, device=Z_s.device)
         b = gp_ops.GPBatch(Z_s, y_s, priors, cfg.gp_kernel, Z_q=Z_q, y_q=y_q, n_s=n_s, n_q=n_q, ard=cfg.use_ard)
         phi0, _ = gp_ops.init_params_batch(b, cfg.use_numeric_labels, cfg.use_lengthscale_prior)
-        b.flags = gp_ops.REUSE_DIST
+        # (the hypergradient call below redoes ill-conditioned tasks in float64 itself: the fit need not)
+        b.flags = gp_ops.REUSE_DIST | gp_ops.DEFER_REFINE
         phi, f_in, gnorm, nev, info_fit = gp_ops.fit(b, phi0, cfg.inner_max_evals, cfg.inner_gtol, cfg.inner_ftol,
                                                      cfg.inner_exact_evals, events=fit_events, inplace=True)
         b.flags = gp_ops.REUSE_DIST | gp_ops.REUSE_INNER

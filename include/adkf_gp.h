@@ -56,6 +56,11 @@ extern "C" {
 #define ADKF_BATCH_REUSE_INNER 2 /* A^-1, alpha and the scalars of exactly this phi are in the workspace (adkf_fit
                                     leaves them for its result; adkf_mll_value_grad for its argument) */
 
+#define ADKF_BATCH_DEFER_REFINE 8 /* adkf_fit only: skip the float64 re-evaluation of ill-conditioned tasks at phi* (csrc/refine64.h) - the
+                                    caller goes on to adkf_ift_hypergrad / adkf_outer_nll_value_grad / adkf_predict with REUSE_INNER on
+                                    this workspace, which redo those tasks in float64 themselves; f_final / gnorm of such tasks are
+                                    then the float32 values */
+
 /* ARD kernel (``use_ard``: fs_mol/models/adaptive_dkt.py:107-108 -> gpytorch ``ard_num_dims``): one lengthscale per
  * feature dimension.  With this flag EVERY phi / g_phi / v argument has h = 2 + d entries per task, laid out
  * (raw_noise, raw_outputscale, raw_lengthscale[0..d)); priors stay [T,4] (the lengthscale prior applies to each
