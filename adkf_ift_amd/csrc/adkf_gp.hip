@@ -11,6 +11,9 @@
 #include "outer_step.h"
 #include "refine64.h"
 #include "hyper.h"
+#if ADKF_VARIANT_DZ   // A/B experiment only (measured slower than the two ProbDZ launches: see its header)
+#include "../../tools/variants/dz.h"
+#endif
 
 using namespace adkf;
 
@@ -494,8 +497,18 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         ProbDZ<true> pzq; pzq.tv = tv; pzq.Wss = w.Wss; pzq.Wqs = w.Wqs; pzq.Wqq = w.Wqq; pzq.Zs = b->Z_s; pzq.Zq = b->Z_q; pzq.dZ = dZ_q; pzq.d = d;
         // (both cotangents in ONE launch through gemm.h's select() hook, with the two functors behind a run-time switch, was
         // measured at 139.8 us against 62.6 + 56.4 for the two launches: dropped)
-        if (dZ_s) launch_gemm(pzs, T, ns, d, st);
-        if (dZ_q) launch_gemm(pzq, T, nq, d, st);
+#if ADKF_VARIANT_DZ
+        static const bool dz_optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dz), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         (int)DZ_LDS_BYTES) == hipSuccess;
+        if (dz_optin && ns == HY_N && nq == HY_N && !b->n_s && !b->n_q && tv.vec && (d % HY_N) == 0) {
+            DzArgs da{w.Wss, w.Wqs, w.Wqq, b->Z_s, b->Z_q, dZ_s, dZ_q, d, T};
+            k_dz<<<grid_for(T, 1), HY_NT, DZ_LDS_BYTES, st>>>(da);
+        } else
+#endif
+        {
+            if (dZ_s) launch_gemm(pzs, T, ns, d, st);
+            if (dZ_q) launch_gemm(pzq, T, nq, d, st);
+        }
     }
     if (w.w64) {
         // flagged (ill-conditioned) tasks, ONE launch at the very end: the factorisation-type stages (A^-1, alpha, P, the Hessian, C,

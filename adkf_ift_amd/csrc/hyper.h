@@ -187,22 +187,33 @@ struct HyFrag {
     }
 };
 
-template <bool A_MN, bool B_MN>
+// DB: the fragments of block kb + 1 are fetched before the 32 MFMAs of block kb issue (72 registers of fragments); DB = false
+// (k_dz: four accumulator sets) fetches and multiplies in turn - the SIMD's other wave covers the LDS latency.
+template <bool A_MN, bool B_MN, bool DB = true>
 __device__ __forceinline__ void hy_gemm(f32x4_t (&acc)[8], const float* A, int lda, const float* B, int ldb, int kblocks) {
     const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
     const float* ap = A_MN ? A + (4 * g) * lda + 16 * w + p : A + (16 * w + p) * lda + 4 * g;
     const float* bp = B_MN ? B + (4 * g) * ldb + p : B + p * ldb + 4 * g;
-    HyFrag<A_MN, B_MN> f0, f1;
-    f0.fetch(ap, lda, bp, ldb, 0);
-    int kb = 0;
+    if constexpr (!DB) {
+#pragma unroll 1
+        for (int kb = 0; kb < kblocks; ++kb) {
+            HyFrag<A_MN, B_MN> f;
+            f.fetch(ap, lda, bp, ldb, kb);
+            f.multiply(acc);
+        }
+    } else {
+        HyFrag<A_MN, B_MN> f0, f1;
+        f0.fetch(ap, lda, bp, ldb, 0);
+        int kb = 0;
 #pragma unroll 1   // (fully unrolled - FULL has a constant trip count - hipcc hoists the fragment reads of all blocks and spills 390 registers)
-    for (; kb + 2 <= kblocks; kb += 2) {
-        f1.fetch(ap, lda, bp, ldb, kb + 1);
-        f0.multiply(acc);
-        if (kb + 2 < kblocks) f0.fetch(ap, lda, bp, ldb, kb + 2);
-        f1.multiply(acc);
+        for (; kb + 2 <= kblocks; kb += 2) {
+            f1.fetch(ap, lda, bp, ldb, kb + 1);
+            f0.multiply(acc);
+            if (kb + 2 < kblocks) f0.fetch(ap, lda, bp, ldb, kb + 2);
+            f1.multiply(acc);
+        }
+        if (kb < kblocks) f0.multiply(acc);
     }
-    if (kb < kblocks) f0.multiply(acc);
 }
 
 __device__ __forceinline__ void hy_zero(f32x4_t (&acc)[8]) {

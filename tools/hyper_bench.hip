@@ -1,9 +1,9 @@
 // Phase stamps and launch time of k_hyper (csrc/hyper.h) at the C2 shape (256 tasks x 128 + 128 points).  Not part of the library.
-//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -DADKF_STAMP_SMALL=1 -I adkf_ift_amd/csrc tools/hyper_bench.hip -o tools/hyper_bench
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -DADKF_STAMP_SMALL=1 -I adkf_ift_amd/csrc -I tools tools/hyper_bench.hip -o tools/hyper_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "hyper.h"
+#include "variants/dz.h"
 using namespace adkf;
 
 int main() {
@@ -65,5 +65,29 @@ int main() {
     for (int k = 1; k <= 24; ++k) { printf("%-22s %8llu cycles\n", nm[k], st[k] - st[k - 1]); tot += st[k] - st[k - 1]; }
     printf("total %llu cycles (s_memtime ticks at 100 MHz x ... see DESIGN)\n", tot);
 #endif
+    {   // k_dz on the same weight matrices
+        const int d = 256;
+        float *Zs, *Zq, *dZs, *dZq;
+        for (float** p : {&Zs, &Zq, &dZs, &dZq}) hipMalloc(p, (size_t)T * n * d * 4);
+        std::vector<float> z((size_t)T * n * d);
+        for (auto& v : z) v = rnd() - 0.5f;
+        hipMemcpy(Zs, z.data(), z.size() * 4, hipMemcpyHostToDevice); hipMemcpy(Zq, z.data(), z.size() * 4, hipMemcpyHostToDevice);
+        hipMemset(Wss, 0, NN * 4); hipMemset(Wqs, 0, NN * 4); hipMemset(Wqq, 0, NN * 4);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dz), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DZ_LDS_BYTES) != hipSuccess) { printf("no LDS opt-in\n"); return 1; }
+        DzArgs da{Wss, Wqs, Wqq, Zs, Zq, dZs, dZq, d, T};
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0);
+            for (int i = 0; i < 20; ++i) k_dz<<<T, HY_NT, DZ_LDS_BYTES>>>(da);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("k_dz %.2f us per launch (%s)\n", ms * 1000 / 20, hipGetErrorString(hipGetLastError()));
+        }
+#if ADKF_STAMP_SMALL
+        unsigned long long st2[32];
+        hipMemcpyFromSymbol(st2, HIP_SYMBOL(g_small_stamps), sizeof(st2));
+        for (int k = 1; k < 20; ++k) printf("k_dz stamp %2d -> %2d: %8llu cycles%s\n", k - 1, k, st2[k] - st2[k - 1], (k & 1) ? "   <- product / output" : "");
+#endif
+    }
     return 0;
 }
