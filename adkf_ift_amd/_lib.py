@@ -27,6 +27,12 @@ class Batch(C.Structure):
                 ("Z_q", C.c_void_p), ("y_q", C.c_void_p), ("priors", C.c_void_p)]
 
 
+class MsgEt(C.Structure):
+    """adkf_msg_et_t"""
+    _fields_ = [("src", C.c_void_p), ("tgt", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("dW", C.c_void_p),
+                ("db", C.c_void_p), ("E", C.c_int32)]
+
+
 class FitOptions(C.Structure):
     _fields_ = [("max_evals", C.c_int32), ("exact_evals", C.c_int32), ("gtol", C.c_float), ("ftol", C.c_float),
                 ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
@@ -56,14 +62,11 @@ SIGNATURES = {
                                      C.c_void_p]),
     "adkf_check_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "adkf_workspace_bytes_ard": (C.c_size_t, [C.c_int32] * 4),
-    "adkf_msg_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                   C.c_int64, C.c_void_p, C.c_void_p]),
-    "adkf_msg_backward_scratch_bytes": (C.c_size_t, [C.c_int32] * 4),
-    "adkf_msg_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-                                    C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
-                                    C.c_void_p]),
-    "adkf_msg_dx_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
-                                     C.c_void_p, C.c_void_p]),
+    "adkf_msg_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "adkf_msg_backward_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "adkf_msg_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
     "adkf_readout_pool": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p] * 7),
     "adkf_readout_pool_backward": (C.c_int, [C.c_void_p] * 10 + [C.c_int32] * 5 + [C.c_void_p] * 6),
     "adkf_pna_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -999,61 +999,82 @@ int adkf_ift_hypergrad_cg(const adkf_batch_t* b, const float* phi, int32_t flags
                    static_cast<hipStream_t>(stream));
 }
 
-int adkf_msg_forward(const float* x, const int64_t* src, const int64_t* tgt, const float* W, const float* bias, int32_t E, int32_t H,
-                     int32_t in, int32_t out, int64_t e_off, float* msgs, void* stream) {
-    (void)hipGetLastError();
-    if (!x || !W || !bias || !msgs || E < 0 || H <= 0 || in <= 0 || out <= 0 || (E > 0 && (!src || !tgt))) return ADKF_E_BADARG;
-    if (E == 0) return 0;
-    MsgArgs m{};
-    m.x = x; m.src = src; m.tgt = tgt; m.W = W; m.bias = bias; m.msgs = msgs; m.E = E; m.H = H; m.in = in; m.out = out; m.e_off = e_off;
-    m.vec = (in % 4 == 0) && (out % 4 == 0) && aligned16(x) && aligned16(W) && aligned16(msgs);
-    ProbMsgFwd p; p.m = m;
-    launch_gemm(p, H, E, out, static_cast<hipStream_t>(stream));
-    LAUNCH_OK();
-    return 0;
-}
-
-size_t adkf_msg_backward_scratch_bytes(int32_t E, int32_t H, int32_t in, int32_t out) {
-    if (E <= 0 || H <= 0 || in <= 0 || out <= 0) return 0;
-    return sizeof(float) * (size_t)msg_nsplit(E) * msg_part_stride(H, in, out);
-}
-
-int adkf_msg_backward(const float* x, const int64_t* src, const int64_t* tgt, const float* W, const float* msgs, const float* d_msgs,
-                      int32_t E, int32_t H, int32_t in, int32_t out, int64_t e_off, float* dcat, float* dW, float* db, void* scratch,
-                      size_t scratch_bytes, void* stream) {
-    (void)hipGetLastError();
-    if (!x || !W || !msgs || !d_msgs || !dcat || !dW || !db || E < 0 || H <= 0 || in <= 0 || out <= 0 || (E > 0 && (!src || !tgt))) return ADKF_E_BADARG;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (E == 0) {   // an edge type without edges: its parameters get exact zeros
-        if (hipMemsetAsync(dW, 0, sizeof(float) * (size_t)H * 2 * in * out, st) != hipSuccess) return ADKF_E_LAUNCH;
-        if (hipMemsetAsync(db, 0, sizeof(float) * (size_t)H * out, st) != hipSuccess) return ADKF_E_LAUNCH;
-        return 0;
+namespace {
+// fills the per-edge-type table of MsgArgs; returns the total number of edges, or -1 for a bad argument
+long msg_table(MsgArgs& m, const adkf_msg_et_t* ets, int n_et, bool backward) {
+    long e_all = 0;
+    int splits = 0;
+    for (int q = 0; q < n_et; ++q) {
+        const adkf_msg_et_t& s = ets[q];
+        if (s.E < 0 || !s.W || (s.E > 0 && (!s.src || !s.tgt)) || (!backward && !s.bias) || (backward && (!s.dW || !s.db))) return -1;
+        MsgEt& et = msg_row(m, q);
+        et.src = s.src; et.tgt = s.tgt; et.W = s.W; et.bias = s.bias; et.dW = s.dW; et.db = s.db; et.E = s.E;
+        et.e_off = (int)e_all; et.tile0 = 0; et.split0 = splits; et.chunk = s.E > 0 ? msg_chunk(s.E) : 1;
+        splits += msg_nsplit(s.E);
+        e_all += s.E;
+        if (e_all > 0x7fffffffL) return -1;
     }
-    if (!scratch || scratch_bytes < adkf_msg_backward_scratch_bytes(E, H, in, out)) return ADKF_E_WORKSPACE;
+    m.n_et = n_et; m.nsplit_all = splits;
+    return e_all;
+}
+int msg_tiles(MsgArgs& m, int n_cols) {   // lays the edge types' tiles side by side for a launch whose result has n_cols columns
+    int total = 0;
+    for (int q = 0; q < m.n_et; ++q) { msg_row(m, q).tile0 = total; total += ceil_div(msg_row(m, q).E, GT) * ceil_div(n_cols, GT); }
+    return total;
+}
+}  // namespace
+
+int adkf_msg_forward(const float* x, const adkf_msg_et_t* ets, int32_t n_et, int32_t H, int32_t in, int32_t out, float* msgs, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !ets || !msgs || n_et <= 0 || n_et > MSG_MAX_ET || H <= 0 || in <= 0 || out <= 0) return ADKF_E_BADARG;
     MsgArgs m{};
-    m.x = x; m.src = src; m.tgt = tgt; m.W = W; m.msgs = const_cast<float*>(msgs); m.d_msgs = d_msgs; m.dcat = dcat;
-    m.part = static_cast<float*>(scratch);
-    m.E = E; m.H = H; m.in = in; m.out = out; m.e_off = e_off; m.chunk = msg_chunk(E);
-    m.vec = (in % 4 == 0) && (out % 4 == 0) && aligned16(x) && aligned16(W) && aligned16(msgs) && aligned16(d_msgs);
-    const int nsplit = msg_nsplit(E);
-    ProbMsgBwdX px; px.m = m;
-    launch_gemm(px, H, E, 2 * in, st);
-    ProbMsgBwdW pw; pw.m = m; pw.nsplit = nsplit;
-    launch_gemm(pw, H * nsplit, 2 * in, out, st);
-    k_msg_dbias<<<dim3(ceil_div(H * out, 64), nsplit), 256, 0, st>>>(m);
-    const int n_w = H * 2 * in * out, n_b = H * out;
-    k_msg_reduce<<<ceil_div(n_w + n_b, 256), 256, 0, st>>>(m.part, nsplit, msg_part_stride(H, in, out), n_w, n_b, dW, db);
+    m.x = x; m.msgs = msgs; m.H = H; m.in = in; m.out = out;
+    if (msg_table(m, ets, n_et, false) < 0) return ADKF_E_BADARG;
+    m.vec = (in % 4 == 0) && (out % 4 == 0) && aligned16(x) && aligned16(msgs);
+    for (int q = 0; q < n_et; ++q) m.vec = m.vec && aligned16(ets[q].W);
+    const int total = msg_tiles(m, out);
+    if (total == 0) return 0;
+    ProbMsgFwd p; p.m = m;
+    k_bgemm<ProbMsgFwd, GT><<<grid_for(H, total), 256, 0, static_cast<hipStream_t>(stream)>>>(p, H, 1, total);
     LAUNCH_OK();
     return 0;
 }
 
-int adkf_msg_dx_gather(const float* dcat, const int64_t* perm_src, const int64_t* rowptr_src, const int64_t* perm_tgt,
-                       const int64_t* rowptr_tgt, int32_t V, int32_t H, int32_t in, float* dx, void* stream) {
+size_t adkf_msg_backward_scratch_bytes(const adkf_msg_et_t* ets, int32_t n_et, int32_t H, int32_t in, int32_t out) {
+    if (!ets || n_et <= 0 || n_et > MSG_MAX_ET || H <= 0 || in <= 0 || out <= 0) return 0;
+    size_t splits = 0;
+    for (int q = 0; q < n_et; ++q) splits += (size_t)msg_nsplit(ets[q].E);
+    return sizeof(float) * splits * msg_part_stride(H, in, out);
+}
+
+int adkf_msg_backward(const float* x, const adkf_msg_et_t* ets, int32_t n_et, int32_t H, int32_t in, int32_t out, const float* msgs,
+                      const float* d_msgs, const int64_t* perm_src, const int64_t* rowptr_src, const int64_t* perm_tgt,
+                      const int64_t* rowptr_tgt, int32_t V, float* dcat, float* dx, void* scratch, size_t scratch_bytes, void* stream) {
     (void)hipGetLastError();
-    if (!dcat || !perm_src || !rowptr_src || !perm_tgt || !rowptr_tgt || !dx || V <= 0 || H <= 0 || in <= 0) return ADKF_E_BADARG;
-    MsgDxArgs a{dcat, perm_src, rowptr_src, perm_tgt, rowptr_tgt, dx, V, H, in};
+    if (!x || !ets || !msgs || !d_msgs || !dcat || !dx || !perm_src || !rowptr_src || !perm_tgt || !rowptr_tgt) return ADKF_E_BADARG;
+    if (n_et <= 0 || n_et > MSG_MAX_ET || H <= 0 || in <= 0 || out <= 0 || V <= 0) return ADKF_E_BADARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MsgArgs m{};
+    m.x = x; m.msgs = const_cast<float*>(msgs); m.d_msgs = d_msgs; m.dcat = dcat; m.part = static_cast<float*>(scratch);
+    m.H = H; m.in = in; m.out = out;
+    const long e_all = msg_table(m, ets, n_et, true);
+    if (e_all < 0) return ADKF_E_BADARG;
+    if (m.nsplit_all > 0 && (!scratch || scratch_bytes < adkf_msg_backward_scratch_bytes(ets, n_et, H, in, out))) return ADKF_E_WORKSPACE;
+    m.vec = (in % 4 == 0) && (out % 4 == 0) && aligned16(x) && aligned16(msgs) && aligned16(d_msgs);
+    for (int q = 0; q < n_et; ++q) m.vec = m.vec && aligned16(ets[q].W);
+    const int total = msg_tiles(m, 2 * in);
+    if (total > 0) {
+        ProbMsgBwdX px; px.m = m;
+        k_bgemm<ProbMsgBwdX, GT><<<grid_for(H, total), 256, 0, st>>>(px, H, 1, total);
+        ProbMsgBwdW pw; pw.m = m;
+        launch_gemm(pw, H * m.nsplit_all, 2 * in, out, st);
+        k_msg_dbias<<<dim3(ceil_div(H * out, 64), m.nsplit_all), 256, 0, st>>>(m);
+    }
+    // d W / d b of every edge type (exact zeros where it has no edges), then d x gathered over each node's edge lists
+    k_msg_reduce<<<dim3(ceil_div(H * 2 * in * out + H * out, 256), n_et), 256, 0, st>>>(m);
+    MsgDxArgs da{dcat, perm_src, rowptr_src, perm_tgt, rowptr_tgt, dx, V, H, in};
     const long n = (long)V * H * in;
-    k_msg_dx<<<(unsigned)((n + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(a);
+    k_msg_dx<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(da);
     LAUNCH_OK();
     return 0;
 }

@@ -112,24 +112,37 @@ __global__ __launch_bounds__(256) void k_pna_bwd(PnaArgs a) {
 //                                                          CSR order by k_msg_dx - every element of d x written exactly once
 //     d W[h]  = sum over fixed chunks of edges of cat(x)^T (d msgs . [msgs > 0]): one partial per chunk, summed IN ORDER by
 //     d b[h]    k_msg_reduce (the same for the bias partials of k_msg_dbias); the chunking depends on E alone
-// "task" of k_bgemm = tower (forward, d cat) or (tower, edge chunk) (d W).
+// "task" of k_bgemm = tower (forward, d cat) or (tower, edge chunk) (d W).  ALL edge types go through ONE launch of each kind
+// (round 4: the flat tile / chunk index is mapped to its edge type by the functor; three launches per kind left the two rare bond
+// types of a molecule - a few thousand edges - with a handful of workgroups each).
 // ---------------------------------------------------------------------------------------------------------------------
 #include "problems.h"
 namespace adkf {
 
-struct MsgArgs {
-    const float* x;            // [V, H, in]
+constexpr int MSG_MAX_ET = 4;
+
+struct MsgEt {
     const int64_t *src, *tgt;  // [E]
     const float* W;            // [H, 2 in, out]
     const float* bias;         // [H, out]
-    float* msgs;               // [E_all, H, out] (this edge type starts at row e_off)
-    const float* d_msgs;       // backward
-    float* dcat;               // [E_all, H, 2 in] (this edge type starts at row e_off)
-    float* part;               // [nsplit, H * 2 in * out + H * out]: per-chunk partials of d W | d b
-    int E, H, in, out, chunk;  // chunk: edges per split of the d W / d b products
-    int64_t e_off;
-    bool vec;
+    float *dW, *db;            // backward outputs of this edge type
+    int E;
+    int e_off;                 // first row of this edge type in msgs / d_msgs / dcat
+    int tile0;                 // first flat tile of this edge type in the launch at hand (forward / d cat)
+    int split0, chunk;         // first chunk of this edge type among all chunks; edges per chunk
 };
+
+struct MsgArgs {
+    const float* x;            // [V, H, in]
+    float* msgs;               // [E_all, H, out]
+    const float* d_msgs;       // backward
+    float* dcat;               // [E_all, H, 2 in]
+    float* part;               // [nsplit_all, H * 2 in * out + H * out]: per-chunk partials of d W | d b
+    int H, in, out, n_et, nsplit_all;
+    bool vec;
+    MsgEt e0, e1, e2, e3;      // (four named rows, not an array: see msg_et)
+};
+inline MsgEt& msg_row(MsgArgs& m, int q) { return q == 0 ? m.e0 : q == 1 ? m.e1 : q == 2 ? m.e2 : m.e3; }   // host side
 
 // Edges per split of the d W / d b products: a function of E ALONE (at most MSG_SPLITS partials, at least 512 edges each,
 // a multiple of the GEMM's K chunk), so the summation order - hence the bits - does not depend on anything else.
@@ -139,15 +152,42 @@ inline int msg_chunk(int E) {
     const int r = ((c + 31) / 32) * 32;
     return r < 512 ? 512 : r;
 }
-inline int msg_nsplit(int E) { const int c = msg_chunk(E); return (E + c - 1) / c; }
+inline int msg_nsplit(int E) { if (E <= 0) return 0; const int c = msg_chunk(E); return (E + c - 1) / c; }
 __host__ __device__ inline size_t msg_part_stride(int H, int in, int out) { return (size_t)H * 2 * in * out + (size_t)H * out; }
 
-// d bias partial of one chunk: 64 columns x 4 row groups per workgroup (grid: ceil(H * out / 64) x nsplit), eight loads in
+// Edge type ei's row of the table.  The rows are four named members and the lookup a chain of selects: an array in the functor,
+// indexed at run time or not, made hipcc keep the whole functor in private memory - every access in the operand loops then went
+// through scratch and the merged forward launch ran 4 x slower than the three separate ones.
+__device__ __forceinline__ MsgEt msg_et(const MsgArgs& m, int ei) {   // (whole-row copies in separate branches, like ProbDistMulti::select)
+    MsgEt e;
+    if (ei == 0) { e = m.e0; }
+    else if (ei == 1) { e = m.e1; }
+    else if (ei == 2) { e = m.e2; }
+    else { e = m.e3; }
+    return e;
+}
+__device__ __forceinline__ int msg_find_tile(const MsgArgs& m, int idx) {    // the edge type whose tile range holds idx
+    int ei = 0;
+    if (m.n_et > 1 && idx >= m.e1.tile0) ei = 1;
+    if (m.n_et > 2 && idx >= m.e2.tile0) ei = 2;
+    if (m.n_et > 3 && idx >= m.e3.tile0) ei = 3;
+    return ei;
+}
+__device__ __forceinline__ int msg_find_split(const MsgArgs& m, int idx) {   // ... whose chunk range holds idx
+    int ei = 0;
+    if (m.n_et > 1 && idx >= m.e1.split0) ei = 1;
+    if (m.n_et > 2 && idx >= m.e2.split0) ei = 2;
+    if (m.n_et > 3 && idx >= m.e3.split0) ei = 3;
+    return ei;
+}
+
+// d bias partial of one chunk: 64 columns x 4 row groups per workgroup (grid: ceil(H * out / 64) x nsplit_all), eight loads in
 // flight per thread; the four row-group sums are combined in a fixed order
 __global__ __launch_bounds__(256) void k_msg_dbias(MsgArgs m) {
     __shared__ float part[4][64];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, width = m.H * m.out;
-    const int e0 = blockIdx.y * m.chunk, e1 = min(m.E, e0 + m.chunk);
+    const MsgEt et = msg_et(m, msg_find_split(m, (int)blockIdx.y));
+    const int e0 = ((int)blockIdx.y - et.split0) * et.chunk, e1 = min(et.E, e0 + et.chunk);
     float s = 0.f;
     if (c < width) {
         int e = e0 + g;
@@ -155,14 +195,14 @@ __global__ __launch_bounds__(256) void k_msg_dbias(MsgArgs m) {
             float dv[8], mv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const size_t o = (size_t)(m.e_off + e + 4 * u) * width + c;
+                const size_t o = (size_t)(et.e_off + e + 4 * u) * width + c;
                 dv[u] = m.d_msgs[o]; mv[u] = m.msgs[o];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += mv[u] > 0.f ? dv[u] : 0.f;
         }
         for (; e < e1; e += 4) {
-            const size_t o = (size_t)(m.e_off + e) * width + c;
+            const size_t o = (size_t)(et.e_off + e) * width + c;
             s += m.msgs[o] > 0.f ? m.d_msgs[o] : 0.f;
         }
     }
@@ -173,10 +213,16 @@ __global__ __launch_bounds__(256) void k_msg_dbias(MsgArgs m) {
             (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
 }
 
-// out[i] = part[0][i] + part[1][i] + ... (in this order) for the n_w elements of d W and the n_b of d b
-__global__ __launch_bounds__(256) void k_msg_reduce(const float* part, int nsplit, size_t stride, int n_w, int n_b, float* dW, float* db) {
+// out[i] = part[first][i] + part[first + 1][i] + ... (in this order) for the n_w elements of d W and the n_b of d b of every edge
+// type (blockIdx.y); an edge type without edges gets exact zeros
+__global__ __launch_bounds__(256) void k_msg_reduce(MsgArgs m) {
+    const MsgEt et = msg_et(m, (int)blockIdx.y);
+    const int n_w = m.H * 2 * m.in * m.out, n_b = m.H * m.out;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_w + n_b) return;
+    const size_t stride = msg_part_stride(m.H, m.in, m.out);
+    const int nsplit = (et.E + et.chunk - 1) / et.chunk;
+    const float* part = m.part + (size_t)et.split0 * stride;
     float s = 0.f;
     int p = 0;
     for (; p + 8 <= nsplit; p += 8) {
@@ -187,7 +233,7 @@ __global__ __launch_bounds__(256) void k_msg_reduce(const float* part, int nspli
         for (int u = 0; u < 8; ++u) s += v[u];
     }
     for (; p < nsplit; ++p) s += part[(size_t)p * stride + i];
-    if (i < n_w) dW[i] = s; else db[i - n_w] = s;
+    if (i < n_w) et.dW[i] = s; else et.db[i - n_w] = s;
 }
 
 // d x[v, h, :] = sum over v's outgoing edges of d cat[e, h, 0:in]  +  sum over its incoming edges of d cat[e, h, in:2 in],
@@ -209,22 +255,45 @@ __global__ __launch_bounds__(256) void k_msg_dx(MsgDxArgs a) {
     a.dx[(size_t)v * width + c] = s;
 }
 
+// Inside the GEMM functors (kernel arguments that select() / setup() write to) a row is picked FIELD BY FIELD in explicit branches:
+// a whole-row copy through msg_et() made hipcc keep the entire functor in private memory - every access of the operand loops went
+// through scratch and the merged forward launch ran 4 x slower than three separate ones (tools/: bisected on the code object's
+// private_segment_fixed_size).
+#define MSG_ROW(ei_, stmt_) do { if ((ei_) == 0) { const MsgEt& r_ = m.e0; stmt_; } else if ((ei_) == 1) { const MsgEt& r_ = m.e1; stmt_; } \
+                                 else if ((ei_) == 2) { const MsgEt& r_ = m.e2; stmt_; } else { const MsgEt& r_ = m.e3; stmt_; } } while (0)
+
+// flat tile -> (edge type, tile inside it): the edge types' tiles are laid side by side (gemm.h: select())
+__device__ __forceinline__ int msg_select(const MsgArgs& m, int& tile) {
+    int ei = 0, t0 = 0;
+    if (m.n_et > 1 && tile >= m.e1.tile0) { ei = 1; t0 = m.e1.tile0; }
+    if (m.n_et > 2 && tile >= m.e2.tile0) { ei = 2; t0 = m.e2.tile0; }
+    if (m.n_et > 3 && tile >= m.e3.tile0) { ei = 3; t0 = m.e3.tile0; }
+    tile -= t0;
+    return ei;
+}
+
 struct ProbMsgFwd {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = false;
     static constexpr int NRED = 0;
-    MsgArgs m; int h; bool vec;
-    __device__ bool setup(int t) { h = t; vec = m.vec; return m.E > 0; }
-    __device__ int M() const { return m.E; } __device__ int N() const { return m.out; } __device__ int K() const { return 2 * m.in; }
+    MsgArgs m; int h, ei; bool vec;
+    const int64_t *src, *tgt; const float *W, *bias; int E, e_off;
+    __device__ void select(int& tile, int& tiles_n) { ei = msg_select(m, tile); tiles_n = (m.out + GT - 1) / GT; }
+    __device__ bool setup(int t) {
+        h = t; vec = m.vec;
+        MSG_ROW(ei, (src = r_.src, tgt = r_.tgt, W = r_.W, bias = r_.bias, E = r_.E, e_off = r_.e_off));
+        return E > 0;
+    }
+    __device__ int M() const { return E; } __device__ int N() const { return m.out; } __device__ int K() const { return 2 * m.in; }
     __device__ const float* arow(int i, int k) const {
-        const int64_t node = k < m.in ? m.src[i] : m.tgt[i];
+        const int64_t node = k < m.in ? src[i] : tgt[i];
         return m.x + ((size_t)node * m.H + h) * m.in + (k < m.in ? k : k - m.in);
     }
     __device__ float a(int i, int k) const { return *arow(i, k); }
-    __device__ float b(int k, int j) const { return m.W[((size_t)h * 2 * m.in + k) * m.out + j]; }
+    __device__ float b(int k, int j) const { return W[((size_t)h * 2 * m.in + k) * m.out + j]; }
     __device__ void a4(int i, int k, float (&v)[4]) const { ld4(arow(i, k), v); }   // in % 4 == 0: a group never straddles the halves
-    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(m.W + ((size_t)h * 2 * m.in + k) * m.out + j, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(W + ((size_t)h * 2 * m.in + k) * m.out + j, v); }
     __device__ void epi(int i, int j, float acc, float*) const {
-        m.msgs[((size_t)(m.e_off + i) * m.H + h) * m.out + j] = fmaxf(acc + m.bias[h * m.out + j], 0.f);
+        m.msgs[((size_t)(e_off + i) * m.H + h) * m.out + j] = fmaxf(acc + bias[h * m.out + j], 0.f);
     }
     __device__ void store_red(int, const float*) const {}
 };
@@ -232,24 +301,30 @@ struct ProbMsgFwd {
 struct ProbMsgBwdX {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
     static constexpr int NRED = 0;
-    MsgArgs m; int h; bool vec;
-    __device__ bool setup(int t) { h = t; vec = m.vec; return m.E > 0; }
-    __device__ int M() const { return m.E; } __device__ int N() const { return 2 * m.in; } __device__ int K() const { return m.out; }
+    MsgArgs m; int h, ei; bool vec;
+    const float* W; int E, e_off;
+    __device__ void select(int& tile, int& tiles_n) { ei = msg_select(m, tile); tiles_n = (2 * m.in + GT - 1) / GT; }
+    __device__ bool setup(int t) {
+        h = t; vec = m.vec;
+        MSG_ROW(ei, (W = r_.W, E = r_.E, e_off = r_.e_off));
+        return E > 0;
+    }
+    __device__ int M() const { return E; } __device__ int N() const { return 2 * m.in; } __device__ int K() const { return m.out; }
     __device__ float a(int i, int k) const {
-        const size_t o = ((size_t)(m.e_off + i) * m.H + h) * m.out + k;
+        const size_t o = ((size_t)(e_off + i) * m.H + h) * m.out + k;
         return m.msgs[o] > 0.f ? m.d_msgs[o] : 0.f;
     }
-    __device__ float b(int k, int j) const { return m.W[((size_t)h * 2 * m.in + j) * m.out + k]; }
+    __device__ float b(int k, int j) const { return W[((size_t)h * 2 * m.in + j) * m.out + k]; }
     __device__ void a4(int i, int k, float (&v)[4]) const {
-        const size_t o = ((size_t)(m.e_off + i) * m.H + h) * m.out + k;
+        const size_t o = ((size_t)(e_off + i) * m.H + h) * m.out + k;
         float ms[4];
         ld4(m.d_msgs + o, v); ld4(m.msgs + o, ms);
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = ms[q] > 0.f ? v[q] : 0.f;
     }
-    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(m.W + ((size_t)h * 2 * m.in + j) * m.out + k, v); }
+    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(W + ((size_t)h * 2 * m.in + j) * m.out + k, v); }
     __device__ void epi(int i, int j, float acc, float*) const {
-        m.dcat[((size_t)(m.e_off + i) * m.H + h) * 2 * m.in + j] = acc;
+        m.dcat[((size_t)(e_off + i) * m.H + h) * 2 * m.in + j] = acc;
     }
     __device__ void store_red(int, const float*) const {}
 };
@@ -257,24 +332,29 @@ struct ProbMsgBwdX {
 struct ProbMsgBwdW {
     static constexpr bool A_KCONTIG = false, B_KCONTIG = false;
     static constexpr int NRED = 0;
-    MsgArgs m; int nsplit; int h, sp, e0, len; bool vec;
+    MsgArgs m; int h, sp, e0, len; bool vec;
+    const int64_t *src, *tgt; int e_off;
     __device__ bool setup(int t) {
-        h = t / nsplit; sp = t % nsplit; e0 = sp * m.chunk; len = min(m.chunk, m.E - e0); vec = m.vec;
+        h = t / m.nsplit_all; sp = t % m.nsplit_all; vec = m.vec;
+        const int ei = msg_find_split(m, sp);
+        int split0, chunk, E;
+        MSG_ROW(ei, (src = r_.src, tgt = r_.tgt, e_off = r_.e_off, split0 = r_.split0, chunk = r_.chunk, E = r_.E));
+        e0 = (sp - split0) * chunk; len = min(chunk, E - e0);
         return len > 0;
     }
     __device__ int M() const { return 2 * m.in; } __device__ int N() const { return m.out; } __device__ int K() const { return len; }
     __device__ const float* arow(int i, int k) const {
-        const int64_t node = i < m.in ? m.src[e0 + k] : m.tgt[e0 + k];
+        const int64_t node = i < m.in ? src[e0 + k] : tgt[e0 + k];
         return m.x + ((size_t)node * m.H + h) * m.in + (i < m.in ? i : i - m.in);
     }
     __device__ float a(int i, int k) const { return *arow(i, k); }
     __device__ float b(int k, int j) const {
-        const size_t o = ((size_t)(m.e_off + e0 + k) * m.H + h) * m.out + j;
+        const size_t o = ((size_t)(e_off + e0 + k) * m.H + h) * m.out + j;
         return m.msgs[o] > 0.f ? m.d_msgs[o] : 0.f;
     }
     __device__ void a4(int i, int k, float (&v)[4]) const { ld4(arow(i, k), v); }
     __device__ void b4(int k, int j, float (&v)[4]) const {
-        const size_t o = ((size_t)(m.e_off + e0 + k) * m.H + h) * m.out + j;
+        const size_t o = ((size_t)(e_off + e0 + k) * m.H + h) * m.out + j;
         float ms[4];
         ld4(m.d_msgs + o, v); ld4(m.msgs + o, ms);
 #pragma unroll

@@ -78,10 +78,18 @@ class GraphBatch:
     adjacency_lists: List[torch.Tensor]    # num_edge_types x [E_t, 2] int64 (src, tgt)
     node_to_graph: torch.Tensor            # [V] int64
     num_graphs: int
+    plan: Optional["_GraphPlan"] = None    # graph constants built once per batch (with_plan); None: built per forward
 
     def to(self, device):
         return GraphBatch(self.node_features.to(device), [a.to(device) for a in self.adjacency_lists],
-                          self.node_to_graph.to(device), self.num_graphs)
+                          self.node_to_graph.to(device), self.num_graphs, self.plan.to(device) if self.plan is not None else None)
+
+    def with_plan(self, bidirectional: bool = True, pna: bool = True, dtype: torch.dtype = torch.float32) -> "GraphBatch":
+        """Builds the graph constants here (on whatever device the batch lives on - the host, in a data pipeline) so that the
+        extractor's forward does not: ``batch.with_plan().to(device)``."""
+        self.plan = _GraphPlan(self.adjacency_lists, self.node_features.shape[0], bidirectional, pna, dtype,
+                               self.node_to_graph, self.num_graphs)
+        return self
 
 
 def concat_graph_batches(batches: Sequence[GraphBatch]) -> GraphBatch:
@@ -99,10 +107,28 @@ def concat_graph_batches(batches: Sequence[GraphBatch]) -> GraphBatch:
 
 
 class _GraphPlan:
-    """Per-forward graph constants shared by all layers and towers."""
+    """Graph constants shared by all layers and towers: bidirectional edge lists, degrees and PNA scalers, the CSR lists of the
+    fused kernels (by target, by source, nodes by graph).  They depend on the batch alone, so a data pipeline builds them ONCE per
+    batch on the host (``GraphBatch.with_plan`` - ``collate_meta_batch`` does) and ships them with it: built on the device per
+    forward they cost ~25 tiny launches and three host synchronisations (``torch.bincount`` returns a size)."""
+
+    def to(self, device):
+        new = object.__new__(_GraphPlan)
+        for k, v in self.__dict__.items():
+            if isinstance(v, torch.Tensor):
+                v = v.to(device)
+            elif isinstance(v, list):
+                v = [t.to(device) for t in v]
+            setattr(new, k, v)
+        return new
+
+    def matches(self, num_nodes: int, bidirectional: bool, pna: bool, device, dtype) -> bool:
+        return (self.num_nodes == num_nodes and self.bidirectional == bidirectional and (self.pna or not pna)
+                and self.all_tgts.device == device and self.inv_count.dtype == dtype)
 
     def __init__(self, adjacency_lists: List[torch.Tensor], num_nodes: int, bidirectional: bool, pna: bool,
-                 dtype: torch.dtype = torch.float32):
+                 dtype: torch.dtype = torch.float32, node_to_graph: Optional[torch.Tensor] = None, num_graphs: int = 0):
+        self.bidirectional, self.pna = bidirectional, pna
         if bidirectional:  # fs_mol/modules/gnn.py:540-544
             adjacency_lists = [torch.cat((a, a.flip(1)), dim=0) for a in adjacency_lists]
         self.srcs = [a[:, 0].contiguous() for a in adjacency_lists]   # contiguous: the HIP kernels index them directly
@@ -125,6 +151,13 @@ class _GraphPlan:
             log_deg = torch.log(deg + 1.0)
             self.amplify = (log_deg / PNA_DELTA).unsqueeze(-1)                      # gnn.py:241
             self.attenuate = (PNA_DELTA / (log_deg + SMALL_NUMBER)).unsqueeze(-1)   # gnn.py:242
+        # nodes by graph, for the read-out pooling kernels (csrc/readout.h)
+        self.num_graphs = int(num_graphs)
+        self.perm_graph = self.rowptr_graph = None
+        if node_to_graph is not None:
+            gcounts = torch.bincount(node_to_graph, minlength=self.num_graphs)
+            self.perm_graph = torch.argsort(node_to_graph, stable=True)
+            self.rowptr_graph = torch.cat((gcounts.new_zeros(1), torch.cumsum(gcounts, 0)))
 
 
 class TowerMessagePassing(nn.Module):
@@ -216,7 +249,24 @@ class TowerMessagePassing(nn.Module):
 
 class _MessageFunction(torch.autograd.Function):
     """relu(cat(x[src], x[tgt]) W_et + b_et) for every edge type and tower -> [E_all, H, out] (``adkf_msg_forward`` /
-    ``adkf_msg_backward``, csrc/pna.h).  x [V, H*in] float32 contiguous; weights[et] [H, 2 in, out], biases[et] [H, out]."""
+    ``adkf_msg_backward``, csrc/pna.h: ONE launch of each kind for all edge types).  x [V, H*in] float32 contiguous; weights[et]
+    [H, 2 in, out], biases[et] [H, out]."""
+
+    @staticmethod
+    def _table(plan, weights, biases=None, dWs=None, dbs=None):
+        import ctypes as C
+
+        from . import _lib
+        n_et = len(weights)
+        tab = (_lib.MsgEt * n_et)()
+        for et in range(n_et):
+            tab[et].src, tab[et].tgt = plan.srcs[et].data_ptr(), plan.tgts[et].data_ptr()
+            tab[et].W = weights[et].data_ptr()
+            tab[et].bias = biases[et].data_ptr() if biases is not None else None
+            tab[et].dW = dWs[et].data_ptr() if dWs is not None else None
+            tab[et].db = dbs[et].data_ptr() if dbs is not None else None
+            tab[et].E = int(plan.srcs[et].shape[0])
+        return tab
 
     @staticmethod
     def forward(ctx, x, plan, H, in_dim, out_dim, *params):
@@ -225,18 +275,13 @@ class _MessageFunction(torch.autograd.Function):
         from . import _lib
         lib = _lib.load()
         n_et = len(params) // 2
-        weights, biases = params[:n_et], params[n_et:]
+        weights, biases = [w.contiguous() for w in params[:n_et]], [b.contiguous() for b in params[n_et:]]
         E_all = int(plan.all_tgts.shape[0])
         msgs = torch.empty(E_all, H, out_dim, dtype=torch.float32, device=x.device)
         st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        off = 0
-        for et in range(n_et):
-            E = int(plan.srcs[et].shape[0])
-            w, b = weights[et].contiguous(), biases[et].contiguous()
-            _lib.check(lib.adkf_msg_forward(C.c_void_p(x.data_ptr()), C.c_void_p(plan.srcs[et].data_ptr()), C.c_void_p(plan.tgts[et].data_ptr()),
-                                            C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), E, H, in_dim, out_dim, off,
-                                            C.c_void_p(msgs.data_ptr()), st), "adkf_msg_forward")
-            off += E
+        tab = _MessageFunction._table(plan, weights, biases)
+        _lib.check(lib.adkf_msg_forward(C.c_void_p(x.data_ptr()), C.cast(tab, C.c_void_p), n_et, H, in_dim, out_dim,
+                                        C.c_void_p(msgs.data_ptr()), st), "adkf_msg_forward")
         ctx.save_for_backward(x, msgs, *weights)
         ctx.plan, ctx.dims, ctx.n_et = plan, (H, in_dim, out_dim), n_et
         return msgs
@@ -256,26 +301,17 @@ class _MessageFunction(torch.autograd.Function):
         E_all = int(plan.all_tgts.shape[0])
         # no floating-point atomics anywhere (csrc/pna.h): d cat is written once per edge and d x gathered over each node's
         # edge lists; d W / d b are per-chunk partials summed in a fixed order - every output element is written, none pre-filled
-        dcat = torch.empty(E_all, H, 2 * in_dim, dtype=torch.float32, device=dev)
+        dcat = torch.empty(max(E_all, 1), H, 2 * in_dim, dtype=torch.float32, device=dev)
         dW_all = [torch.empty_like(w) for w in weights]
         db_all = torch.empty(n_et, H, out_dim, dtype=torch.float32, device=dev)
-        need = max((int(lib.adkf_msg_backward_scratch_bytes(int(plan.srcs[et].shape[0]), H, in_dim, out_dim)) for et in range(n_et)), default=0)
+        dbs = [db_all[et] for et in range(n_et)]
+        tab = _MessageFunction._table(plan, weights, None, dW_all, dbs)
+        need = int(lib.adkf_msg_backward_scratch_bytes(C.cast(tab, C.c_void_p), n_et, H, in_dim, out_dim))
         scratch = torch.empty(max(need, 4) // 4, dtype=torch.float32, device=dev)
-        dbs, off = [], 0
-        for et in range(n_et):
-            E = int(plan.srcs[et].shape[0])
-            w = weights[et].contiguous()
-            _lib.check(lib.adkf_msg_backward(ptr(x), ptr(plan.srcs[et]), ptr(plan.tgts[et]), ptr(w), ptr(msgs), ptr(d_msgs), E, H, in_dim,
-                                             out_dim, off, ptr(dcat), ptr(dW_all[et]), ptr(db_all[et]), ptr(scratch), scratch.numel() * 4, st),
-                       "adkf_msg_backward")
-            dbs.append(db_all[et])
-            off += E
         dx = torch.empty_like(x)
-        if E_all > 0:
-            _lib.check(lib.adkf_msg_dx_gather(ptr(dcat), ptr(plan.perm_src), ptr(plan.rowptr_src), ptr(plan.perm), ptr(plan.rowptr),
-                                              x.shape[0], H, in_dim, ptr(dx), st), "adkf_msg_dx_gather")
-        else:
-            dx.zero_()
+        _lib.check(lib.adkf_msg_backward(ptr(x), C.cast(tab, C.c_void_p), n_et, H, in_dim, out_dim, ptr(msgs), ptr(d_msgs),
+                                         ptr(plan.perm_src), ptr(plan.rowptr_src), ptr(plan.perm), ptr(plan.rowptr), x.shape[0],
+                                         ptr(dcat), ptr(dx), ptr(scratch), scratch.numel() * 4, st), "adkf_msg_backward")
         return (dx, None, None, None, None, *dW_all, *dbs)
 
 
@@ -373,9 +409,10 @@ class GNN(nn.Module):
         self.config = config
         self.gnn_blocks = nn.ModuleList(GNNBlock(config) for _ in range(config.num_layers))
 
-    def forward(self, node_features: torch.Tensor, adj_lists: List[torch.Tensor]) -> List[torch.Tensor]:
-        plan = _GraphPlan(adj_lists, node_features.shape[0], self.config.make_edges_bidirectional,
-                          self.config.type.lower() == "pna", node_features.dtype)
+    def forward(self, node_features: torch.Tensor, adj_lists: List[torch.Tensor], plan: Optional[_GraphPlan] = None) -> List[torch.Tensor]:
+        bidir, pna = self.config.make_edges_bidirectional, self.config.type.lower() == "pna"
+        if plan is None or not plan.matches(node_features.shape[0], bidir, pna, node_features.device, node_features.dtype):
+            plan = _GraphPlan(adj_lists, node_features.shape[0], bidir, pna, node_features.dtype)
         cur, states = node_features, [node_features]
         for blk in self.gnn_blocks:
             cur = blk(cur, plan)
@@ -398,7 +435,7 @@ class _ReadoutPool(torch.autograd.Function):
     node list; the backward writes every element once.  Bit-reproducible, unlike ``index_add_`` and the backward of a gather."""
 
     @staticmethod
-    def forward(ctx, s_mean, v_mean, s_sum, v_sum, emb, node_to_graph, num_graphs, nh, hd):
+    def forward(ctx, s_mean, v_mean, s_sum, v_sum, emb, node_to_graph, num_graphs, nh, hd, perm=None, rowptr=None):
         import ctypes as C
 
         from . import _lib
@@ -407,9 +444,10 @@ class _ReadoutPool(torch.autograd.Function):
         V, D, G = emb.shape[0], emb.shape[1], int(num_graphs)
         s_mean, v_mean, s_sum, v_sum, emb = (t.contiguous() for t in (s_mean, v_mean, s_sum, v_sum, emb))
         n2g = node_to_graph.contiguous()
-        counts = torch.bincount(n2g, minlength=G)
-        perm = torch.argsort(n2g, stable=True)
-        rowptr = torch.cat((counts.new_zeros(1), torch.cumsum(counts, 0)))
+        if perm is None or rowptr is None:      # (no plan on the batch: three tiny launches and a host synchronisation)
+            counts = torch.bincount(n2g, minlength=G)
+            perm = torch.argsort(n2g, stable=True)
+            rowptr = torch.cat((counts.new_zeros(1), torch.cumsum(counts, 0)))
         f32 = dict(dtype=torch.float32, device=dev)
         w_mean, w_sum = torch.empty(V, nh, **f32), torch.empty(V, nh, **f32)
         g_mean, g_sum, g_max = torch.empty(G, nh * hd, **f32), torch.empty(G, nh * hd, **f32), torch.empty(G, D, **f32)
@@ -440,7 +478,7 @@ class _ReadoutPool(torch.autograd.Function):
         _lib.check(lib.adkf_readout_pool_backward(ptr(v_mean), ptr(v_sum), ptr(w_mean), ptr(w_sum), ptr(g_mean), ptr(argmax), ptr(n2g),
                                                   ptr(dg_mean), ptr(dg_sum), ptr(dg_max), V, G, nh, hd, D, ptr(d_s_mean), ptr(d_v_mean),
                                                   ptr(d_s_sum), ptr(d_v_sum), ptr(d_emb), st), "adkf_readout_pool_backward")
-        return d_s_mean, d_v_mean, d_s_sum, d_v_sum, d_emb, None, None, None, None
+        return d_s_mean, d_v_mean, d_s_sum, d_v_sum, d_emb, None, None, None, None, None, None
 
 
 class CombinedGraphReadout(nn.Module):
@@ -461,15 +499,18 @@ class CombinedGraphReadout(nn.Module):
         self.max_combination = nn.Linear(node_dim, out_dim, bias=False)
         self.combination_layer = nn.Linear(3 * out_dim, out_dim, bias=False)
 
-    def forward(self, node_embeddings: torch.Tensor, node_to_graph_id: torch.Tensor, num_graphs: int) -> torch.Tensor:
+    def forward(self, node_embeddings: torch.Tensor, node_to_graph_id: torch.Tensor, num_graphs: int, plan: Optional[_GraphPlan] = None) -> torch.Tensor:
         V, hid = node_embeddings.shape[0], self.nh * self.hd
         h = F.relu(self.first(node_embeddings))
         h_ms, h_mv, h_ss, h_sv = h.split(hid, dim=1)
         if node_embeddings.is_cuda and node_embeddings.dtype == torch.float32:
             # GPU: one fused, order-fixed pooling kernel (no fallback: a missing library raises)
+            ok = (plan is not None and plan.perm_graph is not None and plan.num_graphs == num_graphs
+                  and plan.perm_graph.device == node_embeddings.device and plan.perm_graph.shape[0] == V)
+            segs = (plan.perm_graph, plan.rowptr_graph) if ok else (None, None)
             g_mean, g_sum, g_max = _ReadoutPool.apply(self.mean_score_out(h_ms), self.mean_value_out(h_mv), self.sum_score_out(h_ss),
                                                       self.sum_value_out(h_sv), node_embeddings, node_to_graph_id, num_graphs,
-                                                      self.nh, self.hd)
+                                                      self.nh, self.hd, *segs)
         else:
             w_mean = _segment_softmax(self.mean_score_out(h_ms), node_to_graph_id, num_graphs)      # [V, heads]
             w_sum = torch.sigmoid(self.sum_score_out(h_ss))
@@ -507,9 +548,10 @@ class GraphFeatureExtractor(nn.Module):
 
     def forward(self, batch) -> torch.Tensor:
         """``batch`` = anything with node_features, adjacency_lists, node_to_graph, num_graphs (FSMolBatch layout)."""
-        states = self.gnn(self.init_node_proj(batch.node_features), list(batch.adjacency_lists))
+        plan = getattr(batch, "plan", None)
+        states = self.gnn(self.init_node_proj(batch.node_features), list(batch.adjacency_lists), plan)
         node_repr = torch.cat(states, dim=-1) if self.config.readout_config.use_all_states else states[-1]
-        out = self.readout(node_repr, batch.node_to_graph, batch.num_graphs)
+        out = self.readout(node_repr, batch.node_to_graph, batch.num_graphs, plan)
         if self.final_norm_layer is not None:
             out = self.final_norm_layer(out)
         return out

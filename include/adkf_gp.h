@@ -177,25 +177,34 @@ int adkf_ift_hypergrad_cg(const adkf_batch_t* b, const float* phi, int32_t flags
                           float* f_out, float* dZ_s, float* dZ_q, float* g_phi_out, float* v, int32_t* cg_iters,
                           int32_t* info, void* ws, size_t ws_bytes, void* stream);
 
-/* a1 (message functions of RelationalMP, fs_mol/modules/gnn.py:95-148, for the default depth-1 message MLP): all towers of
- * one edge type in one batched GEMM with the source / target node states gathered on the fly:
- *   msgs[e_off + e, h, :] = relu(cat(x[src_e, h, :], x[tgt_e, h, :]) W[h] + bias[h]),
- * x [V, H, in], W [H, 2 in, out], bias [H, out], msgs [E_all, H, out].
+/* a1 (message functions of RelationalMP, fs_mol/modules/gnn.py:95-148, for the default depth-1 message MLP): all towers of ALL
+ * edge types in one batched GEMM with the source / target node states gathered on the fly:
+ *   msgs[e_off(t) + e, h, :] = relu(cat(x[src_e, h, :], x[tgt_e, h, :]) W_t[h] + bias_t[h])   for edge e of edge type t,
+ * x [V, H, in], W_t [H, 2 in, out], bias_t [H, out], msgs [E_all, H, out]; the edge types' rows follow one another in msgs in
+ * the order of `ets` (e_off = number of edges of the types before); at most 4 edge types.
  * The backward is reproducible to the bit - no floating-point atomics (the reference's scatter ops and PyTorch's index_add_
- * are, on a GPU): adkf_msg_backward writes d cat[e_off + e, h, :] = (d msgs . [msgs > 0]) W[h]^T into dcat [E_all, H, 2 in]
- * and the complete dW [H, 2 in, out], db [H, out] of this edge type (per-chunk partials in `scratch`, at least
- * adkf_msg_backward_scratch_bytes(E, H, in, out) bytes, summed in a fixed order; nothing needs initialising; E = 0 zero-fills
- * dW and db).  After all edge types, ONE adkf_msg_dx_gather forms dx [V, H, in]: the sum over each node's outgoing edges of
- * the first half of d cat and over its incoming edges of the second half, in the order of the two CSR lists (perm_*: edge
- * ids of the concatenated edge list sorted stably by source / target node, rowptr_* [V + 1]). */
-int adkf_msg_forward(const float* x, const int64_t* src, const int64_t* tgt, const float* W, const float* bias, int32_t E,
-                     int32_t H, int32_t in, int32_t out, int64_t e_off, float* msgs, void* stream);
-size_t adkf_msg_backward_scratch_bytes(int32_t E, int32_t H, int32_t in, int32_t out);
-int adkf_msg_backward(const float* x, const int64_t* src, const int64_t* tgt, const float* W, const float* msgs,
-                      const float* d_msgs, int32_t E, int32_t H, int32_t in, int32_t out, int64_t e_off, float* dcat,
-                      float* dW, float* db, void* scratch, size_t scratch_bytes, void* stream);
-int adkf_msg_dx_gather(const float* dcat, const int64_t* perm_src, const int64_t* rowptr_src, const int64_t* perm_tgt,
-                       const int64_t* rowptr_tgt, int32_t V, int32_t H, int32_t in, float* dx, void* stream);
+ * are, on a GPU): d cat[e, h, :] = (d msgs . [msgs > 0]) W[h]^T is written once per edge into dcat [E_all, H, 2 in]; dx [V, H, in]
+ * is then the sum over each node's outgoing edges of the first half of d cat and over its incoming edges of the second half, in
+ * the order of the two CSR lists (perm_*: edge ids of the concatenated edge list sorted stably by source / target node,
+ * rowptr_* [V + 1]); every edge type's dW [H, 2 in, out] and db [H, out] are sums over fixed chunks of its edges (partials in
+ * `scratch`, at least adkf_msg_backward_scratch_bytes() bytes), added in a fixed order.  Nothing needs initialising; an edge type
+ * without edges gets exact zeros. */
+typedef struct adkf_msg_et {
+    const int64_t* src; /* [E] source node of every edge */
+    const int64_t* tgt; /* [E] target node */
+    const float* W;     /* [H, 2 in, out] */
+    const float* bias;  /* [H, out] (forward) */
+    float* dW;          /* [H, 2 in, out] (backward: output) */
+    float* db;          /* [H, out]       (backward: output) */
+    int32_t E;
+} adkf_msg_et_t;
+int adkf_msg_forward(const float* x, const adkf_msg_et_t* ets, int32_t n_et, int32_t H, int32_t in, int32_t out, float* msgs,
+                     void* stream);
+size_t adkf_msg_backward_scratch_bytes(const adkf_msg_et_t* ets, int32_t n_et, int32_t H, int32_t in, int32_t out);
+int adkf_msg_backward(const float* x, const adkf_msg_et_t* ets, int32_t n_et, int32_t H, int32_t in, int32_t out, const float* msgs,
+                      const float* d_msgs, const int64_t* perm_src, const int64_t* rowptr_src, const int64_t* perm_tgt,
+                      const int64_t* rowptr_tgt, int32_t V, float* dcat, float* dx, void* scratch, size_t scratch_bytes,
+                      void* stream);
 
 /* a1 (per-graph pooling of CombinedGraphReadout, fs_mol/modules/graph_readout.py:119-177: the weighted-mean head's
  * scatter_softmax + index_add_ :238-252, the weighted-sum head's sigmoid weights :236, the max pooler's scatter :289) between
