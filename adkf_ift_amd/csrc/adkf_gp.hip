@@ -8,6 +8,7 @@
 #include "ard.h"
 #include "pna.h"
 #include "readout.h"
+#include "block.h"
 #include "outer_step.h"
 #include "refine64.h"
 #include "hyper.h"
@@ -1132,6 +1133,61 @@ int adkf_pna_aggregate_backward(const float* msgs, const int64_t* perm, const in
     if (!msgs || !perm || !rowptr || !agg || !argmax || !d_agg || !d_msgs || V <= 0 || H <= 0 || m <= 0) return ADKF_E_BADARG;
     PnaArgs a{msgs, perm, rowptr, const_cast<float*>(agg), const_cast<int32_t*>(argmax), d_agg, d_msgs, V, H, m};
     k_pna_bwd<<<V, 256, 0, static_cast<hipStream_t>(stream)>>>(a);
+    LAUNCH_OK();
+    return 0;
+}
+
+int adkf_block_combine(const float* p, const float* x, const float* amp, const float* att, const float* bias, const float* alpha,
+                       const float* gamma, const float* beta, float eps, int32_t V, int32_t hid, float* x1, float* h, float* mu,
+                       float* rstd, void* stream) {
+    (void)hipGetLastError();
+    if (!p || !x || !amp || !att || !bias || !alpha || !gamma || !beta || !x1 || !h || !mu || !rstd) return ADKF_E_BADARG;
+    if (V <= 0 || hid <= 0 || (hid % 64) || hid > 64 * BLK_MAXC) return ADKF_E_SIZE;
+    BlockArgs a{};
+    a.p = p; a.x = x; a.amp = amp; a.att = att; a.bias = bias; a.alpha = alpha; a.gamma = gamma; a.beta = beta;
+    a.x1 = x1; a.h = h; a.mu = mu; a.rstd = rstd; a.eps = eps; a.V = V; a.hid = hid;
+    int grid = ceil_div(V, 4);
+    grid = grid > 16384 ? 16384 : grid;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (hid / 64) {
+        case 1: k_block_fwd<1><<<grid, 256, 0, st>>>(a); break;
+        case 2: k_block_fwd<2><<<grid, 256, 0, st>>>(a); break;
+        case 3: k_block_fwd<3><<<grid, 256, 0, st>>>(a); break;
+        default: k_block_fwd<4><<<grid, 256, 0, st>>>(a); break;
+    }
+    LAUNCH_OK();
+    return 0;
+}
+
+size_t adkf_block_combine_scratch_bytes(int32_t V, int32_t hid) {
+    if (V <= 0 || hid <= 0) return 0;
+    return sizeof(float) * (size_t)ceil_div(V, BLK_ROWS) * (3 * (size_t)hid + 1);
+}
+
+int adkf_block_combine_backward(const float* p, const float* x1, const float* amp, const float* att, const float* bias,
+                                const float* alpha, const float* gamma, const float* mu, const float* rstd, const float* g_x1,
+                                const float* g_h, int32_t V, int32_t hid, float* d_p, float* d_x, float* d_bias, float* d_alpha,
+                                float* d_gamma, float* d_beta, void* scratch, size_t scratch_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!p || !x1 || !amp || !att || !bias || !alpha || !gamma || !mu || !rstd || !g_x1 || !g_h || !d_p || !d_x || !d_bias || !d_alpha ||
+        !d_gamma || !d_beta || !scratch)
+        return ADKF_E_BADARG;
+    if (V <= 0 || hid <= 0 || (hid % 64) || hid > 64 * BLK_MAXC) return ADKF_E_SIZE;
+    if (scratch_bytes < adkf_block_combine_scratch_bytes(V, hid)) return ADKF_E_WORKSPACE;
+    BlockArgs a{};
+    a.p = p; a.x1 = const_cast<float*>(x1); a.amp = amp; a.att = att; a.bias = bias; a.alpha = alpha; a.gamma = gamma;
+    a.mu = const_cast<float*>(mu); a.rstd = const_cast<float*>(rstd); a.g_x1 = g_x1; a.g_h = g_h; a.d_p = d_p; a.d_x = d_x;
+    a.part = static_cast<float*>(scratch); a.V = V; a.hid = hid;
+    const int nwg = ceil_div(V, BLK_ROWS);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (hid / 64) {
+        case 1: k_block_bwd<1><<<nwg, 256, 0, st>>>(a); break;
+        case 2: k_block_bwd<2><<<nwg, 256, 0, st>>>(a); break;
+        case 3: k_block_bwd<3><<<nwg, 256, 0, st>>>(a); break;
+        default: k_block_bwd<4><<<nwg, 256, 0, st>>>(a); break;
+    }
+    const int n = 3 * hid + 1;
+    k_block_reduce<<<ceil_div(n, 64), 64, 0, st>>>(a.part, nwg, n, d_bias, d_gamma, d_beta, d_alpha, hid);
     LAUNCH_OK();
     return 0;
 }

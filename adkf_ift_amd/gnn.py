@@ -31,6 +31,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 SMALL_NUMBER = 1e-7
+_FUSED_BLOCK = __import__("os").environ.get("ADKF_GNN_FUSED_BLOCK", "1") != "0"   # diagnostics: 0 keeps the PyTorch ops in the middle of a block
 NUM_NODE_FEATURES = 32   # fs_mol/data/fsmol_dataset.py:21
 NUM_EDGE_TYPES = 3       # fs_mol/data/fsmol_dataset.py:22
 PNA_DELTA = 1.1515       # fs_mol/modules/gnn.py:237
@@ -178,6 +179,7 @@ class TowerMessagePassing(nn.Module):
         self.biases = nn.ParameterList()
         self.depth = config.message_function_depth
         self.capture: Optional[list] = None   # diagnostics: a list here receives the post-ReLU messages [E_all, H, out] of each forward
+        self.capture_argmax: Optional[list] = None   # ... and here the arg-max message ids [V, H, m] of the max aggregation (GPU path)
         for _ in range(config.num_edge_types):
             for l in range(self.depth):
                 w = torch.empty(H, dims[l], dims[l + 1])
@@ -205,7 +207,9 @@ class TowerMessagePassing(nn.Module):
             msgs = _MessageFunction.apply(x.contiguous(), plan, H, self.in_dim, self.out_msg, *self.weights, *self.biases)
             if self.capture is not None:
                 self.capture.append(msgs.detach())
-            agg = _PNAAggregate.apply(msgs, plan.perm, plan.rowptr, V)
+            agg, amax = _PNAAggregate.apply(msgs, plan.perm, plan.rowptr, V)
+            if self.capture_argmax is not None:
+                self.capture_argmax.append(amax)
             if self.kind == "pna" and scale:
                 amp, att = plan.amplify.unsqueeze(-1).to(x.dtype), plan.attenuate.unsqueeze(-1).to(x.dtype)
                 agg = torch.cat((agg, amp * agg, att * agg), dim=2)
@@ -228,7 +232,7 @@ class TowerMessagePassing(nn.Module):
         if msgs.is_cuda and msgs.dtype == torch.float32:
             # one HIP kernel for sum | mean | std | max (and one for their backward) instead of the ~15 (~30) element-wise,
             # index and scatter launches below per layer; no fallback on the GPU: a missing library raises
-            agg = _PNAAggregate.apply(msgs.contiguous(), plan.perm, plan.rowptr, V)
+            agg, _ = _PNAAggregate.apply(msgs.contiguous(), plan.perm, plan.rowptr, V)
             if self.kind == "pna":
                 amp, att = plan.amplify.unsqueeze(-1).to(x.dtype), plan.attenuate.unsqueeze(-1).to(x.dtype)
                 agg = torch.cat((agg, amp * agg, att * agg), dim=2)
@@ -332,10 +336,11 @@ class _PNAAggregate(torch.autograd.Function):
         _lib.check(lib.adkf_pna_aggregate(C.c_void_p(msgs.data_ptr()), C.c_void_p(perm.data_ptr()), C.c_void_p(rowptr.data_ptr()),
                                           V, H, m, C.c_void_p(agg.data_ptr()), C.c_void_p(argmax.data_ptr()), st), "adkf_pna_aggregate")
         ctx.save_for_backward(msgs, perm, rowptr, agg, argmax)
-        return agg
+        ctx.mark_non_differentiable(argmax)
+        return agg, argmax
 
     @staticmethod
-    def backward(ctx, d_agg):
+    def backward(ctx, d_agg, _d_argmax=None):
         import ctypes as C
 
         from . import _lib
@@ -349,6 +354,52 @@ class _PNAAggregate(torch.autograd.Function):
                                                    C.c_void_p(agg.data_ptr()), C.c_void_p(argmax.data_ptr()), C.c_void_p(d_agg.data_ptr()),
                                                    V, H, m4 // 4, C.c_void_p(d_msgs.data_ptr()), st), "adkf_pna_aggregate_backward")
         return d_msgs, None, None, None
+
+
+class _BlockCombine(torch.autograd.Function):
+    """new = p0 + amp p1 + att p2 + bias;  x1 = x + alpha new;  h = LayerNorm(x1)  ->  (x1, h)   as one HIP kernel forward and one
+    backward (``adkf_block_combine``, csrc/block.h) instead of nine / ~twenty element-wise and reduction launches per block."""
+
+    @staticmethod
+    def forward(ctx, p, x, amp, att, bias, alpha, gamma, beta, eps):
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        V, hid = x.shape
+        p, x, amp, att = p.contiguous(), x.contiguous(), amp.contiguous(), att.contiguous()
+        bias, gamma, beta = bias.contiguous(), gamma.contiguous(), beta.contiguous()
+        x1, h = torch.empty_like(x), torch.empty_like(x)
+        mu = torch.empty(V, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mu)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(lib.adkf_block_combine(ptr(p), ptr(x), ptr(amp), ptr(att), ptr(bias), ptr(alpha), ptr(gamma), ptr(beta), float(eps), V, hid,
+                                          ptr(x1), ptr(h), ptr(mu), ptr(rstd), st), "adkf_block_combine")
+        ctx.save_for_backward(p, x1, amp, att, bias, alpha, gamma, mu, rstd)
+        return x1, h
+
+    @staticmethod
+    def backward(ctx, g_x1, g_h):
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        p, x1, amp, att, bias, alpha, gamma, mu, rstd = ctx.saved_tensors
+        V, hid = x1.shape
+        dev = x1.device
+        g_x1 = torch.zeros_like(x1) if g_x1 is None else g_x1.contiguous()
+        g_h = torch.zeros_like(x1) if g_h is None else g_h.contiguous()
+        d_p, d_x = torch.empty_like(p), torch.empty_like(x1)
+        d_bias, d_gamma, d_beta, d_alpha = torch.empty_like(bias), torch.empty_like(gamma), torch.empty_like(gamma), torch.empty_like(alpha)
+        need = int(lib.adkf_block_combine_scratch_bytes(V, hid))
+        scratch = torch.empty(need // 4, dtype=torch.float32, device=dev)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.adkf_block_combine_backward(ptr(p), ptr(x1), ptr(amp), ptr(att), ptr(bias), ptr(alpha), ptr(gamma), ptr(mu), ptr(rstd),
+                                                   ptr(g_x1), ptr(g_h), V, hid, ptr(d_p), ptr(d_x), ptr(d_bias), ptr(d_alpha), ptr(d_gamma),
+                                                   ptr(d_beta), ptr(scratch), need, st), "adkf_block_combine_backward")
+        return d_p, d_x, None, None, d_bias, d_alpha, d_gamma, d_beta, None
 
 
 class BOOMLayer(nn.Module):
@@ -387,6 +438,15 @@ class GNNBlock(nn.Module):
             H, q, hid = self.mp.H, 4 * self.mp.msg, self.config.hidden_dim
             w = self.msg_out_projection.weight.view(hid, H, 3, q).permute(2, 0, 1, 3).reshape(3 * hid, H * q)
             p = F.linear(self.mp(x, plan, scale=False), w)
+            fused = (_FUSED_BLOCK and x.is_cuda and x.dtype == torch.float32 and self.config.use_rezero_scaling and self.boom_layer is not None
+                     and self.config.dropout_rate == 0.0 and hid % 64 == 0 and hid <= 256 and isinstance(self.boom_norm_layer, nn.LayerNorm))
+            if fused:
+                # GPU: the combination, the ReZero residual and the BOOM layer norm in one kernel (csrc/block.h; no fallback on the
+                # GPU for this configuration: a missing library raises)
+                ln = self.boom_norm_layer
+                x1, h = _BlockCombine.apply(p, x, plan.amplify.reshape(-1), plan.attenuate.reshape(-1), self.msg_out_projection.bias,
+                                            self.alpha, ln.weight, ln.bias, ln.eps)
+                return torch.addcmul(x1, self.alpha, self.boom_layer(h))          # x1 + alpha BOOM(LN(x1))
             new = p[:, :hid] + plan.amplify.to(x.dtype) * p[:, hid:2 * hid] + plan.attenuate.to(x.dtype) * p[:, 2 * hid:] \
                 + self.msg_out_projection.bias
             new = self.dropout_layer(new)
@@ -417,6 +477,10 @@ class GNN(nn.Module):
         for blk in self.gnn_blocks:
             cur = blk(cur, plan)
             states.append(cur)
+        if getattr(self, "state_grads", None) is not None:     # diagnostics (tools/diag_gnn_states.py): gradient arriving at every node state
+            for k, st in enumerate(states):
+                if st.requires_grad:
+                    st.register_hook(lambda g, k=k: self.state_grads.__setitem__(k, g.detach().clone()))
         return states
 
 

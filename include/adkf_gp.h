@@ -233,6 +233,22 @@ int adkf_pna_aggregate_backward(const float* msgs, const int64_t* perm, const in
                                 const int32_t* argmax, const float* d_agg, int32_t V, int32_t H, int32_t m,
                                 float* d_msgs, void* stream);
 
+/* a1 (the element-wise middle of GNNBlock.forward, fs_mol/modules/gnn.py:477-515, between the output projection of the message
+ * passing and the BOOM MLP):   new = p0 + amp[v] p1 + att[v] p2 + bias  (p = [p0 | p1 | p2] [V, 3 hid]: the projected unscaled
+ * aggregates; amp / att [V]: the PNA scalers),   x1 = x + alpha new  (ReZero),   h = LayerNorm(x1; gamma, beta, eps).
+ * Outputs x1, h [V, hid] and the row statistics mu, rstd [V] the backward needs.  hid a multiple of 64, at most 256 (else
+ * ADKF_E_SIZE: the caller keeps its own path).  The backward takes the gradients arriving at x1 (g_x1) and h (g_h) and writes d_p
+ * [V, 3 hid], d_x [V, hid] and the parameter gradients d_bias, d_gamma, d_beta [hid], d_alpha [1], reduced over the nodes in a fixed
+ * order (per-workgroup partials in `scratch`, adkf_block_combine_scratch_bytes(V, hid) bytes): bit-reproducible. */
+int adkf_block_combine(const float* p, const float* x, const float* amp, const float* att, const float* bias, const float* alpha,
+                       const float* gamma, const float* beta, float eps, int32_t V, int32_t hid, float* x1, float* h, float* mu,
+                       float* rstd, void* stream);
+size_t adkf_block_combine_scratch_bytes(int32_t V, int32_t hid);
+int adkf_block_combine_backward(const float* p, const float* x1, const float* amp, const float* att, const float* bias,
+                                const float* alpha, const float* gamma, const float* mu, const float* rstd, const float* g_x1,
+                                const float* g_h, int32_t V, int32_t hid, float* d_p, float* d_x, float* d_bias, float* d_alpha,
+                                float* d_gamma, float* d_beta, void* scratch, size_t scratch_bytes, void* stream);
+
 /* H (outer update of ADKTModelTrainer.train_loop, fs_mol/utils/adaptive_dkt_utils.py:402-413: task-mean of the
  * accumulated gradients, torch.nn.utils.clip_grad_norm_, torch.optim.Adam.step) for a handful of parameter tensors.
  *   adkf_grad_sumsq      partials[0 .. ADKF_SUMSQ_PARTS) = per-workgroup sums of g^2 (fixed partition: deterministic).

@@ -60,13 +60,22 @@ def scatter_softmax(src, index, n):
     return out
 
 
-def multi_aggr_mp(x, adj_lists, p, name: str, cfg) -> torch.Tensor:
-    """One tower: RelationalMultiAggrMP with PNA scalers (cfg.type == 'PNA')."""
-    msgs, tgts_all = [], []
+def multi_aggr_mp(x, adj_lists, p, name: str, cfg, std_mask=None, argmax=None, relu_mask=None) -> torch.Tensor:
+    """One tower: RelationalMultiAggrMP with PNA scalers (cfg.type == 'PNA').
+    ``std_mask`` [E, m] bool (tests only): the indicator [b_e^2 > mean^2] of the std aggregation is TAKEN from the caller instead of
+    being evaluated here.  The reference's relu(b^2 - mean^2) has a kink with slope up to 1 / (2 sqrt(1e-7)) = 1581 behind it, so
+    which side a nearly-equal message falls on is decided by the rounding of its inputs; with the float32 device's own indicators
+    the float64 restatement is the SMOOTH function the device evaluated, and its gradients are comparable at 1e-5 instead of 1e-3.
+    ``argmax`` [V, m] int (tests only; -1: no incoming message): likewise the winner of the max aggregation - between two nearly equal
+    messages the float32 and the float64 forward may pick different ones, and the gradient then flows to a different edge."""
+    msgs, tgts_all, e0 = [], [], 0
     for et, adj in enumerate(adj_lists):
         srcs, tgts = adj[:, 0], adj[:, 1]
         m = _mlp(torch.cat((x[srcs], x[tgts]), dim=1), p, f"{name}.message_fns.{et}", cfg.message_function_depth - 1)
-        msgs.append(F.relu(m))
+        # relu_mask [E_all, 3 m] (tests only): which messages the caller's forward let through - the same idea as std_mask for the
+        # ReLU behind the message function (an element within rounding distance of 0 is on or off depending on the arithmetic)
+        msgs.append(F.relu(m) if relu_mask is None else torch.where(relu_mask[e0:e0 + m.shape[0]], m, torch.zeros_like(m)))
+        e0 += m.shape[0]
         tgts_all.append(tgts)
     messages, targets = torch.cat(msgs), torch.cat(tgts_all)
     V, m = x.shape[0], cfg.per_head_dim
@@ -75,9 +84,14 @@ def multi_aggr_mp(x, adj_lists, p, name: str, cfg) -> torch.Tensor:
     s_sum = scatter_sum(messages[:, :m], targets, V)
     mean_messages = messages[:, m:2 * m]
     s_mean = scatter_mean(mean_messages, targets, V)
-    dev = F.relu(mean_messages.pow(2) - s_mean[targets].pow(2)) + SMALL_NUMBER
+    diff = mean_messages.pow(2) - s_mean[targets].pow(2)
+    dev = (F.relu(diff) if std_mask is None else torch.where(std_mask, diff, torch.zeros_like(diff))) + SMALL_NUMBER
     s_std = torch.sqrt(scatter_sum(dev, targets, V))
-    s_max = scatter_max(messages[:, 2 * m:3 * m], targets, V)
+    if argmax is None:
+        s_max = scatter_max(messages[:, 2 * m:3 * m], targets, V)
+    else:
+        am = argmax.long()
+        s_max = torch.where(am >= 0, messages[:, 2 * m:3 * m].gather(0, am.clamp(min=0)), torch.zeros((), dtype=messages.dtype))
     out = torch.cat((s_sum, s_mean, s_std, s_max), dim=1)
     if cfg.type.lower() == "pna":
         deg = scatter_sum(torch.ones_like(targets).unsqueeze(-1), targets, V).squeeze(-1)
@@ -87,9 +101,12 @@ def multi_aggr_mp(x, adj_lists, p, name: str, cfg) -> torch.Tensor:
     return out
 
 
-def gnn_block(x, adj_lists, p, name: str, cfg) -> torch.Tensor:
+def gnn_block(x, adj_lists, p, name: str, cfg, std_mask=None, argmax=None, relu_mask=None) -> torch.Tensor:
+    """``std_mask`` [E, heads, m], ``argmax`` [V, heads, m], ``relu_mask`` [E, heads, 3 m] (see multi_aggr_mp)."""
     in_dim = cfg.hidden_dim // cfg.num_heads
-    agg = [multi_aggr_mp(x[:, h * in_dim:(h + 1) * in_dim], adj_lists, p, f"{name}.mp_layers.{h}", cfg) for h in range(cfg.num_heads)]
+    agg = [multi_aggr_mp(x[:, h * in_dim:(h + 1) * in_dim], adj_lists, p, f"{name}.mp_layers.{h}", cfg,
+                         None if std_mask is None else std_mask[:, h], None if argmax is None else argmax[:, h],
+                         None if relu_mask is None else relu_mask[:, h]) for h in range(cfg.num_heads)]
     new = _linear(torch.cat(agg, dim=-1), p, f"{name}.msg_out_projection")
     if cfg.use_rezero_scaling:
         new = p[f"{name}.alpha"] * new
@@ -111,7 +128,10 @@ def weighted_readout(x, n2g, G, p, name: str, rcfg, kind: str):
     return _linear(per_graph, p, f"{name}._combination_layer", bias=False)
 
 
-def graph_feature_extractor(batch, p: Dict[str, torch.Tensor], cfg, prefix: str = "graph_feature_extractor.") -> torch.Tensor:
+def graph_feature_extractor(batch, p: Dict[str, torch.Tensor], cfg, prefix: str = "graph_feature_extractor.", std_masks=None,
+                            argmaxes=None, relu_masks=None) -> torch.Tensor:
+    """``std_masks`` / ``argmaxes``: one [E_all, heads, m] bool / [V, heads, m] int tensor per block (see multi_aggr_mp), or None for
+    the reference's own indicators / winners."""
     p = {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
     g, r = cfg.gnn_config, cfg.readout_config
     x = _linear(batch.node_features, p, "init_node_proj", bias=False)
@@ -120,7 +140,8 @@ def graph_feature_extractor(batch, p: Dict[str, torch.Tensor], cfg, prefix: str 
         adj = [torch.cat((a, torch.flip(a, dims=(1,))), dim=0) for a in adj]
     states = [x]
     for b in range(g.num_layers):
-        x = gnn_block(x, adj, p, f"gnn.gnn_blocks.{b}", g)
+        x = gnn_block(x, adj, p, f"gnn.gnn_blocks.{b}", g, None if std_masks is None else std_masks[b],
+                      None if argmaxes is None else argmaxes[b], None if relu_masks is None else relu_masks[b])
         states.append(x)
     node_repr = torch.cat(states, dim=-1) if r.use_all_states else states[-1]
     G = batch.num_graphs
@@ -174,3 +195,18 @@ def random_reference_state_dict(cfg, seed: int = 0, dtype=torch.float64, prefix:
     sd["readout._max_pooler._combination_layer.weight"] = rnd(r.output_dim, node_dim)
     sd["readout._combination_layer.weight"] = rnd(r.output_dim, 3 * r.output_dim)
     return {prefix + k: v for k, v in sd.items()}
+
+
+def std_indicators(messages_per_block, adjacency_lists, num_nodes: int, m: int, bidirectional: bool = True):
+    """The indicators [b_e^2 > mean^2] of the std aggregation from captured post-ReLU messages ([E_all, heads, 3 m] per block, e.g. a
+    float32 device forward: ``TowerMessagePassing.capture``), evaluated in float64 - products of float32 numbers are exact there,
+    which is also how the device kernels decide (csrc/pna.h)."""
+    adj = [torch.cat((a, a.flip(1)), 0) if bidirectional else a for a in adjacency_lists]
+    tg = torch.cat([a[:, 1] for a in adj]).cpu()
+    cnt = torch.bincount(tg, minlength=num_nodes).clamp(min=1).double().view(num_nodes, 1, 1)
+    out = []
+    for msgs in messages_per_block:
+        b = msgs.detach().double().cpu()[..., m:2 * m]
+        mean = torch.zeros(num_nodes, *b.shape[1:], dtype=torch.float64).index_add_(0, tg, b) / cnt
+        out.append(b.pow(2) > mean[tg].pow(2))
+    return out
