@@ -350,8 +350,9 @@ bool refine64_lds_optin() {
 Refine64Args refine_args(const TaskView& tv, const adkf_batch_t* b, const Workspace& w, bool with_hessian, int level, float* f_out,
                          int32_t* info, float* f_in, float* g_in, float* gnorm, size_t& lds_bytes) {
     const bool lds_inv = refine64_lds_optin();   // (beyond R64_LDS_POINTS the diagonal blocks of the blocked inverse live there)
-    const size_t lds_pts = w.vld <= R64_LDS_POINTS ? (size_t)w.vld : (size_t)R64_LDS_POINTS;
-    lds_bytes = lds_inv ? sizeof(double) * lds_pts * lds_pts : 0;
+    // (always the full R64_LDS_POINTS^2 doubles - 128 KB: the staged products of refine64.h work in blocks of that edge whatever the
+    // batch size; one workgroup per CU, which is what this path runs at anyway)
+    lds_bytes = lds_inv ? sizeof(double) * (size_t)R64_LDS_POINTS * R64_LDS_POINTS : 0;
     return Refine64Args{tv, b->Z_s, b->Z_q, b->d, b->y_s, b->y_q, b->priors, w.Ainv, with_hessian ? w.P : nullptr, level >= 1 ? w.C : nullptr,
                         level >= 2 ? w.S : nullptr, w.vecs, w.scal, f_out, info, f_in, g_in, gnorm, w.w64, w.w64_stride, r64_threshold(), b->T,
                         with_hessian ? 1 : 0, level, lds_inv ? 1 : 0};
@@ -517,7 +518,7 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         size_t lds_bytes;
         const Refine64Args ra = refine_args(tv, b, w, with_hessian, 2, f_out, info, nullptr, nullptr, nullptr, lds_bytes);
         Cot64Args ca{tv, b->Z_s, b->Z_q, dZ_s, dZ_q, d, w.vecs, w.scal, w.w64, w.w64_stride, r64_threshold(), T,
-                     with_hessian ? 1 : 0, flags, dirscale, corrscale, g_phi_out, v_out, H_out};
+                     with_hessian ? 1 : 0, flags, dirscale, corrscale, g_phi_out, v_out, H_out, lds_bytes ? 1 : 0};
         k_tail64<<<T, R64_NT, lds_bytes, st>>>(ra, ca);
     }
     LAUNCH_OK();

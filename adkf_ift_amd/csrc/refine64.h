@@ -40,7 +40,7 @@ struct Refine64Args {
     float* vecs; float* scal; float* f_out; int32_t* info;
     float *f_in, *g_in, *gnorm;        // optional: the refined inner value / raw gradient / max |gradient| (adkf_fit, adkf_mll_value_grad)
     double* w64; size_t w64_stride;    // [T][stride] doubles
-    float thresh; int T, want_hess, want_outer, lds_inverse;   // lds_inverse: the launch carries R64_LDS_POINTS^2 doubles of dynamic LDS; want_outer: 0 = inner quantities only, 1 = + C and mu (prediction), 2 = + S, S^-1, e, f_out
+    float thresh; int T, want_hess, want_outer, lds_inverse;   // lds_inverse: the launch carries R64_LDS_POINTS^2 doubles of dynamic LDS (the in-LDS inverse and the staged B operands of the products); want_outer: 0 = inner quantities only, 1 = + C and mu (prediction), 2 = + S, S^-1, e, f_out
 };
 
 // doubles per task: [A1 A2 A3 | B1 B2 | S1 S2 | 8 vectors | DDss DDqs DDqq | spare]
@@ -64,7 +64,7 @@ inline size_t refine64_doubles(int ns, int nq) {
 // product and workgroup, ~4 ms per launch of the path (profiles/r03_bench_*_d4.json, "before").  Barrier at the end.
 typedef double f64x4_t __attribute__((ext_vector_type(4)));
 template <class FA, class FB, class FE>
-__device__ __forceinline__ void r64_mm(int M, int N, int K, FA fa, FB fb, FE fe) {
+__device__ __forceinline__ void r64_mm_direct(int M, int N, int K, FA fa, FB fb, FE fe) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tn = (N + 15) >> 4, tiles = ((M + 15) >> 4) * tn;
     const int lr = lane & 15, lk = lane >> 4;
@@ -89,6 +89,62 @@ __device__ __forceinline__ void r64_mm(int M, int N, int K, FA fa, FB fb, FE fe)
     __syncthreads();
 }
 
+// The same product with the B operand STAGED in LDS (round 4; `stage`: 128 x 128 doubles, the region the in-LDS inverse uses): per
+// 128 x 128 block of B the workgroup copies it once (32 values per lane), then wave w forms rows 16 w .. 16 w + 15 of that column
+// block as eight accumulator tiles - ONE operand load from L2 per lane and k step (A: the wave's own rows, shared by its eight
+// tiles) instead of two per tile, eight LDS reads.  The direct version above spent ~100 us per 128^3 product waiting for L2 (two
+// dependent-latency loads in front of every MFMA, every B value fetched by eight waves); this one is bounded by the FP64 matrix
+// pipe (64 cycles per MFMA and SIMD: 14 us per 128^3 product) and the A loads.
+template <class FA, class FB, class FE>
+__device__ __forceinline__ void r64_mm_staged(int M, int N, int K, FA fa, FB fb, FE fe, double* stage) {
+    constexpr int B = R64_LDS_POINTS;   // 128: the launch carries B^2 doubles of dynamic LDS whatever the batch size
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+    for (int n0 = 0; n0 < N; n0 += B)
+        for (int m0 = 0; m0 < M; m0 += B) {
+            const int ar = m0 + 16 * wv + lr;
+            const bool aok = ar < M;
+            f64x4_t acc[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) acc[x] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
+            for (int kc = 0; kc < K; kc += B) {
+                __syncthreads();                                   // the previous block of B has been read by everybody
+                for (int e = threadIdx.x; e < B * B; e += R64_NT) {
+                    const int kk = e >> 7, j = e & 127;
+                    stage[e] = (kc + kk < K && n0 + j < N) ? fb(kc + kk, n0 + j) : 0.0;
+                }
+                __syncthreads();
+                const int kend = min(B, K - kc);
+                if (16 * wv < M - m0) {                            // (wave-uniform: this wave's rows exist)
+                    double av = (aok && kc + lk < K) ? fa(ar, kc + lk) : 0.0;
+                    for (int k0 = 0; k0 < kend; k0 += 4) {
+                        const int kn = kc + k0 + 4 + lk;
+                        const double an = (aok && k0 + 4 < kend && kn < K) ? fa(ar, kn) : 0.0;   // next step's A: in flight under the MFMAs
+                        const double* bp = stage + (k0 + lk) * B + lr;
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[16 * x], acc[x], 0, 0, 0);
+                        av = an;
+                    }
+                }
+            }
+            if (16 * wv < M - m0) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = m0 + 16 * wv + lk + 4 * r, j = n0 + 16 * x + lr;
+                        if (i < M && j < N) fe(i, j, acc[x][r]);
+                    }
+            }
+        }
+    __syncthreads();
+}
+
+template <class FA, class FB, class FE>
+__device__ __forceinline__ void r64_mm(int M, int N, int K, FA fa, FB fb, FE fe, double* stage = nullptr) {
+    if (stage) r64_mm_staged(M, N, K, fa, fb, fe, stage);
+    else r64_mm_direct(M, N, K, fa, fb, fe);
+}
+
 // y_i = sum_k fa(i, k) fx(k), delivered to fe(i, value): a wave per row, the lanes along k (coalesced for a row-major matrix;
 // round 2 ran the row-wise mat-vecs as a thread per row - 128 different cache lines per k step), wave-reduced.  Barrier at the end.
 template <class FA, class FX, class FE>
@@ -110,7 +166,7 @@ __device__ __forceinline__ void r64_mv(int M, int K, FA fa, FX fx, FE fe) {
 // of it (tools/diag_stress.py: dL/dZ_s 1.9e-4 -> 1.7e-6 on the one stress task that stayed above 1e-4).  In float64 the same
 // form carries eps64 |x|^2 - nothing - and runs on the matrix pipe (r64_mm); `same`: X == Y, the diagonal is exactly zero.
 // nx / ny: scratch for the squared row norms (nx + ny doubles).
-__device__ void r64_distances(const float* X, const float* Y, int nx, int ny, int d, double* out, int ldo, double* sx, double* sy, bool same) {
+__device__ void r64_distances(const float* X, const float* Y, int nx, int ny, int d, double* out, int ldo, double* sx, double* sy, bool same, double* stage = nullptr) {
     for (int i = threadIdx.x; i < nx + ny; i += R64_NT) {
         const float* r = i < nx ? X + (size_t)i * d : Y + (size_t)(i - nx) * d;
         double s = 0.0;
@@ -119,7 +175,7 @@ __device__ void r64_distances(const float* X, const float* Y, int nx, int ny, in
     }
     __syncthreads();
     r64_mm(nx, ny, d, [=](int i, int k) { return (double)X[(size_t)i * d + k]; }, [=](int k, int j) { return (double)Y[(size_t)j * d + k]; },
-       [=](int i, int j, double v) { const double q = sx[i] + sy[j] - 2.0 * v; out[(size_t)i * ldo + j] = (same && i == j) ? 0.0 : (q > 0.0 ? q : 0.0); });
+       [=](int i, int j, double v) { const double q = sx[i] + sy[j] - 2.0 * v; out[(size_t)i * ldo + j] = (same && i == j) ? 0.0 : (q > 0.0 ? q : 0.0); }, stage);
 }
 
 __device__ __forceinline__ void kappa3_d(int kind, double u, double& k0, double& k1, double& k2) {
@@ -266,6 +322,7 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
     const float rs = a.want_outer < 2 ? 0.f : sc[S_PIVR_S];
     if (!(ra > a.thresh || rs > a.thresh)) return;       // uniform over the workgroup
 
+    double* const stage = a.lds_inverse ? r64_lds : nullptr;   // B operands of the products go through LDS (r64_mm_staged)
     double* W = a.w64 + (size_t)t * a.w64_stride;
     double* A1 = W;                                 // A -> L -> A^-1
     double* A2 = A1 + (size_t)ld * ld;              // L^-1, then G
@@ -282,11 +339,11 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
     double* DDqs = DDss + (size_t)ld * ld;
     double* DDqq = DDqs + (size_t)ldq * ld;
     const float* Zs = a.Zs + (size_t)t * ld * a.d;
-    r64_distances(Zs, Zs, n, n, a.d, DDss, ld, gjc, gjr, true);
+    r64_distances(Zs, Zs, n, n, a.d, DDss, ld, gjc, gjr, true, stage);
     if (m > 0) {
         const float* Zq = a.Zq + (size_t)t * ldq * a.d;
-        r64_distances(Zq, Zs, m, n, a.d, DDqs, ld, gjc, gjr, false);
-        r64_distances(Zq, Zq, m, m, a.d, DDqq, ldq, gjc, gjr, true);
+        r64_distances(Zq, Zs, m, n, a.d, DDqs, ld, gjc, gjr, false, stage);
+        r64_distances(Zq, Zq, m, m, a.d, DDqq, ldq, gjc, gjr, true, stage);
     }
     __syncthreads();
     const float* ys = a.y_s + (size_t)t * ld;
@@ -322,7 +379,7 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
         if (a.want_hess) {
             __syncthreads();
             r64_mm(n, n, n, [=](int i, int k) { return A1[(size_t)i * ld + k]; }, [=](int k, int j) { return A2[(size_t)k * ld + j]; },
-                   [=](int i, int j, double v) { A3[(size_t)i * ld + j] = v; });   // P = A^-1 G
+                   [=](int i, int j, double v) { A3[(size_t)i * ld + j] = v; }, stage);   // P = A^-1 G
         }
         __syncthreads();
         double trAinv = 0, trAinvG = 0, aGa = 0, trA2 = 0, trPA = 0, trPP = 0, trAinvKll = 0, aKlla = 0;
@@ -408,7 +465,7 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
     }
     __syncthreads();
     r64_mm(m, n, n, [=](int i, int k) { return B1[(size_t)i * ld + k]; }, [=](int k, int j) { return A1[(size_t)k * ld + j]; },
-           [=](int i, int j, double v) { B2[(size_t)i * ld + j] = v; });           // C = K_qs A^-1
+           [=](int i, int j, double v) { B2[(size_t)i * ld + j] = v; }, stage);           // C = K_qs A^-1
     r64_mv(m, n, [=](int i, int k) { return B1[(size_t)i * ld + k]; }, [=](int k) { return v_al[k]; },
            [=](int i, double v) { v_mu[i] = v; v_r[i] = yq ? (double)yq[i] - v : 0.0; });
     if (a.C) {
@@ -426,7 +483,7 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
                double k0, k1, k2; kappa3_d(kind, DDqq[(size_t)i * ldq + j] * il2, k0, k1, k2);
                const double sv = os * k0 + (i == j ? noise : 0.0) - v;
                S1[(size_t)i * ldq + j] = sv; S1[(size_t)j * ldq + i] = sv;
-           });
+           }, stage);
     double logdetS;
     const int badS = m <= R64_LDS_POINTS ? r64_inverse(S1, m, ldq, logdetS, gjc, gjr, a.lds_inverse ? r64_lds : nullptr)
                                          : r64_inverse_blocked(S1, m, ldq, logdetS, gjc, gjr, r64_lds, scr);
@@ -473,6 +530,7 @@ struct Cot64Args {
     TaskView tv; const float *Zs, *Zq; float *dZs, *dZq; int d; float* vecs; float* scal;
     double* w64; size_t w64_stride; float thresh; int T, with_hessian, flags; float dirscale, corrscale; float *g_phi_out, *v_out;
     float* H_out;   // [T, 9] or null: the float64 path's Hessian (k_refine64 leaves it in the scalars) for the caller
+    int lds_stage;  // the launch carries R64_LDS_POINTS^2 doubles of dynamic LDS: the products stage their B operands there
 };
 
 __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
@@ -489,6 +547,7 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
     const float ra = sc[S_PIVR_A], rs = sc[S_PIVR_S];   // (the blocked path writes both as well: large.h)
     if (!(ra > a.thresh || rs > a.thresh)) return;
 
+    double* const stage = a.lds_stage ? r64_lds : nullptr;
     double* W = a.w64 + (size_t)t * a.w64_stride;                            // the layout of k_refine64
     double* A1 = W;                                 // A^-1
     double* A2 = A1 + (size_t)ld * ld;              // (G: spent)        -> M_A -> W_ss
@@ -517,7 +576,7 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
     }
     __syncthreads();
     r64_mm(m, n, m, [=](int i, int k) { return S1[(size_t)i * ldq + k]; }, [=](int k, int j) { return B2[(size_t)k * ld + j]; },
-           [=](int i, int j, double v) { B1[(size_t)i * ld + j] = 0.5 * (v - v_e[i] * v_cte[j]); });   // Omega C = (S^-1 C - e (C^T e)^T) / 2
+           [=](int i, int j, double v) { B1[(size_t)i * ld + j] = 0.5 * (v - v_e[i] * v_cte[j]); }, stage);   // Omega C = (S^-1 C - e (C^T e)^T) / 2
     double oc0 = 0, oc1 = 0, ma0 = 0, ma1 = 0, ma2 = 0, qq0 = 0, qq1 = 0, qq2 = 0;
     {   // M_A = C^T (Omega C) + sym(C^T e alpha^T)   (the three reductions ride in the product's epilogue)
         double* pm0 = &ma0; double* pm1 = &ma1; double* pm2 = &ma2;
@@ -529,7 +588,7 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
                    double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
                    if (i == j) *pm0 += MA;
                    *pm1 += MA * k0; *pm2 += MA * os * k1 * u * gl;
-               });
+               }, stage);
     }                                               // (barrier inside) Omega C has been read by everybody: it turns into W_qs in place
     for (int e = tid; e < m * n; e += R64_NT) {     // M_B -> W_qs
         const int i = e / n, j = e % n;
@@ -601,7 +660,7 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
     if (corr != 0.0) {
         const double ca = cn - cs * noise;
         r64_mm(n, n, n, [=](int i, int k) { return ca * A1[(size_t)i * ld + k] + (i == k ? cs : 0.0) + cl * A3[(size_t)i * ld + k]; },
-               [=](int k, int j) { return A1[(size_t)k * ld + j]; }, wss_of);
+               [=](int k, int j) { return A1[(size_t)k * ld + j]; }, wss_of, stage);
     } else {
         for (int e = tid; e < n * n; e += R64_NT) wss_of(e / n, e % n, 0.0);
         __syncthreads();
@@ -626,13 +685,13 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
         // dZs_i = 4 (rs_ss_i z_i - sum_k Wss_ik z_k) + 2 (cs_qs_i z_i - sum_q Wqs_qi zq_q): one product over k = [support | query]
         r64_mm(n, d, n + m, [=](int i, int k) { return k < n ? 4.0 * A2[(size_t)i * ld + k] : 2.0 * B1[(size_t)(k - n) * ld + i]; },
                [=](int k, int c) { return k < n ? (double)Zs[(size_t)k * d + c] : (double)Zq[(size_t)(k - n) * d + c]; },
-               [=](int i, int c, double v) { out[(size_t)i * d + c] = (float)((4.0 * rs_ss[i] + 2.0 * rs_qs_col[i]) * (double)Zs[(size_t)i * d + c] - v); });
+               [=](int i, int c, double v) { out[(size_t)i * d + c] = (float)((4.0 * rs_ss[i] + 2.0 * rs_qs_col[i]) * (double)Zs[(size_t)i * d + c] - v); }, stage);
     }
     if (a.dZq) {
         float* out = a.dZq + (size_t)t * ldq * d;
         r64_mm(m, d, n + m, [=](int i, int k) { return k < n ? 2.0 * B1[(size_t)i * ld + k] : 4.0 * S2[(size_t)i * ldq + (k - n)]; },
                [=](int k, int c) { return k < n ? (double)Zs[(size_t)k * d + c] : (double)Zq[(size_t)(k - n) * d + c]; },
-               [=](int i, int c, double v) { out[(size_t)i * d + c] = (float)((2.0 * rs_qs_row[i] + 4.0 * rs_qq[i]) * (double)Zq[(size_t)i * d + c] - v); });
+               [=](int i, int c, double v) { out[(size_t)i * d + c] = (float)((2.0 * rs_qs_row[i] + 4.0 * rs_qq[i]) * (double)Zq[(size_t)i * d + c] - v); }, stage);
     }
 }
 
