@@ -368,12 +368,12 @@ def main():
             traffic = traffic_src = None
             # the <= 128-register build (two tasks per CU) is taken when the batch has more tasks than the chip has CUs (adkf_gp.hip: num_cus())
             low = T > torch.cuda.get_device_properties(dev).multi_processor_count
-            pmc = os.path.join(ROOT, "profiles", "r03_k_inner_pmc.json")
+            pmc = os.path.join(ROOT, "profiles", "r04_k_inner_pmc.json")
             if os.path.exists(pmc) and (T, N, Nq, d, I) == (256, 128, 128, 256, 20) and args.kernel == "rbf" and not args.ard and not args.regression:
                 with open(pmc) as fh:
                     pm = json.load(fh)
                 traffic = (2.0 * pm["FETCH_SIZE_KB_per_launch"] + pm["WRITE_SIZE_KB_per_launch"]) * 1024.0
-                traffic_src = {"file": "profiles/r03_k_inner_pmc.json", "commit": pm.get("commit"),
+                traffic_src = {"file": "profiles/r04_k_inner_pmc.json", "commit": pm.get("commit"),
                                "correction": "2 x FETCH_SIZE + WRITE_SIZE"}
             pmc5 = os.path.join(ROOT, "profiles", "r03_c5_fit_pmc.json")
             if os.path.exists(pmc5) and (T, N, Nq, d, I) == (8, 1024, 1024, 512, 20) and args.kernel == "rbf" and not args.ard and not args.regression:

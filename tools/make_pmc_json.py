@@ -2,7 +2,8 @@
 """Turns the rocprofv3 passes of tools/round3_profiles.sh (merged back under gpurun_out/) into the tracked evidence:
 profiles/r03_bench_kernel_stats.csv, r03_k_inner_pmc.json (FETCH_SIZE / WRITE_SIZE per launch), r03_k_inner_sq_pmc.json
 (SQ, LDS and MFMA counters per launch), r03_c5_kernel_stats.csv and r03_c5_fit_pmc.json (traffic of one blocked fit).
-    python tools/make_pmc_json.py [commit]"""
+    python tools/make_pmc_json.py [commit]            (round 3 layout)
+    python tools/make_pmc_json.py r04 [commit]        (round 4: tools/round4_profiles.sh; k_inner AND k_hyper, profiles/r04_*)"""
 import csv
 import glob
 import json
@@ -41,7 +42,51 @@ def stats_avg_us(stats_csv, name):
     return None, 0
 
 
+def main_r04(commit):
+    prof = os.path.join(ROOT, "profiles")
+    stats = glob.glob(os.path.join(OUT, "prof_r04", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(prof, "r04_bench_kernel_stats.csv"))
+    stats5 = glob.glob(os.path.join(OUT, "prof_r04_c5", "**", "*kernel_stats.csv"), recursive=True)
+    if stats5:
+        shutil.copy(stats5[0], os.path.join(prof, "r04_c5_kernel_stats.csv"))
+    sq_names = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"]
+    lds_names = ["SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"]
+    for tag, kernel, what in (("k_inner", KINNER, "read D2 (16.8 MB) + write A^-1 (16.8 MB) + vectors"),
+                              ("k_hyper", "k_hyper<", "read A^-1 twice, D2_ss / D2_qs / D2_qq (several passes, L2 hits after the first), the parked "
+                                                      "exponential factors; write W_ss, W_qs, W_qq and the parked factors: 7 x 16.8 MB compulsory")):
+        avg_us = stats_avg_us(stats[0], kernel)[0] if stats else None
+        fetch, nf = per_launch("prof_r04_fetch", ["FETCH_SIZE"], kernel)
+        write, nw = per_launch("prof_r04_write", ["WRITE_SIZE"], kernel)
+        out = {"kernel": tag, "workload": "C2: 256 tasks, N=Nq=128, d=256, I=20", "commit": commit, "avg_duration_us": avg_us,
+               "FETCH_SIZE_KB_per_launch": fetch["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": write["WRITE_SIZE"], "pmc_launches": [nf, nw],
+               "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters alone with --kernel-trace) of `python bench.py --steps 5 "
+                       "--warmup 2`; KB as reported, summed over XCDs by rocprofv3; bench.py applies the guide's gfx950 correction (2 x FETCH_SIZE for "
+                       "16-byte-per-lane streaming reads); compulsory traffic of the launch: " + what}
+        with open(os.path.join(prof, f"r04_{tag}_pmc.json"), "w") as fh:
+            json.dump(out, fh, indent=1)
+        print(out)
+        sq, n1 = per_launch("prof_r04_sq", sq_names, kernel)
+        lds, n2 = per_launch("prof_r04_lds", lds_names, kernel)
+        sqo = {"kernel": tag, "workload": out["workload"], "commit": commit, "per_launch": {**sq, **{k: v for k, v in lds.items() if k not in sq}},
+               "launches": [n1, n2],
+               "note": "two rocprofv3 --pmc passes (7 SQ/GRBM counters each); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over "
+                       "waves, SQ_VALU_MFMA_BUSY_CYCLES cycles summed over SIMDs (MI355X_MICROARCH.md)"}
+        if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_WAIT_ANY") is not None:
+            sqo["wait_any_frac_of_wave_cycles"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
+            sqo["valu_issue_frac_of_wave_cycles"] = (sq.get("SQ_ACTIVE_INST_VALU") or 0.0) / sq["SQ_WAVE_CYCLES"]
+        if lds.get("SQ_VALU_MFMA_BUSY_CYCLES") and sq.get("GRBM_GUI_ACTIVE"):
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 256 CUs x 4 SIMDs run for GRBM / 8 cycles each
+            sqo["mfma_busy_frac_of_simd_cycles"] = lds["SQ_VALU_MFMA_BUSY_CYCLES"] / (sq["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        with open(os.path.join(prof, f"r04_{tag}_sq_pmc.json"), "w") as fh:
+            json.dump(sqo, fh, indent=1)
+        print(sqo)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "r04":
+        commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
+        return main_r04(commit)
     commit = sys.argv[1] if len(sys.argv) > 1 else subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
     prof = os.path.join(ROOT, "profiles")
     stats = glob.glob(os.path.join(OUT, "prof_r03", "**", "*kernel_stats.csv"), recursive=True)
