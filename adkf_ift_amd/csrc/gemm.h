@@ -67,6 +67,8 @@ template <class P, class = void> struct has_active : std::false_type {};
 template <class P> struct has_active<P, std::void_t<decltype(&P::active)>> : std::true_type {};
 template <class P, class = void> struct has_select : std::false_type {};
 template <class P> struct has_select<P, std::void_t<decltype(&P::select)>> : std::true_type {};
+template <class P, class = void> struct has_map : std::false_type {};      // the problem maps workgroups to (task, tile) itself (large.h: task groups)
+template <class P> struct has_map<P, std::void_t<decltype(&P::map)>> : std::true_type {};
 template <class P, class = void> struct has_epi4 : std::false_type {};
 template <class P> struct has_epi4<P, std::void_t<decltype(&P::epi4)>> : std::true_type {};
 
@@ -74,6 +76,14 @@ template <class P, class = void> struct has_rowsq : std::false_type {};
 template <class P> struct has_rowsq<P, std::void_t<decltype(&P::set_rowsq)>> : std::true_type {};
 template <class P, class = void> struct has_rowsum : std::false_type {};
 template <class P> struct has_rowsum<P, std::void_t<decltype(&P::set_rowsum)>> : std::true_type {};
+// DEEP (with the two-phase operand path): when K is exactly DEEP chunks, the raw loads of ALL chunks are issued before the first
+// MFMA - one trip to memory per workgroup instead of one per chunk.  For the K = 128 products of the blocked sweep (large.h), whose
+// launches are a few workgroups per CU and therefore as long as ONE workgroup's chain of dependent loads.
+template <class P, class = void> struct has_deep : std::false_type {};
+template <class P> struct has_deep<P, std::void_t<decltype(P::DEEP)>> : std::true_type {};
+// pre4 / epi4p: the epilogue's own operand (the matrix tile a product is subtracted from) is fetched with the operands, not after the last MFMA
+template <class P, class = void> struct has_pre : std::false_type {};
+template <class P> struct has_pre<P, std::void_t<decltype(&P::pre4)>> : std::true_type {};
 template <class P, class = void> struct has_raw : std::false_type {};
 template <class P> struct has_raw<P, std::void_t<decltype(P::A_NRAW)>> : std::true_type {};
 
@@ -185,7 +195,11 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
     using C = GemmCfg<TM>;
     constexpr int MI = C::MI, LD_K = C::LD_K, GPT = C::GPT, WT = TM / 2;
     int task, tile;
-    if (!task_tile(T, tiles_m * tiles_n, task, tile)) return;
+    if constexpr (has_map<P>::value) {
+        if (!p.map(tiles_m * tiles_n, task, tile)) return;
+    } else {
+        if (!task_tile(T, tiles_m * tiles_n, task, tile)) return;
+    }
     if constexpr (has_select<P>::value) p.select(tile, tiles_n);   // several sub-problems in one launch (tiles_m = 1, tiles_n = all tiles)
     if (!p.setup(task)) return;
     const int M = p.M(), N = p.N();
@@ -260,8 +274,35 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
     float sqa[GPT / 4], sqb[GPT / 4];
 #pragma unroll
     for (int ps = 0; ps < GPT / 4; ++ps) { sqa[ps] = 0.f; sqb[ps] = 0.f; }
-    bool fast = false;
-#ifndef ADKF_GEMM_NO_RAW   // diagnostics: -DADKF_GEMM_NO_RAW sends every tile through the checked path (tools/ab_lib.py)
+    bool fast = false, deep = false;
+    float pre[has_pre<P>::value ? MI : 1][has_pre<P>::value ? MI : 1][4];
+    if constexpr (has_deep<P>::value && has_raw<P>::value) {
+        static_assert(has_pre<P>::value && has_epi4<P>::value, "a DEEP problem prefetches its epilogue operand");
+        constexpr int DEEP = P::DEEP;
+        deep = p.vec && m0 + TM <= M && n0 + TM <= N && K == DEEP * GK && p.raw_ok();
+        if (deep) {
+            float4 qa[DEEP][GPT / 4][P::A_NRAW], qb[DEEP][GPT / 4][P::B_NRAW];
+#pragma unroll
+            for (int c = 0; c < DEEP; ++c) {
+                gemm_fetch_raw<P, true, TM, P::A_NRAW>(p, qa[c], m0, c * GK);
+                gemm_fetch_raw<P, false, TM, P::B_NRAW>(p, qb[c], n0, c * GK);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) p.pre4(m0 + wr * WT + i * 16 + fk * 4, n0 + wc * WT + j * 16 + fi, pre[i][j]);
+#pragma unroll
+            for (int c = 0; c < DEEP; ++c) {
+                gemm_stage_raw<P, true, TM, P::A_NRAW, 0>(p, As, qa[c], m0, c * GK, sqa);
+                gemm_stage_raw<P, false, TM, P::B_NRAW, 0>(p, Bs, qb[c], n0, c * GK, sqb);
+                ADKF_GEMM_SYNC();
+                multiply_chunk();
+                ADKF_GEMM_SYNC();
+            }
+        }
+    }
+#ifndef ADKF_GEMM_NO_RAW
+    if (deep) {} else   // diagnostics: -DADKF_GEMM_NO_RAW sends every tile through the checked path (tools/ab_lib.py)
     if constexpr (has_raw<P>::value) {
         fast = p.vec && m0 + TM <= M && n0 + TM <= N && K > 0 && (K % GK) == 0 && p.raw_ok();
         if (fast) {
@@ -283,7 +324,7 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
         }
     }
 #endif
-    if (!fast) {
+    if (!fast && !deep) {
         float ra[GPT], rb[GPT];
         gemm_fetch<P, true, TM>(p, ra, m0, 0, M, K);
         gemm_fetch<P, false, TM>(p, rb, n0, 0, N, K);
@@ -339,6 +380,13 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
 #if (ADKF_GEMM_ABLATE & 8)   // no epilogue (the accumulators stay alive through a store that never happens)
             if (acc[i][j][0] != 123.456f) continue;
 #endif
+            if constexpr (has_pre<P>::value) {
+                if (deep) {   // (a deep tile lies fully inside the task)
+                    const float v4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    p.epi4p(gi0, gj, v4, pre[i][j], red);
+                    continue;
+                }
+            }
             if constexpr (has_epi4<P>::value) {
                 if (gi0 + 3 < M && gj < N) {
                     const float v4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};

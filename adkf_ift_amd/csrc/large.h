@@ -34,7 +34,15 @@ struct LgMat {
     float* pext;            // [T, 2] smallest / largest pivot so far: the condition estimate that picks the float64 path (refine64.h)
     int32_t* info;          // [T] first non-positive pivot (1-based) or 0
     int T; bool vec;
-    __device__ __forceinline__ bool active(int t) const { return !fit || fit[t].phase != PH_DONE; }
+    // Task groups (adkf_gp.hip, LgGroups): a launch serves the tasks [t_lo, t_hi) only, so that groups on different streams are at
+    // different stages of their block steps at the same time (one group's 128-pivot diagonal sweeps - one workgroup per task - under
+    // another group's trailing update on the same XCD).  The workgroup map stays device_utils.h's task-per-XCD map over all T tasks
+    // (workgroups of tasks outside the group leave at once): numbering a group's workgroups task-major, so that ONE task's tiles go
+    // round all XCDs, was measured - the update of C5 takes 29.3 us instead of 23.9 (tools/lg_bench.hip), the L2 of the task's XCD is
+    // what feeds it.
+    int t_lo, t_hi;
+    __device__ __forceinline__ bool active(int t) const { return t >= t_lo && t < t_hi && (!fit || fit[t].phase != PH_DONE); }
+    __device__ __forceinline__ bool map(int tiles, int& t, int& tile) const { return task_tile(T, tiles, t, tile); }
     __device__ __forceinline__ int n(int t) const { return n_arr ? n_arr[t] : ld; }
 };
 
@@ -43,7 +51,7 @@ __global__ __launch_bounds__(512) void k_lg_diag(LgMat a, int step) {
     constexpr int RB = SW::RB, CB = SW::CB;
     __shared__ SweepSmem<128, 512> sm;
     int t, tile;
-    if (!task_tile(a.T, 1, t, tile)) return;
+    if (!a.map(1, t, tile)) return;
     if (!a.active(t)) return;
     const int n = a.n(t), p0 = step * LB;
     const int nloc = min(LB, n - p0);
@@ -98,6 +106,7 @@ struct ProbLgPanel {
     static constexpr int NRED = 0;
     LgMat m; int step;
     int n, p0, nloc; const float *Dv, *Mi; float *Cb, *Fb; bool vec;
+    __device__ bool map(int tiles, int& t, int& tile) const { return m.map(tiles, t, tile); }
     __device__ bool setup(int t) {
         if (!m.active(t)) return false;
         n = m.n(t); p0 = step * LB; nloc = min(LB, n - p0); vec = m.vec;
@@ -122,6 +131,20 @@ struct ProbLgPanel {
         Fb[(size_t)i * m.ld + j] = acc;
         Cb[(size_t)i * m.ld + j] = Mi[(size_t)(p0 + i) * m.ld + j];
     }
+    // full block steps (K = 128 = DEEP chunks): all operand loads and the snapshot's source in flight before the first MFMA (gemm.h)
+    static constexpr int DEEP = LB / GK;
+    __device__ void pre4(int i0, int j, float (&v)[4]) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = Mi[(size_t)(p0 + i0 + r) * m.ld + j];
+    }
+    __device__ void epi4(int i0, int j, const float (&acc)[4], float* red) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) epi(i0 + r, j, acc[r], red);
+    }
+    __device__ void epi4p(int i0, int j, const float (&acc)[4], const float (&pre)[4], float*) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { Fb[(size_t)(i0 + r) * m.ld + j] = acc[r]; Cb[(size_t)(i0 + r) * m.ld + j] = pre[r]; }
+    }
     __device__ void store_red(int, const float*) const {}
 };
 
@@ -130,6 +153,20 @@ struct ProbLgUpdate {
     static constexpr int NRED = 0;
     LgMat m; int step;
     int n, p0, nloc; const float *Dv, *Cb, *Fb; float* Mi; bool vec;
+    int tri;   // > 0: the launch has tri = tn (tn + 1) / 2 workgroups per task, one per tile on or above the diagonal (the others would exit at once)
+    __device__ bool map(int tiles, int& t, int& tile) const {
+        if (tri <= 0) return m.map(tiles, t, tile);
+        int u;
+        if (!m.map(tri, t, u)) return false;
+        // row ti of the upper triangle starts at ti tn - ti (ti - 1) / 2
+        const int tn = (int)((sqrtf(8.f * (float)tri + 1.f) - 1.f) * 0.5f + 0.5f);
+        int ti = (int)(((float)(2 * tn + 1) - sqrtf((float)((2 * tn + 1) * (2 * tn + 1) - 8 * u))) * 0.5f);
+        ti = max(0, min(ti, tn - 1));
+        while (ti > 0 && ti * tn - ti * (ti - 1) / 2 > u) --ti;
+        while (ti + 1 < tn && (ti + 1) * tn - (ti + 1) * ti / 2 <= u) ++ti;
+        tile = ti * tn + ti + (u - (ti * tn - ti * (ti - 1) / 2));
+        return true;
+    }
     __device__ bool setup(int t) {
         if (!m.active(t)) return false;
         n = m.n(t); p0 = step * LB; nloc = min(LB, n - p0); vec = m.vec;
@@ -187,6 +224,19 @@ struct ProbLgUpdate {
         }
         *reinterpret_cast<float4*>(Mi + (size_t)j * m.ld + i0) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    // a DEEP tile is a computed one: above or on the diagonal, outside the pivot rows and columns
+    static constexpr int DEEP = LB / GK;
+    __device__ void pre4(int i0, int j, float (&v)[4]) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = Mi[(size_t)(i0 + r) * m.ld + j];
+    }
+    __device__ void epi4p(int i0, int j, const float (&acc)[4], const float (&pre)[4], float*) const {
+        const bool mirror = (i0 >> 6) < (j >> 6);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = pre[r] - acc[r]; Mi[(size_t)(i0 + r) * m.ld + j] = v[r]; }
+        if (mirror) *reinterpret_cast<float4*>(Mi + (size_t)j * m.ld + i0) = make_float4(v[0], v[1], v[2], v[3]);
+    }
     __device__ void store_red(int, const float*) const {}
 };
 
@@ -229,7 +279,7 @@ __global__ void k_lg_begin(LgInner a) {
 // M = s kappa(D2 / l^2) + noise I at the trial point of the task's state machine (64 x 64 tile per workgroup)
 __global__ __launch_bounds__(256) void k_lg_build(LgInner a) {
     int t, tile;
-    if (!task_tile(a.in.T, a.ntiles, t, tile)) return;
+    if (!a.mat.map(a.ntiles, t, tile)) return;
     if (!a.mat.active(t)) return;
     const int n = a.mat.n(t), ld = a.in.ld;
     const int m0 = (tile / a.tiles_1d) * GT, n0 = (tile % a.tiles_1d) * GT;
@@ -258,7 +308,7 @@ __global__ __launch_bounds__(256) void k_lg_traces(LgInner a) {
     __shared__ float red[3 * 4];
     __shared__ float redmax[4];
     int t, tile;
-    if (!task_tile(a.in.T, a.ntiles, t, tile)) return;
+    if (!a.mat.map(a.ntiles, t, tile)) return;
     if (!a.mat.active(t)) return;
     const int n = a.mat.n(t), ld = a.in.ld;
     const int m0 = (tile / a.tiles_1d) * GT, n0 = (tile % a.tiles_1d) * GT;
@@ -312,7 +362,7 @@ __global__ __launch_bounds__(64) void k_lg_advance(LgInner a) {
     const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= a.in.T) return;
     FitShared& fs = a.fit[t];
-    if (fs.phase == PH_DONE) return;
+    if (!a.mat.active(t)) return;
     const int n = a.mat.n(t);
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float dmax = 0.f;
