@@ -217,101 +217,19 @@ LgMat lg_mat(const Workspace& w, float* M, int ld, const int32_t* n_arr, const F
     m.M = M; m.ld = ld; m.n_arr = n_arr; m.fit = fit;
     m.Dinv = w.lg_Dinv; m.Cbuf = w.lg_C; m.Fbuf = w.lg_F; m.logdet = w.lg_logdet; m.pext = w.lg_pext; m.info = w.lg_info;
     m.T = T; m.vec = (ld & 3) == 0;
-    m.t_lo = 0; m.t_hi = T;
     return m;
 }
 
-// workgroups of a launch over `tiles` tiles per task of m's group
-inline int lg_grid(const LgMat& m, int tiles) { return grid_for(m.T, tiles); }
-
-struct LgGroups;
-void lg_fork(LgGroups* g);
-
-// M -> -(M^-1) in place by 128-pivot block steps (large.h), for the tasks of m's group; stagger: the other groups' streams are let go
-// after THIS group's first diagonal block, so that they run half a block step behind (see LgGroups)
-void lg_sweep(const LgMat& m, hipStream_t st, LgGroups* stagger = nullptr) {
+// M -> -(M^-1) in place by 128-pivot block steps (large.h)
+void lg_sweep(const LgMat& m, hipStream_t st) {
     const int nb = ceil_div(m.ld, LB), tn = ceil_div(m.ld, GT);
     for (int step = 0; step < nb; ++step) {
-        k_lg_diag<<<lg_grid(m, 1), 512, 0, st>>>(m, step);
-        if (step == 0 && stagger) lg_fork(stagger);
+        k_lg_diag<<<grid_for(m.T, 1), 512, 0, st>>>(m, step);
         ProbLgPanel pp; pp.m = m; pp.step = step;
-        k_bgemm<ProbLgPanel><<<lg_grid(m, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn);
+        k_bgemm<ProbLgPanel><<<grid_for(m.T, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn);
         ProbLgUpdate pu; pu.m = m; pu.step = step; pu.tri = tn * (tn + 1) / 2;   // workgroups for the tiles on or above the diagonal only
-        k_bgemm<ProbLgUpdate><<<lg_grid(m, pu.tri), 256, 0, st>>>(pu, m.T, tn, tn);
+        k_bgemm<ProbLgUpdate><<<grid_for(m.T, pu.tri), 256, 0, st>>>(pu, m.T, tn, tn);
     }
-}
-
-// Task groups of the blocked path.  A block step is three dependent launches, and the first of them (k_lg_diag: the 128-pivot sweep
-// of the diagonal block) is ONE workgroup per task: at C5 (8 tasks) 248 of 256 CUs wait 24 us of every 57.  Tasks do not depend on
-// each other, so the batch is cut into groups whose launch sequences go to different streams: one group's diagonal sweeps run under
-// another group's trailing update.  Nothing is exchanged between the streams inside a fit - one fork and one join per fit (and per
-// poll of the convergence mode), unlike the look-ahead of round 1 that paid two event hand-offs per block step (large.h).
-// The side streams and events are created once per host thread and device and live as long as the thread; while the caller's
-// stream is being captured into a graph the path stays on that one stream.
-// ADKF_LG_GROUPS (read once): number of groups (1 = off; default 2 from 2 tasks on, at most 4); ADKF_LG_SPREAD = 0 keeps the
-// task-per-XCD workgroup map inside a group (default 1: a group's tiles go round all XCDs).
-constexpr int LG_MAXG = 4;
-struct LgGroups {
-    int n = 1;
-    hipStream_t s[LG_MAXG];
-    int lo[LG_MAXG], hi[LG_MAXG];
-    hipEvent_t fork_ev = nullptr, join_ev[LG_MAXG] = {nullptr, nullptr, nullptr, nullptr};
-    bool ok = true;
-    LgGroups(int T, hipStream_t st) {
-        static const int want = [] { const char* e = getenv("ADKF_LG_GROUPS"); return e ? atoi(e) : 0; }();
-        s[0] = st; lo[0] = 0; hi[0] = T;
-        // (task t lives on XCD t % 8: with contiguous halves and 16 tasks or more every XCD hosts tasks of both groups; with fewer,
-        // the groups would sit on different XCDs and have nothing to hide from each other)
-        int g = want > 0 ? std::max(1, std::min(std::min(want, LG_MAXG), T)) : (T >= 16 ? 2 : 1);
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (g > 1 && (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)) g = 1;
-        if (g > 1) {
-            struct Side { int dev = -1; hipStream_t s[LG_MAXG - 1]; hipEvent_t fork_ev, join_ev[LG_MAXG - 1]; };
-            thread_local Side side[16];
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) g = 1;
-            else {
-                Side& sd = side[dev];
-                if (sd.dev != dev) {
-                    bool made = hipEventCreateWithFlags(&sd.fork_ev, hipEventDisableTiming) == hipSuccess;
-                    for (int q = 0; q < LG_MAXG - 1 && made; ++q)
-                        made = hipStreamCreateWithFlags(&sd.s[q], hipStreamNonBlocking) == hipSuccess &&
-                               hipEventCreateWithFlags(&sd.join_ev[q], hipEventDisableTiming) == hipSuccess;
-                    if (made) sd.dev = dev; else g = 1;
-                }
-                if (g > 1) {
-                    fork_ev = sd.fork_ev;
-                    for (int q = 1; q < g; ++q) { s[q] = sd.s[q - 1]; join_ev[q] = sd.join_ev[q - 1]; }
-                }
-            }
-        }
-        n = g;
-        for (int q = 0; q < n; ++q) { lo[q] = (int)((long)T * q / n); hi[q] = (int)((long)T * (q + 1) / n); }
-    }
-    LgMat of(LgMat m, int q) const { m.t_lo = lo[q]; m.t_hi = hi[q]; return m; }
-    // the side streams wait for everything enqueued on the caller's stream so far
-    void fork() {
-        if (n == 1) return;
-        ok = ok && hipEventRecord(fork_ev, s[0]) == hipSuccess;
-        for (int q = 1; q < n; ++q) ok = ok && hipStreamWaitEvent(s[q], fork_ev, 0) == hipSuccess;
-    }
-    // the caller's stream waits for everything enqueued on the side streams so far
-    void join() {
-        for (int q = 1; q < n; ++q) {
-            ok = ok && hipEventRecord(join_ev[q], s[q]) == hipSuccess;
-            ok = ok && hipStreamWaitEvent(s[0], join_ev[q], 0) == hipSuccess;
-        }
-    }
-};
-
-void lg_fork(LgGroups* g) { g->fork(); }
-
-// the block sweep of a whole batch (outer stage: one sweep per step), group by group on the groups' streams
-void lg_sweep_grouped(const LgMat& m, hipStream_t st, bool& ok) {
-    LgGroups G(m.T, st);
-    for (int q = 0; q < G.n; ++q) lg_sweep(G.of(m, q), G.s[q], q == 0 ? &G : nullptr);
-    G.join();
-    ok = G.ok;
 }
 
 // Convergence-mode early exit for the fits that are a sequence of launches (blocked path, ARD): every POLL_EVERY
@@ -341,9 +259,8 @@ struct FitPoll {
         enabled = true;
     }
     // true when every task has finished (call after the advance kernel of evaluation e)
-    bool due(int e) const { return enabled && (e + 1) % POLL_EVERY == 0; }
     bool finished(int e, const void* state, size_t stride, size_t phase_offset, int T, hipStream_t st, int done_value = PH_DONE) {
-        if (!due(e)) return false;
+        if (!enabled || (e + 1) % POLL_EVERY != 0) return false;
         k_count_unfinished<<<1, 64, 0, st>>>(static_cast<const char*>(state), stride, phase_offset, T, done_value, dev);
         if (hipMemcpyAsync(host, dev, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
         if (hipStreamSynchronize(st) != hipSuccess) return false;
@@ -360,28 +277,14 @@ int launch_inner_large(const InnerArgs& a, const Workspace& w, hipStream_t st) {
     k_lg_begin<<<ceil_div(a.T, 64), 64, 0, st>>>(li);
     const int n_evals = a.max_evals > 0 ? a.max_evals : 1;
     FitPoll poll(a.max_evals > 0 && !a.exact_evals, a.max_evals, w.lg_info, st);   // lg_info[0] is free between block sweeps
-    LgGroups G(a.T, st);
-    bool forked = false;
     for (int e = 0; e < n_evals; ++e) {
-        for (int q = 0; q < G.n; ++q) {
-            LgInner lq = li; lq.mat = G.of(li.mat, q);
-            LgMatvecArgs mq = mv; mq.m = lq.mat;
-            hipStream_t sq = G.s[q];
-            k_lg_build<<<lg_grid(lq.mat, li.ntiles), 256, 0, sq>>>(lq);
-            lg_sweep(lq.mat, sq, (q == 0 && !forked) ? &G : nullptr);
-            forked = true;
-            k_lg_matvec<<<dim3(ceil_div(a.ld, 4), a.T), 256, 0, sq>>>(mq);
-            k_lg_traces<<<lg_grid(lq.mat, li.ntiles), 256, 0, sq>>>(lq);
-            k_lg_advance<<<a.T, 64, 0, sq>>>(lq);
-        }
-        if (poll.due(e)) {
-            G.join();
-            if (poll.finished(e, w.lg_fit, sizeof(FitShared), offsetof(FitShared, phase), a.T, st)) break;
-            forked = false;
-        }
+        k_lg_build<<<grid_for(a.T, li.ntiles), 256, 0, st>>>(li);
+        lg_sweep(li.mat, st);
+        k_lg_matvec<<<dim3(ceil_div(a.ld, 4), a.T), 256, 0, st>>>(mv);
+        k_lg_traces<<<grid_for(a.T, li.ntiles), 256, 0, st>>>(li);
+        k_lg_advance<<<a.T, 64, 0, st>>>(li);
+        if (poll.finished(e, w.lg_fit, sizeof(FitShared), offsetof(FitShared, phase), a.T, st)) break;
     }
-    G.join();   // (again after a poll that ended the loop: a second wait on an event that has completed costs nothing)
-    if (!G.ok) return ADKF_E_LAUNCH;
     LAUNCH_OK();
     return 0;
 }
@@ -487,9 +390,7 @@ int launch_outer_factor(const OuterArgs& a, const Workspace& w, int nq, hipStrea
     if (nq > REG_POINTS) {
         k_lg_resid<<<dim3(ceil_div(nq, 4), a.T), 256, 0, st>>>(a);
         LgMat m = lg_mat(w, a.S, a.tv.nq_ld, a.tv.n_q, nullptr, a.T);
-        bool groups_ok = true;
-        lg_sweep_grouped(m, st, groups_ok);
-        if (!groups_ok) return ADKF_E_LAUNCH;
+        lg_sweep(m, st);
         LgMatvecArgs mv{m, a.vecs + (size_t)V_R * a.tv.vld, (size_t)NVEC * a.tv.vld, a.vecs + (size_t)V_E * a.tv.vld, (size_t)NVEC * a.tv.vld, -1.f};
         k_lg_matvec<<<dim3(ceil_div(nq, 4), a.T), 256, 0, st>>>(mv);
         const int tn = ceil_div(nq, GT);

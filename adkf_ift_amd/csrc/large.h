@@ -8,7 +8,12 @@
 //                   their epilogue writes F_R, F_R^T and -Dinv
 //   after the last step M = -(A^-1).
 // (A look-ahead that factorises the next diagonal block on a side stream while the rest of the update runs was measured:
-//  the two event hand-offs per block step cost more than the overlap buys - C5 15.6 -> 17.4 ms, N = 256: 4.8 -> 5.3 ms.)
+//  the two event hand-offs per block step cost more than the overlap buys - C5 15.6 -> 17.4 ms, N = 256: 4.8 -> 5.3 ms.
+//  Round 4 tried the event-free version - the batch cut into task groups whose launch sequences run on streams of their own, one
+//  fork and one join per fit, so that one group's diagonal sweeps sit under another group's update (commit ef34797): the kernels do
+//  overlap (profiles/r04_c5_groups.txt) but a task's launches only ever use the 32 CUs of its XCD, so with 8 tasks there is nothing
+//  on an XCD to hide behind (C5 13.5 -> 15.0 ms), and from 16 tasks on the gain is 3-5 % (16 x 1024: 18.0 -> 17.2 ms; 32 x 512:
+//  7.89 -> 7.63; 64 x 256: 3.60 -> 3.79, slower) - removed again.  What did pay: DEEP and the upper-triangle grid below.)
 //
 // One MLL evaluation = k_lg_build (kernel matrix from the squared distances) + the block steps + k_lg_matvec (alpha) +
 // k_lg_traces (the three O(N^2) reductions; also flips the sign in place) + k_lg_advance (value, gradient, and one
@@ -34,15 +39,7 @@ struct LgMat {
     float* pext;            // [T, 2] smallest / largest pivot so far: the condition estimate that picks the float64 path (refine64.h)
     int32_t* info;          // [T] first non-positive pivot (1-based) or 0
     int T; bool vec;
-    // Task groups (adkf_gp.hip, LgGroups): a launch serves the tasks [t_lo, t_hi) only, so that groups on different streams are at
-    // different stages of their block steps at the same time (one group's 128-pivot diagonal sweeps - one workgroup per task - under
-    // another group's trailing update on the same XCD).  The workgroup map stays device_utils.h's task-per-XCD map over all T tasks
-    // (workgroups of tasks outside the group leave at once): numbering a group's workgroups task-major, so that ONE task's tiles go
-    // round all XCDs, was measured - the update of C5 takes 29.3 us instead of 23.9 (tools/lg_bench.hip), the L2 of the task's XCD is
-    // what feeds it.
-    int t_lo, t_hi;
-    __device__ __forceinline__ bool active(int t) const { return t >= t_lo && t < t_hi && (!fit || fit[t].phase != PH_DONE); }
-    __device__ __forceinline__ bool map(int tiles, int& t, int& tile) const { return task_tile(T, tiles, t, tile); }
+    __device__ __forceinline__ bool active(int t) const { return !fit || fit[t].phase != PH_DONE; }
     __device__ __forceinline__ int n(int t) const { return n_arr ? n_arr[t] : ld; }
 };
 
@@ -51,7 +48,7 @@ __global__ __launch_bounds__(512) void k_lg_diag(LgMat a, int step) {
     constexpr int RB = SW::RB, CB = SW::CB;
     __shared__ SweepSmem<128, 512> sm;
     int t, tile;
-    if (!a.map(1, t, tile)) return;
+    if (!task_tile(a.T, 1, t, tile)) return;
     if (!a.active(t)) return;
     const int n = a.n(t), p0 = step * LB;
     const int nloc = min(LB, n - p0);
@@ -106,7 +103,6 @@ struct ProbLgPanel {
     static constexpr int NRED = 0;
     LgMat m; int step;
     int n, p0, nloc; const float *Dv, *Mi; float *Cb, *Fb; bool vec;
-    __device__ bool map(int tiles, int& t, int& tile) const { return m.map(tiles, t, tile); }
     __device__ bool setup(int t) {
         if (!m.active(t)) return false;
         n = m.n(t); p0 = step * LB; nloc = min(LB, n - p0); vec = m.vec;
@@ -155,9 +151,9 @@ struct ProbLgUpdate {
     int n, p0, nloc; const float *Dv, *Cb, *Fb; float* Mi; bool vec;
     int tri;   // > 0: the launch has tri = tn (tn + 1) / 2 workgroups per task, one per tile on or above the diagonal (the others would exit at once)
     __device__ bool map(int tiles, int& t, int& tile) const {
-        if (tri <= 0) return m.map(tiles, t, tile);
+        if (tri <= 0) return task_tile(m.T, tiles, t, tile);
         int u;
-        if (!m.map(tri, t, u)) return false;
+        if (!task_tile(m.T, tri, t, u)) return false;
         // row ti of the upper triangle starts at ti tn - ti (ti - 1) / 2
         const int tn = (int)((sqrtf(8.f * (float)tri + 1.f) - 1.f) * 0.5f + 0.5f);
         int ti = (int)(((float)(2 * tn + 1) - sqrtf((float)((2 * tn + 1) * (2 * tn + 1) - 8 * u))) * 0.5f);
@@ -279,7 +275,7 @@ __global__ void k_lg_begin(LgInner a) {
 // M = s kappa(D2 / l^2) + noise I at the trial point of the task's state machine (64 x 64 tile per workgroup)
 __global__ __launch_bounds__(256) void k_lg_build(LgInner a) {
     int t, tile;
-    if (!a.mat.map(a.ntiles, t, tile)) return;
+    if (!task_tile(a.in.T, a.ntiles, t, tile)) return;
     if (!a.mat.active(t)) return;
     const int n = a.mat.n(t), ld = a.in.ld;
     const int m0 = (tile / a.tiles_1d) * GT, n0 = (tile % a.tiles_1d) * GT;
@@ -308,7 +304,7 @@ __global__ __launch_bounds__(256) void k_lg_traces(LgInner a) {
     __shared__ float red[3 * 4];
     __shared__ float redmax[4];
     int t, tile;
-    if (!a.mat.map(a.ntiles, t, tile)) return;
+    if (!task_tile(a.in.T, a.ntiles, t, tile)) return;
     if (!a.mat.active(t)) return;
     const int n = a.mat.n(t), ld = a.in.ld;
     const int m0 = (tile / a.tiles_1d) * GT, n0 = (tile % a.tiles_1d) * GT;
@@ -362,7 +358,7 @@ __global__ __launch_bounds__(64) void k_lg_advance(LgInner a) {
     const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= a.in.T) return;
     FitShared& fs = a.fit[t];
-    if (!a.mat.active(t)) return;
+    if (fs.phase == PH_DONE) return;
     const int n = a.mat.n(t);
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float dmax = 0.f;
