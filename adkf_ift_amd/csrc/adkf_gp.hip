@@ -97,7 +97,11 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
         w.lg_fit = reinterpret_cast<FitShared*>(take(Tz * ((sizeof(FitShared) + 3) / 4)));
     }
     w.w64 = nullptr; w.w64_stride = 0;
-    if (w.vld <= R64_MAXN) {
+    // the float64 region of refine64.h is carved for EVERY task (any of them may turn out ill-conditioned): 8 refine64_doubles(ns, nq)
+    // bytes per task - 1.3 MB at 128 points, 5.2 MB at 256, 82 MB at 1024 (1.7 x the float32 part of the workspace).  ADKF_R64_MAXN
+    // (read once) lowers the largest batch that gets one, e.g. 256: tasks beyond it stay on the float32 path whatever their conditioning
+    static const int r64_maxn = [] { const char* e = getenv("ADKF_R64_MAXN"); const int v = e ? atoi(e) : R64_MAXN; return v < R64_MAXN ? v : R64_MAXN; }();
+    if (w.vld <= r64_maxn) {
         w.w64_stride = refine64_doubles(ns, nq);
         w.w64 = reinterpret_cast<double*>(take(2 * Tz * w.w64_stride));
     }

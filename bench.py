@@ -375,13 +375,13 @@ def main():
                 traffic = (2.0 * pm["FETCH_SIZE_KB_per_launch"] + pm["WRITE_SIZE_KB_per_launch"]) * 1024.0
                 traffic_src = {"file": "profiles/r04_k_inner_pmc.json", "commit": pm.get("commit"),
                                "correction": "2 x FETCH_SIZE + WRITE_SIZE"}
-            pmc5 = os.path.join(ROOT, "profiles", "r03_c5_fit_pmc.json")
+            pmc5 = os.path.join(ROOT, "profiles", "r04_c5_fit_pmc.json")
             if os.path.exists(pmc5) and (T, N, Nq, d, I) == (8, 1024, 1024, 512, 20) and args.kernel == "rbf" and not args.ard and not args.regression:
                 with open(pmc5) as fh:
                     pm = json.load(fh)
                 traffic = (2.0 * pm["FETCH_SIZE_KB_per_fit"] + pm["WRITE_SIZE_KB_per_fit"]) * 1024.0
-                traffic_src = {"file": "profiles/r03_c5_fit_pmc.json", "commit": pm.get("commit"),
-                               "correction": "2 x FETCH_SIZE + WRITE_SIZE, summed over the launches of one fit"}
+                traffic_src = {"file": "profiles/r04_c5_fit_pmc.json", "commit": pm.get("commit"),
+                               "correction": "2 x FETCH_SIZE + WRITE_SIZE, summed over the launches of one adkf_fit call (by dispatch order)"}
             if args.ard:
                 fit_kernel, bound = "ARD inner fit (all launches between the two events)", "mfma"
             elif N <= 128:

@@ -110,7 +110,11 @@ const char* adkf_last_hip_error(void);
 /* Largest support/query set this build handles in its LDS-resident factorisation. */
 int adkf_max_points(void);
 
-/* Bytes of device workspace every call below needs for a batch of this shape. */
+/* Bytes of device workspace every call below needs for a batch of this shape: per task 4 (4 ns^2 + 4 nq ns + 3 nq^2) bytes of
+ * float32 matrices (+ three 128-row panels beyond 128 points) and, up to 1024 points, the float64 region of the ill-conditioned-task
+ * path (csrc/refine64.h; about 1.7 x the float32 part: 1.3 MB per task at 128 points, 82 MB at 1024 - every task has one, any of
+ * them may be flagged).  Environment ADKF_R64_MAXN=<points> (read once) lowers the batch size up to which that region is carved;
+ * larger batches then stay in float32 whatever their conditioning. */
 size_t adkf_workspace_bytes(int32_t T, int32_t ns_max, int32_t nq_max, int32_t d);
 
 /* a3: ADKTModel.compute_median_lengthscale_init (fs_mol/models/adaptive_dkt.py:128-131):

@@ -3,7 +3,8 @@
 profiles/r03_bench_kernel_stats.csv, r03_k_inner_pmc.json (FETCH_SIZE / WRITE_SIZE per launch), r03_k_inner_sq_pmc.json
 (SQ, LDS and MFMA counters per launch), r03_c5_kernel_stats.csv and r03_c5_fit_pmc.json (traffic of one blocked fit).
     python tools/make_pmc_json.py [commit]            (round 3 layout)
-    python tools/make_pmc_json.py r04 [commit]        (round 4: tools/round4_profiles.sh; k_inner AND k_hyper, profiles/r04_*)"""
+    python tools/make_pmc_json.py r04 [commit]        (round 4: tools/round4_profiles.sh; k_inner AND k_hyper, profiles/r04_*)
+    python tools/make_pmc_json.py c5 [commit]         (round 4: tools/r04_c5_pmc.sh; traffic of one blocked fit by dispatch order)"""
 import csv
 import glob
 import json
@@ -83,7 +84,52 @@ def main_r04(commit):
         print(sqo)
 
 
+def main_c5(commit):
+    """Round 4, configuration 5: traffic of ONE blocked inner fit, attributed by dispatch order - the dispatches from k_lg_begin up to
+    the last k_lg_advance before a kernel that is not part of the fit (the blocked sweep of Sigma_q in the outer stage uses the same
+    k_lg_diag / ProbLg* kernels and is NOT counted).  Input: tools/r04_c5_pmc.sh."""
+    prof = os.path.join(ROOT, "profiles")
+    stats5 = glob.glob(os.path.join(OUT, "prof_r04_c5b", "**", "*kernel_stats.csv"), recursive=True)
+    if stats5:
+        shutil.copy(stats5[0], os.path.join(prof, "r04_c5_kernel_stats.csv"))
+    fit_set = ("k_lg_begin", "k_lg_build", "k_lg_diag", "ProbLgPanel", "ProbLgUpdate", "k_lg_matvec", "k_lg_traces", "k_lg_advance")
+
+    def fit_totals(pattern, counter):
+        per = {}
+        for row in counter_rows(pattern):
+            if row["Counter_Name"] == counter:
+                d = per.setdefault(int(row["Dispatch_Id"]), [row["Kernel_Name"], 0.0])
+                d[1] += float(row["Counter_Value"])
+        fits, cur, in_fit, launches = [], 0.0, False, 0
+        for did in sorted(per):
+            name, val = per[did]
+            is_fit = any(k in name for k in fit_set)
+            if "k_lg_begin" in name:
+                in_fit, cur, launches = True, 0.0, 0
+            if in_fit and not is_fit:
+                fits.append((cur, launches))
+                in_fit = False
+            if in_fit:
+                cur += val
+                launches += 1
+        return fits
+
+    f, w = fit_totals("prof_r04_c5_fetch", "FETCH_SIZE"), fit_totals("prof_r04_c5_write", "WRITE_SIZE")
+    c5 = {"workload": "C5: 8 tasks, N=Nq=1024, d=512, I=20 (blocked path, csrc/large.h)", "commit": commit,
+          "FETCH_SIZE_KB_per_fit": sum(v for v, _ in f) / len(f) if f else None, "WRITE_SIZE_KB_per_fit": sum(v for v, _ in w) / len(w) if w else None,
+          "fits": [len(f), len(w)], "launches_per_fit": f[0][1] if f else None,
+          "note": "dispatches of one adkf_fit call by dispatch order (k_lg_begin .. last k_lg_advance): 20 evaluations x (k_lg_build, 8 block steps of "
+                  "k_lg_diag / ProbLgPanel / ProbLgUpdate, k_lg_matvec, k_lg_traces, k_lg_advance); the blocked sweep of Sigma_q in the outer stage is "
+                  "not part of it; separate rocprofv3 --pmc passes; KB as reported by rocprofv3, bench.py applies 2 x FETCH_SIZE + WRITE_SIZE"}
+    with open(os.path.join(prof, "r04_c5_fit_pmc.json"), "w") as fh:
+        json.dump(c5, fh, indent=1)
+    print(c5)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "c5":
+        commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
+        return main_c5(commit)
     if len(sys.argv) > 1 and sys.argv[1] == "r04":
         commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
         return main_r04(commit)
