@@ -69,10 +69,14 @@ SIGNATURES = {
                                     C.c_size_t, C.c_void_p]),
     "adkf_readout_pool": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p] * 7),
     "adkf_readout_pool_backward": (C.c_int, [C.c_void_p] * 10 + [C.c_int32] * 5 + [C.c_void_p] * 6),
+    "adkf_readout_pool_hidden": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32] * 5 + [C.c_void_p] * 9),
+    "adkf_readout_pool_hidden_backward": (C.c_int, [C.c_void_p] * 2 + [C.c_int32] + [C.c_void_p] * 9 + [C.c_int32] * 5 + [C.c_void_p] * 6),
     "adkf_pna_aggregate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "adkf_pna_aggregate_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                               C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "adkf_pna_aggregate_backward_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "adkf_block_combine": (C.c_int, [C.c_void_p] * 8 + [C.c_float, C.c_int32, C.c_int32] + [C.c_void_p] * 5),
     "adkf_block_combine_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "adkf_block_combine_backward": (C.c_int, [C.c_void_p] * 11 + [C.c_int32, C.c_int32] + [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]),

@@ -1058,7 +1058,7 @@ int adkf_msg_backward(const float* x, const adkf_msg_et_t* ets, int32_t n_et, in
                       const float* d_msgs, const int64_t* perm_src, const int64_t* rowptr_src, const int64_t* perm_tgt,
                       const int64_t* rowptr_tgt, int32_t V, float* dcat, float* dx, void* scratch, size_t scratch_bytes, void* stream) {
     (void)hipGetLastError();
-    if (!x || !ets || !msgs || !d_msgs || !dcat || !dx || !perm_src || !rowptr_src || !perm_tgt || !rowptr_tgt) return ADKF_E_BADARG;
+    if (!x || !ets || !d_msgs || !dcat || !dx || !perm_src || !rowptr_src || !perm_tgt || !rowptr_tgt) return ADKF_E_BADARG;   // (msgs may be null: d_msgs already masked)
     if (n_et <= 0 || n_et > MSG_MAX_ET || H <= 0 || in <= 0 || out <= 0 || V <= 0) return ADKF_E_BADARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     MsgArgs m{};
@@ -1067,7 +1067,7 @@ int adkf_msg_backward(const float* x, const adkf_msg_et_t* ets, int32_t n_et, in
     const long e_all = msg_table(m, ets, n_et, true);
     if (e_all < 0) return ADKF_E_BADARG;
     if (m.nsplit_all > 0 && (!scratch || scratch_bytes < adkf_msg_backward_scratch_bytes(ets, n_et, H, in, out))) return ADKF_E_WORKSPACE;
-    m.vec = (in % 4 == 0) && (out % 4 == 0) && aligned16(x) && aligned16(msgs) && aligned16(d_msgs);
+    m.vec = (in % 4 == 0) && (out % 4 == 0) && aligned16(x) && (!msgs || aligned16(msgs)) && aligned16(d_msgs);
     for (int q = 0; q < n_et; ++q) m.vec = m.vec && aligned16(ets[q].W);
     const int total = msg_tiles(m, 2 * in);
     if (total > 0) {
@@ -1123,6 +1123,46 @@ int adkf_readout_pool_backward(const float* v_mean, const float* v_sum, const fl
     return 0;
 }
 
+int adkf_readout_pool_hidden(const float* s_mean, const float* h_mean, const float* s_sum, const float* h_sum, int32_t ldh, const float* emb,
+                             const int64_t* perm, const int64_t* rowptr, int32_t V, int32_t G, int32_t nh, int32_t K, int32_t D,
+                             float* w_mean, float* w_sum, float* p_mean, float* p_sum, float* wtot_mean, float* wtot_sum, float* g_max,
+                             int32_t* argmax, void* stream) {
+    (void)hipGetLastError();
+    if (!s_mean || !h_mean || !s_sum || !h_sum || !emb || !perm || !rowptr || !w_mean || !w_sum || !p_mean || !p_sum || !wtot_mean || !wtot_sum ||
+        !g_max || !argmax)
+        return ADKF_E_BADARG;
+    if (V < 0 || G <= 0 || nh <= 0 || nh > READOUT_MAX_HEADS || K <= 0 || K > 256 * READOUT_KJ_MAX || ldh < K || D <= 0 || D > READOUT_MAX_D) return ADKF_E_BADARG;
+    ReadoutHArgs a{};
+    a.s_mean = s_mean; a.h_mean = h_mean; a.s_sum = s_sum; a.h_sum = h_sum; a.ldh = ldh; a.emb = emb; a.perm = perm; a.rowptr = rowptr;
+    a.w_mean = w_mean; a.w_sum = w_sum; a.p_mean = p_mean; a.p_sum = p_sum; a.wtot_mean = wtot_mean; a.wtot_sum = wtot_sum;
+    a.g_max = g_max; a.argmax = argmax; a.V = V; a.G = G; a.nh = nh; a.K = K; a.D = D;
+    launch_readout_h(a, false, static_cast<hipStream_t>(stream));
+    LAUNCH_OK();
+    return 0;
+}
+
+int adkf_readout_pool_hidden_backward(const float* h_mean, const float* h_sum, int32_t ldh, const float* w_mean, const float* w_sum,
+                                      const int32_t* argmax, const int64_t* perm, const int64_t* rowptr, const float* dp_mean,
+                                      const float* dp_sum, const float* dwtot_sum, const float* dg_max, int32_t V, int32_t G, int32_t nh,
+                                      int32_t K, int32_t D, float* d_s_mean, float* d_h_mean, float* d_s_sum, float* d_h_sum, float* d_emb,
+                                      void* stream) {
+    (void)hipGetLastError();
+    if (!h_mean || !h_sum || !w_mean || !w_sum || !argmax || !perm || !rowptr || !dp_mean || !dp_sum || !dwtot_sum || !dg_max || !d_s_mean ||
+        !d_h_mean || !d_s_sum || !d_h_sum || !d_emb)
+        return ADKF_E_BADARG;
+    if (V < 0 || G <= 0 || nh <= 0 || nh > READOUT_MAX_HEADS || K <= 0 || K > 256 * READOUT_KJ_MAX || ldh < K || D <= 0 || D > READOUT_MAX_D) return ADKF_E_BADARG;
+    if (V == 0) return 0;
+    ReadoutHArgs a{};
+    a.h_mean = h_mean; a.h_sum = h_sum; a.ldh = ldh; a.w_mean = const_cast<float*>(w_mean); a.w_sum = const_cast<float*>(w_sum);
+    a.argmax = const_cast<int32_t*>(argmax); a.perm = perm; a.rowptr = rowptr;
+    a.dp_mean = dp_mean; a.dp_sum = dp_sum; a.dwtot_sum = dwtot_sum; a.dg_max = dg_max;
+    a.d_s_mean = d_s_mean; a.d_h_mean = d_h_mean; a.d_s_sum = d_s_sum; a.d_h_sum = d_h_sum; a.d_emb = d_emb;
+    a.V = V; a.G = G; a.nh = nh; a.K = K; a.D = D;
+    launch_readout_h(a, true, static_cast<hipStream_t>(stream));
+    LAUNCH_OK();
+    return 0;
+}
+
 int adkf_pna_aggregate(const float* msgs, const int64_t* perm, const int64_t* rowptr, int32_t V, int32_t H, int32_t m, float* agg,
                        int32_t* argmax, void* stream) {
     (void)hipGetLastError();
@@ -1137,7 +1177,17 @@ int adkf_pna_aggregate_backward(const float* msgs, const int64_t* perm, const in
                                 const float* d_agg, int32_t V, int32_t H, int32_t m, float* d_msgs, void* stream) {
     (void)hipGetLastError();
     if (!msgs || !perm || !rowptr || !agg || !argmax || !d_agg || !d_msgs || V <= 0 || H <= 0 || m <= 0) return ADKF_E_BADARG;
-    PnaArgs a{msgs, perm, rowptr, const_cast<float*>(agg), const_cast<int32_t*>(argmax), d_agg, d_msgs, V, H, m};
+    PnaArgs a{msgs, perm, rowptr, const_cast<float*>(agg), const_cast<int32_t*>(argmax), d_agg, d_msgs, V, H, m, 0};
+    k_pna_bwd<<<V, 256, 0, static_cast<hipStream_t>(stream)>>>(a);
+    LAUNCH_OK();
+    return 0;
+}
+
+int adkf_pna_aggregate_backward_relu(const float* msgs, const int64_t* perm, const int64_t* rowptr, const float* agg, const int32_t* argmax,
+                                     const float* d_agg, int32_t V, int32_t H, int32_t m, float* d_pre, void* stream) {
+    (void)hipGetLastError();
+    if (!msgs || !perm || !rowptr || !agg || !argmax || !d_agg || !d_pre || V <= 0 || H <= 0 || m <= 0) return ADKF_E_BADARG;
+    PnaArgs a{msgs, perm, rowptr, const_cast<float*>(agg), const_cast<int32_t*>(argmax), d_agg, d_pre, V, H, m, 1};
     k_pna_bwd<<<V, 256, 0, static_cast<hipStream_t>(stream)>>>(a);
     LAUNCH_OK();
     return 0;

@@ -21,6 +21,7 @@ struct PnaArgs {
     float* agg; int32_t* argmax;
     const float* d_agg; float* d_msgs;   // backward only
     int V, H, m;
+    int relu_mask;   // backward: the messages are ReLU outputs and d_msgs is to be the gradient IN FRONT of that ReLU (zero where msgs <= 0)
 };
 
 __global__ __launch_bounds__(256) void k_pna_fwd(PnaArgs a) {
@@ -91,9 +92,15 @@ __global__ __launch_bounds__(256) void k_pna_bwd(PnaArgs a) {
             const int64_t e = a.perm[p];
             const size_t o = ((size_t)e * H + h) * 3 * m;
             const double bb = (double)a.msgs[o + m + f];
-            a.d_msgs[o + f] = d_sum;
-            a.d_msgs[o + m + f] = (float)(((bb * bb > mean * mean) ? 2.0 * bb * g : 0.0) + via_mean);
-            a.d_msgs[o + 2 * m + f] = ((int)e == am) ? d_max : 0.f;
+            float da = d_sum, db = (float)(((bb * bb > mean * mean) ? 2.0 * bb * g : 0.0) + via_mean), dc = ((int)e == am) ? d_max : 0.f;
+            if (a.relu_mask) {   // the consumers (ProbMsgBwdX / BwdW, k_msg_dbias) then read ONE tensor instead of gradient + mask
+                da = a.msgs[o + f] > 0.f ? da : 0.f;
+                db = bb > 0.0 ? db : 0.f;
+                dc = a.msgs[o + 2 * m + f] > 0.f ? dc : 0.f;
+            }
+            a.d_msgs[o + f] = da;
+            a.d_msgs[o + m + f] = db;
+            a.d_msgs[o + 2 * m + f] = dc;
         }
     }
 }
@@ -134,7 +141,7 @@ struct MsgEt {
 
 struct MsgArgs {
     const float* x;            // [V, H, in]
-    float* msgs;               // [E_all, H, out]
+    float* msgs;               // [E_all, H, out]; backward: null = d_msgs is already the gradient in front of the ReLU (PnaArgs::relu_mask)
     const float* d_msgs;       // backward
     float* dcat;               // [E_all, H, 2 in]
     float* part;               // [nsplit_all, H * 2 in * out + H * out]: per-chunk partials of d W | d b
@@ -196,14 +203,14 @@ __global__ __launch_bounds__(256) void k_msg_dbias(MsgArgs m) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const size_t o = (size_t)(et.e_off + e + 4 * u) * width + c;
-                dv[u] = m.d_msgs[o]; mv[u] = m.msgs[o];
+                dv[u] = m.d_msgs[o]; mv[u] = m.msgs ? m.msgs[o] : 1.f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += mv[u] > 0.f ? dv[u] : 0.f;
         }
         for (; e < e1; e += 4) {
             const size_t o = (size_t)(et.e_off + e) * width + c;
-            s += m.msgs[o] > 0.f ? m.d_msgs[o] : 0.f;
+            s += (!m.msgs || m.msgs[o] > 0.f) ? m.d_msgs[o] : 0.f;
         }
     }
     part[g][cl] = s;
@@ -312,15 +319,18 @@ struct ProbMsgBwdX {
     __device__ int M() const { return E; } __device__ int N() const { return 2 * m.in; } __device__ int K() const { return m.out; }
     __device__ float a(int i, int k) const {
         const size_t o = ((size_t)(e_off + i) * m.H + h) * m.out + k;
-        return m.msgs[o] > 0.f ? m.d_msgs[o] : 0.f;
+        return (!m.msgs || m.msgs[o] > 0.f) ? m.d_msgs[o] : 0.f;
     }
     __device__ float b(int k, int j) const { return W[((size_t)h * 2 * m.in + j) * m.out + k]; }
     __device__ void a4(int i, int k, float (&v)[4]) const {
         const size_t o = ((size_t)(e_off + i) * m.H + h) * m.out + k;
-        float ms[4];
-        ld4(m.d_msgs + o, v); ld4(m.msgs + o, ms);
+        ld4(m.d_msgs + o, v);
+        if (m.msgs) {
+            float ms[4];
+            ld4(m.msgs + o, ms);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = ms[q] > 0.f ? v[q] : 0.f;
+            for (int q = 0; q < 4; ++q) v[q] = ms[q] > 0.f ? v[q] : 0.f;
+        }
     }
     __device__ void b4(int k, int j, float (&v)[4]) const { ld4(W + ((size_t)h * 2 * m.in + j) * m.out + k, v); }
     __device__ void epi(int i, int j, float acc, float*) const {
@@ -350,15 +360,18 @@ struct ProbMsgBwdW {
     __device__ float a(int i, int k) const { return *arow(i, k); }
     __device__ float b(int k, int j) const {
         const size_t o = ((size_t)(e_off + e0 + k) * m.H + h) * m.out + j;
-        return m.msgs[o] > 0.f ? m.d_msgs[o] : 0.f;
+        return (!m.msgs || m.msgs[o] > 0.f) ? m.d_msgs[o] : 0.f;
     }
     __device__ void a4(int i, int k, float (&v)[4]) const { ld4(arow(i, k), v); }
     __device__ void b4(int k, int j, float (&v)[4]) const {
         const size_t o = ((size_t)(e_off + e0 + k) * m.H + h) * m.out + j;
-        float ms[4];
-        ld4(m.d_msgs + o, v); ld4(m.msgs + o, ms);
+        ld4(m.d_msgs + o, v);
+        if (m.msgs) {
+            float ms[4];
+            ld4(m.msgs + o, ms);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = ms[q] > 0.f ? v[q] : 0.f;
+            for (int q = 0; q < 4; ++q) v[q] = ms[q] > 0.f ? v[q] : 0.f;
+        }
     }
     __device__ void epi(int i, int j, float acc, float*) const {
         m.part[(size_t)sp * msg_part_stride(m.H, m.in, m.out) + ((size_t)h * 2 * m.in + i) * m.out + j] = acc;

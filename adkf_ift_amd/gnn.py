@@ -32,6 +32,8 @@ import torch.nn.functional as F
 
 SMALL_NUMBER = 1e-7
 _FUSED_BLOCK = __import__("os").environ.get("ADKF_GNN_FUSED_BLOCK", "1") != "0"   # diagnostics: 0 keeps the PyTorch ops in the middle of a block
+_FUSED_MP = __import__("os").environ.get("ADKF_GNN_FUSED_MP", "1") != "0"   # diagnostics: 0 keeps message functions and aggregation as two autograd nodes
+_POOL_HIDDEN = __import__("os").environ.get("ADKF_READOUT_POOL_HIDDEN", "1") != "0"   # diagnostics: 0 pools the value MLPs' outputs (round 3's order)
 NUM_NODE_FEATURES = 32   # fs_mol/data/fsmol_dataset.py:21
 NUM_EDGE_TYPES = 3       # fs_mol/data/fsmol_dataset.py:22
 PNA_DELTA = 1.1515       # fs_mol/modules/gnn.py:237
@@ -204,10 +206,13 @@ class TowerMessagePassing(nn.Module):
         if x.is_cuda and x.dtype == torch.float32 and self.depth == 1 and self.kind != "plain":
             # GPU fast path (csrc/pna.h): per edge type ONE batched MFMA GEMM that gathers source / target states on the fly
             # and applies bias + ReLU in its epilogue, then ONE aggregation kernel; no fallback here - a missing library raises
-            msgs = _MessageFunction.apply(x.contiguous(), plan, H, self.in_dim, self.out_msg, *self.weights, *self.biases)
+            if _FUSED_MP and self.out_msg == 3 * m:
+                agg, amax, msgs = _MessagePass.apply(x.contiguous(), plan, H, self.in_dim, self.out_msg, *self.weights, *self.biases)
+            else:
+                msgs = _MessageFunction.apply(x.contiguous(), plan, H, self.in_dim, self.out_msg, *self.weights, *self.biases)
+                agg, amax = _PNAAggregate.apply(msgs, plan.perm, plan.rowptr, V)
             if self.capture is not None:
                 self.capture.append(msgs.detach())
-            agg, amax = _PNAAggregate.apply(msgs, plan.perm, plan.rowptr, V)
             if self.capture_argmax is not None:
                 self.capture_argmax.append(amax)
             if self.kind == "pna" and scale:
@@ -354,6 +359,66 @@ class _PNAAggregate(torch.autograd.Function):
                                                    C.c_void_p(agg.data_ptr()), C.c_void_p(argmax.data_ptr()), C.c_void_p(d_agg.data_ptr()),
                                                    V, H, m4 // 4, C.c_void_p(d_msgs.data_ptr()), st), "adkf_pna_aggregate_backward")
         return d_msgs, None, None, None
+
+
+class _MessagePass(torch.autograd.Function):
+    """``_MessageFunction`` followed by ``_PNAAggregate`` as ONE node of the graph: x -> (agg [V, H, 4m], argmax, msgs).  Same
+    kernels forward; in the backward the aggregation kernel writes the gradient in front of the messages' ReLU
+    (``adkf_pna_aggregate_backward_relu``) and the three products of ``adkf_msg_backward`` read that one tensor instead of
+    gradient + mask - they are bound by exactly that traffic (csrc/pna.h).  ``msgs`` is returned for diagnostics only."""
+
+    @staticmethod
+    def forward(ctx, x, plan, H, in_dim, out_dim, *params):
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        n_et = len(params) // 2
+        weights, biases = [w.contiguous() for w in params[:n_et]], [b.contiguous() for b in params[n_et:]]
+        E_all, V, m = int(plan.all_tgts.shape[0]), x.shape[0], out_dim // 3
+        dev = x.device
+        msgs = torch.empty(E_all, H, out_dim, dtype=torch.float32, device=dev)
+        agg = torch.empty(V, H, 4 * m, dtype=torch.float32, device=dev)
+        argmax = torch.empty(V, H, m, dtype=torch.int32, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        tab = _MessageFunction._table(plan, weights, biases)
+        _lib.check(lib.adkf_msg_forward(ptr(x), C.cast(tab, C.c_void_p), n_et, H, in_dim, out_dim, ptr(msgs), st), "adkf_msg_forward")
+        _lib.check(lib.adkf_pna_aggregate(ptr(msgs), ptr(plan.perm), ptr(plan.rowptr), V, H, m, ptr(agg), ptr(argmax), st), "adkf_pna_aggregate")
+        ctx.save_for_backward(x, msgs, agg, argmax, *weights)
+        ctx.plan, ctx.dims, ctx.n_et = plan, (H, in_dim, out_dim), n_et
+        ctx.mark_non_differentiable(argmax, msgs)
+        return agg, argmax, msgs
+
+    @staticmethod
+    def backward(ctx, d_agg, _d_argmax=None, _d_msgs=None):
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        x, msgs, agg, argmax, *weights = ctx.saved_tensors
+        plan, (H, in_dim, out_dim), n_et = ctx.plan, ctx.dims, ctx.n_et
+        dev, V, m = x.device, x.shape[0], out_dim // 3
+        d_agg = d_agg.contiguous()
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        E_all = int(plan.all_tgts.shape[0])
+        d_pre = torch.empty_like(msgs)
+        if E_all > 0:
+            _lib.check(lib.adkf_pna_aggregate_backward_relu(ptr(msgs), ptr(plan.perm), ptr(plan.rowptr), ptr(agg), ptr(argmax), ptr(d_agg),
+                                                            V, H, m, ptr(d_pre), st), "adkf_pna_aggregate_backward_relu")
+        dcat = torch.empty(max(E_all, 1), H, 2 * in_dim, dtype=torch.float32, device=dev)
+        dW_all = [torch.empty_like(w) for w in weights]
+        db_all = torch.empty(n_et, H, out_dim, dtype=torch.float32, device=dev)
+        dbs = [db_all[et] for et in range(n_et)]
+        tab = _MessageFunction._table(plan, weights, None, dW_all, dbs)
+        need = int(lib.adkf_msg_backward_scratch_bytes(C.cast(tab, C.c_void_p), n_et, H, in_dim, out_dim))
+        scratch = torch.empty(max(need, 4) // 4, dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x)
+        _lib.check(lib.adkf_msg_backward(ptr(x), C.cast(tab, C.c_void_p), n_et, H, in_dim, out_dim, None, ptr(d_pre),
+                                         ptr(plan.perm_src), ptr(plan.rowptr_src), ptr(plan.perm), ptr(plan.rowptr), V,
+                                         ptr(dcat), ptr(dx), ptr(scratch), scratch.numel() * 4, st), "adkf_msg_backward")
+        return (dx, None, None, None, None, *dW_all, *dbs)
 
 
 class _BlockCombine(torch.autograd.Function):
@@ -545,6 +610,61 @@ class _ReadoutPool(torch.autograd.Function):
         return d_s_mean, d_v_mean, d_s_sum, d_v_sum, d_emb, None, None, None, None, None, None
 
 
+class _ReadoutPoolHidden(torch.autograd.Function):
+    """The same pooling taken BEFORE the last layer of the two value MLPs (``adkf_readout_pool_hidden`` / ``_backward``,
+    csrc/readout.h): per graph and head the pooled hidden activations ``p[h, g, :] = sum_v w[v, h] r_v`` and the weight totals,
+    so that the value layers multiply ``[G, K]`` matrices instead of ``[V, K]`` ones.  ``h_mean`` / ``h_sum`` may be column
+    blocks of one activation tensor (row stride passed to the kernel: no copies).  Same order guarantees as ``_ReadoutPool``."""
+
+    @staticmethod
+    def forward(ctx, s_mean, h_mean, s_sum, h_sum, emb, num_graphs, nh, perm, rowptr):
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        dev = emb.device
+        V, D, G, K = emb.shape[0], emb.shape[1], int(num_graphs), h_mean.shape[1]
+        s_mean, s_sum, emb = s_mean.contiguous(), s_sum.contiguous(), emb.contiguous()
+        if h_mean.stride(1) != 1 or h_sum.stride(1) != 1 or h_mean.stride(0) != h_sum.stride(0):
+            h_mean, h_sum = h_mean.contiguous(), h_sum.contiguous()
+        ldh = h_mean.stride(0) if V > 1 else K
+        f32 = dict(dtype=torch.float32, device=dev)
+        w_mean, w_sum = torch.empty(V, nh, **f32), torch.empty(V, nh, **f32)
+        p_mean, p_sum = torch.empty(nh, G, K, **f32), torch.empty(nh, G, K, **f32)
+        wtot_mean, wtot_sum = torch.empty(G, nh, **f32), torch.empty(G, nh, **f32)
+        g_max, argmax = torch.empty(G, D, **f32), torch.empty(G, D, dtype=torch.int32, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(lib.adkf_readout_pool_hidden(ptr(s_mean), ptr(h_mean), ptr(s_sum), ptr(h_sum), ldh, ptr(emb), ptr(perm), ptr(rowptr), V, G, nh,
+                                                K, D, ptr(w_mean), ptr(w_sum), ptr(p_mean), ptr(p_sum), ptr(wtot_mean), ptr(wtot_sum), ptr(g_max),
+                                                ptr(argmax), st), "adkf_readout_pool_hidden")
+        ctx.save_for_backward(h_mean, h_sum, w_mean, w_sum, argmax, perm, rowptr)
+        ctx.dims = (V, G, nh, K, D, ldh)
+        ctx.mark_non_differentiable(wtot_mean)
+        return p_mean, p_sum, wtot_mean, wtot_sum, g_max
+
+    @staticmethod
+    def backward(ctx, dp_mean, dp_sum, _dwtot_mean, dwtot_sum, dg_max):
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        h_mean, h_sum, w_mean, w_sum, argmax, perm, rowptr = ctx.saved_tensors
+        V, G, nh, K, D, ldh = ctx.dims
+        dev = w_mean.device
+        dp_mean, dp_sum, dwtot_sum, dg_max = dp_mean.contiguous(), dp_sum.contiguous(), dwtot_sum.contiguous(), dg_max.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_s_mean, d_s_sum = torch.empty(V, nh, **f32), torch.empty(V, nh, **f32)
+        d_h_mean, d_h_sum, d_emb = torch.empty(V, K, **f32), torch.empty(V, K, **f32), torch.empty(V, D, **f32)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(lib.adkf_readout_pool_hidden_backward(ptr(h_mean), ptr(h_sum), ldh, ptr(w_mean), ptr(w_sum), ptr(argmax), ptr(perm), ptr(rowptr),
+                                                         ptr(dp_mean), ptr(dp_sum), ptr(dwtot_sum), ptr(dg_max), V, G, nh, K, D, ptr(d_s_mean),
+                                                         ptr(d_h_mean), ptr(d_s_sum), ptr(d_h_sum), ptr(d_emb), st),
+                   "adkf_readout_pool_hidden_backward")
+        return d_s_mean, d_h_mean, d_s_sum, d_h_sum, d_emb, None, None, None, None
+
+
 class CombinedGraphReadout(nn.Module):
     """weighted-mean + weighted-sum (multi-head) + max pooling, then Linear(ReLU(cat))  (graph_readout.py:119-296).
     The two scoring MLPs and two value MLPs share their input, so their first layers run as one GEMM."""
@@ -563,6 +683,14 @@ class CombinedGraphReadout(nn.Module):
         self.max_combination = nn.Linear(node_dim, out_dim, bias=False)
         self.combination_layer = nn.Linear(3 * out_dim, out_dim, bias=False)
 
+    def _project_pooled(self, p: torch.Tensor, wtot: torch.Tensor, layer: nn.Linear) -> torch.Tensor:
+        """``g[g, h, :] = W2[h] p[h, g, :] + b2[h] wtot[g, h]`` for a value layer ``layer`` = (W2 [nh hd, hid], b2)."""
+        G = p.shape[1]
+        w = layer.weight.view(self.nh, self.hd, -1)                                    # [nh, hd, hid]
+        g = torch.bmm(p, w.transpose(1, 2)).permute(1, 0, 2)                          # [G, nh, hd]
+        g = g + wtot.unsqueeze(-1) * layer.bias.view(1, self.nh, self.hd)
+        return g.reshape(G, self.nh * self.hd)
+
     def forward(self, node_embeddings: torch.Tensor, node_to_graph_id: torch.Tensor, num_graphs: int, plan: Optional[_GraphPlan] = None) -> torch.Tensor:
         V, hid = node_embeddings.shape[0], self.nh * self.hd
         h = F.relu(self.first(node_embeddings))
@@ -572,9 +700,20 @@ class CombinedGraphReadout(nn.Module):
             ok = (plan is not None and plan.perm_graph is not None and plan.num_graphs == num_graphs
                   and plan.perm_graph.device == node_embeddings.device and plan.perm_graph.shape[0] == V)
             segs = (plan.perm_graph, plan.rowptr_graph) if ok else (None, None)
-            g_mean, g_sum, g_max = _ReadoutPool.apply(self.mean_score_out(h_ms), self.mean_value_out(h_mv), self.sum_score_out(h_ss),
-                                                      self.sum_value_out(h_sv), node_embeddings, node_to_graph_id, num_graphs,
-                                                      self.nh, self.hd, *segs)
+            if _POOL_HIDDEN and hid <= 1024 and node_embeddings.shape[1] <= 2048:   # (the kernels' register budgets, csrc/readout.h)
+                # pooling is linear in the last layer of the value MLPs: pool their HIDDEN activations per head, then nh products of
+                # [G, hid] x [hid, hd] instead of [V, hid] x [hid, nh hd] over all nodes (csrc/readout.h)
+                if not ok:      # (no plan on the batch: three tiny launches and a host synchronisation)
+                    counts = torch.bincount(node_to_graph_id, minlength=num_graphs)
+                    segs = (torch.argsort(node_to_graph_id, stable=True), torch.cat((counts.new_zeros(1), torch.cumsum(counts, 0))))
+                p_mean, p_sum, wt_mean, wt_sum, g_max = _ReadoutPoolHidden.apply(self.mean_score_out(h_ms), h_mv, self.sum_score_out(h_ss), h_sv,
+                                                                                 node_embeddings, num_graphs, self.nh, *segs)
+                g_mean = self._project_pooled(p_mean, wt_mean, self.mean_value_out)
+                g_sum = self._project_pooled(p_sum, wt_sum, self.sum_value_out)
+            else:
+                g_mean, g_sum, g_max = _ReadoutPool.apply(self.mean_score_out(h_ms), self.mean_value_out(h_mv), self.sum_score_out(h_ss),
+                                                          self.sum_value_out(h_sv), node_embeddings, node_to_graph_id, num_graphs,
+                                                          self.nh, self.hd, *segs)
         else:
             w_mean = _segment_softmax(self.mean_score_out(h_ms), node_to_graph_id, num_graphs)      # [V, heads]
             w_sum = torch.sigmoid(self.sum_score_out(h_ss))

@@ -192,7 +192,8 @@ int adkf_ift_hypergrad_cg(const adkf_batch_t* b, const float* phi, int32_t flags
  * the order of the two CSR lists (perm_*: edge ids of the concatenated edge list sorted stably by source / target node,
  * rowptr_* [V + 1]); every edge type's dW [H, 2 in, out] and db [H, out] are sums over fixed chunks of its edges (partials in
  * `scratch`, at least adkf_msg_backward_scratch_bytes() bytes), added in a fixed order.  Nothing needs initialising; an edge type
- * without edges gets exact zeros. */
+ * without edges gets exact zeros.  msgs = NULL in the backward: d_msgs is already the gradient in front of the ReLU
+ * (adkf_pna_aggregate_backward_relu below) and no mask is applied. */
 typedef struct adkf_msg_et {
     const int64_t* src; /* [E] source node of every edge */
     const int64_t* tgt; /* [E] target node */
@@ -226,6 +227,23 @@ int adkf_readout_pool_backward(const float* v_mean, const float* v_sum, const fl
                                const float* dg_sum, const float* dg_max, int32_t V, int32_t G, int32_t nh, int32_t hd, int32_t D,
                                float* d_s_mean, float* d_v_mean, float* d_s_sum, float* d_v_sum, float* d_emb, void* stream);
 
+/* The same pooling taken BEFORE the last layer of the two value MLPs (graph_readout.py:219-223: _transformation_mlp = Linear . ReLU .
+ * Linear; :242-252 pools its output).  Pooling is linear in that last layer, so
+ *     g[g, h, :] = W2[h] p[h, g, :] + b2[h] wtot[g, h],   p[h, g, :] = sum_v w[v, h] r_v,   wtot[g, h] = sum_v w[v, h],
+ * with r_v [K] the hidden activations: the caller multiplies nh small [G, K] x [K, hd] products instead of [V, K] x [K, nh hd].
+ * h_mean / h_sum: rows of K floats with row stride ldh (column blocks of one activation tensor), K <= 1024; p_* [nh, G, K];
+ * wtot_mean (1, or 0 for an empty graph) and wtot_sum [G, nh]; everything else as adkf_readout_pool.  The backward takes dp_*
+ * [nh, G, K], dwtot_sum [G, nh], dg_max and writes d_s_* [V, nh], d_h_* [V, K] (contiguous), d_emb [V, D], every element once. */
+int adkf_readout_pool_hidden(const float* s_mean, const float* h_mean, const float* s_sum, const float* h_sum, int32_t ldh,
+                             const float* emb, const int64_t* perm, const int64_t* rowptr, int32_t V, int32_t G, int32_t nh,
+                             int32_t K, int32_t D, float* w_mean, float* w_sum, float* p_mean, float* p_sum, float* wtot_mean,
+                             float* wtot_sum, float* g_max, int32_t* argmax, void* stream);
+int adkf_readout_pool_hidden_backward(const float* h_mean, const float* h_sum, int32_t ldh, const float* w_mean, const float* w_sum,
+                                      const int32_t* argmax, const int64_t* perm, const int64_t* rowptr, const float* dp_mean,
+                                      const float* dp_sum, const float* dwtot_sum, const float* dg_max, int32_t V, int32_t G,
+                                      int32_t nh, int32_t K, int32_t D, float* d_s_mean, float* d_h_mean, float* d_s_sum,
+                                      float* d_h_sum, float* d_emb, void* stream);
+
 /* a1 (aggregation inside RelationalMultiAggrMP._aggregate_messages, fs_mol/modules/gnn.py:197-265; torch_scatter's
  * scatter_sum / scatter_mean / scatter_max there): SUM | MEAN | STD | MAX of the incoming messages of every target
  * node in one pass.  msgs [E, H, 3m] post-ReLU messages (per tower: sum-part | mean/std-part | max-part), perm [E] the
@@ -236,6 +254,12 @@ int adkf_pna_aggregate(const float* msgs, const int64_t* perm, const int64_t* ro
 int adkf_pna_aggregate_backward(const float* msgs, const int64_t* perm, const int64_t* rowptr, const float* agg,
                                 const int32_t* argmax, const float* d_agg, int32_t V, int32_t H, int32_t m,
                                 float* d_msgs, void* stream);
+/* The same with the ReLU in front of the messages folded in (msgs are the ReLU OUTPUTS of the message functions, gnn.py:141):
+ * d_pre = d_msgs . [msgs > 0], the gradient in front of that ReLU.  adkf_msg_backward takes it with msgs = NULL and then reads one
+ * [E, H, 3m] tensor per product instead of gradient + mask (its three products are bound by exactly that traffic). */
+int adkf_pna_aggregate_backward_relu(const float* msgs, const int64_t* perm, const int64_t* rowptr, const float* agg,
+                                     const int32_t* argmax, const float* d_agg, int32_t V, int32_t H, int32_t m, float* d_pre,
+                                     void* stream);
 
 /* a1 (the element-wise middle of GNNBlock.forward, fs_mol/modules/gnn.py:477-515, between the output projection of the message
  * passing and the BOOM MLP):   new = p0 + amp[v] p1 + att[v] p2 + bias  (p = [p0 | p1 | p2] [V, 3 hid]: the projected unscaled
