@@ -118,6 +118,81 @@ def test_fused_kernels_on_odd_shapes_vs_cpu_float64(dev, kind, empty_type, hidde
         assert e <= 5e-5, (n, e)
 
 
+@pytest.mark.parametrize("nh,hd", [(12, 8), (8, 6), (5, 7)])
+def test_readout_pooling_before_projection_on_ragged_graphs(dev, nh, hd):
+    """csrc/readout.h, k_readout_h_fwd / _bwd (the pooling taken before the last layer of the value MLPs,
+    fs_mol/modules/graph_readout.py:219-223, 242-252) alone: graphs with 0, 1, 3, 70 and 130 nodes (an empty graph; more nodes than
+    the kernels stage in LDS at a time), head counts that take the 12-, 4- and 1-heads-per-pass builds, against the same module in
+    float64 on the CPU (PyTorch's scatter ops) and against the round-3 order of operations on the device (pooling the value MLPs'
+    outputs, adkf_readout_pool): forward 2e-5, gradients 5e-5 of the largest entry."""
+    from adkf_ift_amd import gnn as G
+
+    sizes = [0, 1, 70, 130, 3]
+    n2g = torch.cat([torch.full((n,), g, dtype=torch.long) for g, n in enumerate(sizes)])
+    V, D = int(n2g.shape[0]), 40
+    gen = torch.Generator().manual_seed(5)
+    x64 = torch.randn(V, D, dtype=torch.float64, generator=gen)
+    torch.manual_seed(3)
+    ref = G.CombinedGraphReadout(D, 24, nh, hd).double()
+    got = G.CombinedGraphReadout(D, 24, nh, hd)
+    got.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    got = got.to(dev)
+    xr = x64.clone().requires_grad_(True)
+    want = ref(xr, n2g, len(sizes))
+    w = torch.randn(want.shape, dtype=torch.float64, generator=gen)
+    (want * w).sum().backward()
+    scale = max(p.grad.abs().max().item() for p in ref.parameters())
+    outs = {}
+    for pool_hidden in (True, False):
+        old = G._POOL_HIDDEN
+        G._POOL_HIDDEN = pool_hidden
+        try:
+            got.zero_grad(set_to_none=True)
+            xg = x64.float().to(dev).requires_grad_(True)
+            z = got(xg, n2g.to(dev), len(sizes))
+            (z * w.float().to(dev)).sum().backward()
+        finally:
+            G._POOL_HIDDEN = old
+        assert (z.double().cpu() - want).abs().max().item() <= 2e-5 * want.abs().max().item(), pool_hidden
+        assert (xg.grad.double().cpu() - xr.grad).abs().max().item() <= 5e-5 * xr.grad.abs().max().item(), pool_hidden
+        for (n, p), q in zip(ref.named_parameters(), got.parameters()):
+            e = (q.grad.double().cpu() - p.grad).abs().max().item() / scale
+            assert e <= 5e-5, (pool_hidden, n, e)
+        outs[pool_hidden] = z.detach().clone()
+    assert (outs[True] - outs[False]).abs().max().item() <= 1e-5 * outs[False].abs().max().item()
+
+
+def test_message_pass_as_one_node_equals_the_two_node_graph_bit_for_bit(dev):
+    """``_MessagePass`` (aggregation backward writes the gradient in front of the messages' ReLU, adkf_pna_aggregate_backward_relu;
+    adkf_msg_backward with msgs = NULL) against ``_MessageFunction`` + ``_PNAAggregate`` (mask applied inside adkf_msg_backward): the
+    same products of the same numbers - every parameter gradient of a small extractor must be IDENTICAL."""
+    from adkf_ift_amd import gnn as G
+    from test_gnn import random_graphs, small_cfg
+
+    cfg = small_cfg("PNA")
+    batch = random_graphs(9, seed=4).to(dev)
+    batch.node_features = batch.node_features.float()
+    torch.manual_seed(11)
+    model = G.GraphFeatureExtractor(cfg).to(dev)
+    with torch.no_grad():
+        for blk in model.gnn.gnn_blocks:
+            blk.alpha.fill_(0.5)
+    grads = {}
+    for fused in (True, False):
+        old = G._FUSED_MP
+        G._FUSED_MP = fused
+        try:
+            model.zero_grad(set_to_none=True)
+            z = model(batch)
+            (z * torch.linspace(-1.0, 1.0, z.numel(), device=dev).view_as(z)).sum().backward()
+        finally:
+            G._FUSED_MP = old
+        grads[fused] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert grads[True].keys() == grads[False].keys()
+    for n in grads[True]:
+        assert torch.equal(grads[True][n], grads[False][n]), n
+
+
 def _molecules(n, seed):
     from adkf_ift_amd.meta_batch import MoleculeFeatures
     from test_gnn import random_graphs
