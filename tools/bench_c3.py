@@ -25,6 +25,9 @@ def main():
                     help="library-GEMM algorithm selection (adkf_ift_amd/gemm_tuning.py): off = hipBLASLt heuristic, shipped = the recorded "
                          "choices for these shapes, tune = measure now into --gemm-file")
     ap.add_argument("--gemm-file", default=None)
+    ap.add_argument("--adam", choices=("fused", "foreach"), default="fused",
+                    help="torch.optim.Adam implementation: fused = one multi-tensor kernel per parameter list (same update as the reference's "
+                         "default; 32 -> 8 launches per step on the 85 tensors of the default model), foreach = PyTorch's default")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     if a.gemm_tuning != "off":
@@ -37,8 +40,9 @@ def main():
         tasks.append(DKTBatch(s, torch.rand(a.support, generator=gen) > 0.5, torch.randn(a.support, generator=gen),
                               q, torch.rand(a.query, generator=gen) > 0.5, torch.randn(a.query, generator=gen)))
     mb = collate_meta_batch(tasks).to(dev)
+    torch.manual_seed(0)                            # the same random-init weights in every run (the step is bit-reproducible given them)
     model = ADKTModel(ADKTModelConfig()).to(dev)   # reference defaults: gnn+ecfp+fc, Matern-5/2, 2048-d features
-    opt = torch.optim.Adam(model.feature_extractor_params(), lr=1e-4)
+    opt = torch.optim.Adam(model.feature_extractor_params(), lr=1e-4, **({"fused": True} if a.adam == "fused" else {}))
     cfg = MetaStepConfig(gp_kernel="matern", clip_value=1.0, inner_max_evals=200)
     for _ in range(a.warmup):
         model_meta_step(model, opt, mb, cfg)
@@ -51,7 +55,7 @@ def main():
     print(json.dumps({"workload": f"C3: {a.tasks} tasks/step, {a.support}-shot, {a.query} query molecules, default GNN+ECFP+fc model "
                                   f"({sum(p.numel() for p in model.parameters()) / 1e6:.1f} M params), inner fit to convergence",
                       "tasks_per_s": a.tasks / dt, "ms_per_step": dt * 1e3, "nodes": int(mb.molecules.node_features.shape[0]),
-                      "mean_loss": float(losses.mean()), "gemm_tuning": a.gemm_tuning}))
+                      "mean_loss": float(losses.mean()), "gemm_tuning": a.gemm_tuning, "adam": a.adam}))
 
 
 if __name__ == "__main__":
