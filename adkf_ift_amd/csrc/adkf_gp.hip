@@ -352,6 +352,12 @@ bool refine64_lds_optin() {
     return ok;
 }
 
+// ADKF_R64_STOP (read once; diagnostics, tools/r64_phases.sh): the float64 path leaves after that phase - results are then garbage
+int r64_stop() {
+    static const int stop = [] { const char* e = getenv("ADKF_R64_STOP"); return e ? atoi(e) : 0; }();
+    return stop;
+}
+
 Refine64Args refine_args(const TaskView& tv, const adkf_batch_t* b, const Workspace& w, bool with_hessian, int level, float* f_out,
                          int32_t* info, float* f_in, float* g_in, float* gnorm, size_t& lds_bytes) {
     const bool lds_inv = refine64_lds_optin();   // (beyond R64_LDS_POINTS the diagonal blocks of the blocked inverse live there)
@@ -360,7 +366,7 @@ Refine64Args refine_args(const TaskView& tv, const adkf_batch_t* b, const Worksp
     lds_bytes = lds_inv ? sizeof(double) * (size_t)R64_LDS_POINTS * R64_LDS_POINTS : 0;
     return Refine64Args{tv, b->Z_s, b->Z_q, b->d, b->y_s, b->y_q, b->priors, w.Ainv, with_hessian ? w.P : nullptr, level >= 1 ? w.C : nullptr,
                         level >= 2 ? w.S : nullptr, w.vecs, w.scal, f_out, info, f_in, g_in, gnorm, w.w64, w.w64_stride, r64_threshold(), b->T,
-                        with_hessian ? 1 : 0, level, lds_inv ? 1 : 0};
+                        with_hessian ? 1 : 0, level, lds_inv ? 1 : 0, r64_stop()};
 }
 
 // Ill-conditioned tasks redo the factorisation-type stages in float64 (refine64.h); everybody else leaves the kernel after
@@ -523,7 +529,7 @@ int outer_pipeline(const adkf_batch_t* b, const Workspace& w, const float* phi, 
         size_t lds_bytes;
         const Refine64Args ra = refine_args(tv, b, w, with_hessian, 2, f_out, info, nullptr, nullptr, nullptr, lds_bytes);
         Cot64Args ca{tv, b->Z_s, b->Z_q, dZ_s, dZ_q, d, w.vecs, w.scal, w.w64, w.w64_stride, r64_threshold(), T,
-                     with_hessian ? 1 : 0, flags, dirscale, corrscale, g_phi_out, v_out, H_out, lds_bytes ? 1 : 0};
+                     with_hessian ? 1 : 0, flags, dirscale, corrscale, g_phi_out, v_out, H_out, lds_bytes ? 1 : 0, r64_stop()};
         k_tail64<<<T, R64_NT, lds_bytes, st>>>(ra, ca);
     }
     LAUNCH_OK();

@@ -40,7 +40,7 @@ struct Refine64Args {
     float* vecs; float* scal; float* f_out; int32_t* info;
     float *f_in, *g_in, *gnorm;        // optional: the refined inner value / raw gradient / max |gradient| (adkf_fit, adkf_mll_value_grad)
     double* w64; size_t w64_stride;    // [T][stride] doubles
-    float thresh; int T, want_hess, want_outer, lds_inverse;   // lds_inverse: the launch carries R64_LDS_POINTS^2 doubles of dynamic LDS (the in-LDS inverse and the staged B operands of the products); want_outer: 0 = inner quantities only, 1 = + C and mu (prediction), 2 = + S, S^-1, e, f_out
+    float thresh; int T, want_hess, want_outer, lds_inverse, stop;   // lds_inverse: the launch carries R64_LDS_POINTS^2 doubles of dynamic LDS (the in-LDS inverse and the staged B operands of the products); want_outer: 0 = inner quantities only, 1 = + C and mu (prediction), 2 = + S, S^-1, e, f_out
 };
 
 // doubles per task: [A1 A2 A3 | B1 B2 | S1 S2 | 8 vectors | DDss DDqs DDqq | spare]
@@ -207,8 +207,62 @@ __device__ __forceinline__ double r64_sum(double v, double* red) {
 // LDS first: 2 n barriers in all.  (Round 2 factored M = L L^T, inverted L one column per thread and formed L^-T L^-1: with
 // 128 points that left 384 of the 512 threads idle through a dependent O(n^2) chain of global loads per column - the float64
 // path cost ~4 ms per launch, i.e. ONE flagged task multiplied the step time by nine; profiles/r03_bench_*_d4.json.)
-__device__ int r64_inverse(double* M, int n, int ld, double& logdet, double* colv, double* rowv, double* lds = nullptr) {
+// Up to 128 points the matrix makes its n steps in REGISTERS (round 4, second session): thread (i = tid / 4, c = tid % 4) holds
+// columns 32 c .. 32 c + 31 of row i; per step the owners publish pivot row and pivot column to LDS (two buffers in turn: one barrier
+// per step), everybody reads its 32 row entries (16-byte broadcast reads) and its one column entry and makes 32 FMAs.  The in-LDS
+// version below ran every step as 32 dependent read-modify-writes per thread with per-element branches and index stepping - 4.6 us per
+// step, 600 us per inverse, 57 % of the float64 path (tools/r64_phases.sh); this one takes ~0.3 us per step.  The register index of
+// the pivot column inside a thread's chunk must be a compile-time constant, hence the unrolled inner loop over the 32 columns of a chunk.
+// `buf`: 512 doubles of LDS, 16-byte aligned.
+__device__ int r64_inverse_reg(double* M, int n, int ld, double& logdet, double* buf) {
+    const int tid = threadIdx.x, i = tid >> 2, c = tid & 3;
+    double m[32];
+    __syncthreads();   // the callers fill M with another thread-to-element map (the in-LDS version read back its own elements)
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj) { const int j = 32 * c + jj; m[jj] = (i < n && j < n) ? M[(size_t)i * ld + j] : 0.0; }
+    int bad = 0;
+    double ld_acc = 0.0;
+    for (int kc = 0; kc < 4; ++kc) {
+        if (32 * kc >= n) break;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const int k = 32 * kc + kk;
+            if (k < n) {                                   // (uniform)
+                double* cb = buf + 256 * (k & 1);
+                double* rb = cb + 128;
+                if (c == kc) cb[i] = m[kk];
+                if (i == k) {
+#pragma unroll
+                    for (int jj = 0; jj < 32; ++jj) rb[32 * c + jj] = m[jj];
+                }
+                __syncthreads();                           // (the other buffer was last read before the previous barrier)
+                const double p = rb[k];
+                if (!(p > 0.0) && !bad) bad = k + 1;
+                const double ps = p > 0.0 ? p : 1.0, r = 1.0 / ps;
+                if (tid == (k & (R64_NT - 1))) ld_acc += log(ps);
+                const double ci = cb[i];
+                if (i == k) {
+#pragma unroll
+                    for (int jj = 0; jj < 32; ++jj) m[jj] = rb[32 * c + jj] * r;
+                } else {
+                    const double cr = ci * r;
+#pragma unroll
+                    for (int jj = 0; jj < 32; ++jj) m[jj] = fma(-cr, rb[32 * c + jj], m[jj]);
+                }
+                if (c == kc) m[kk] = (i == k) ? r : -ci * r;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj) { const int j = 32 * c + jj; if (i < n && j < n) M[(size_t)i * ld + j] = m[jj]; }
+    logdet = r64_sum(ld_acc, buf);      // (two barriers inside: the stores above are visible to the workgroup afterwards)
+    return bad;
+}
+
+__device__ int r64_inverse(double* M, int n, int ld, double& logdet, double* colv, double* rowv, double* lds = nullptr, bool in_registers = true) {
     const int tid = threadIdx.x;
+    if (in_registers && n <= R64_LDS_POINTS && rowv == colv + R64_MAXN) return r64_inverse_reg(M, n, ld, logdet, colv);   // (colv, rowv: one 2 x 1024 array)
     // up to 128 points the matrix makes its n steps in LDS (`lds`: n * n doubles of dynamic shared memory, 128 KB at n = 128):
     // in global memory every step is 32 dependent read-modify-writes per thread at L2 latency - 1.3 ms per inverse, measured
     double* W = M;
@@ -303,12 +357,16 @@ __global__ void k_double_path_tasks(const float* scal, int ld, int ldq, float th
     flagged[t] = (ra > thresh || rs > thresh) ? 1 : 0;
 }
 
+#define R64_STOP(k_) do { if (a.stop == (k_)) return; } while (0)   // uniform over the workgroup
+
 extern __shared__ double r64_lds[];                     // R64_LDS_POINTS^2 doubles when the batch has at most that many points, else nothing
 
 // The body of k_refine64 for the task of this workgroup (all threads call; returns early - uniformly - for unflagged tasks).
 __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
     __shared__ double red[R64_NT / 64];
-    __shared__ double gjc[R64_MAXN], gjr[R64_MAXN];   // pivot column / scaled pivot row of r64_inverse
+    __shared__ __attribute__((aligned(16))) double gj_s[2 * R64_MAXN];   // pivot column / scaled pivot row of r64_inverse (first 512: the two buffers of r64_inverse_reg)
+    double* const gjc = gj_s;
+    double* const gjr = gj_s + R64_MAXN;
     const int t = blockIdx.x, tid = threadIdx.x;
     if (t >= a.T) return;
     const int n = a.tv.ns(t), m = a.want_outer ? a.tv.nq(t) : 0, ld = a.tv.ns_ld, ldq = a.tv.nq_ld, vld = a.tv.vld;
@@ -346,6 +404,7 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
         r64_distances(Zq, Zq, m, m, a.d, DDqq, ldq, gjc, gjr, true, stage);
     }
     __syncthreads();
+    R64_STOP(1);   // distances
     const float* ys = a.y_s + (size_t)t * ld;
     float* vb = a.vecs + (size_t)t * NVEC * vld;
 
@@ -357,13 +416,15 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
     }
     double logdetA;
     double* scr = W + r64_scratch_offset(ld, ldq);
-    const int badA = n <= R64_LDS_POINTS ? r64_inverse(A1, n, ld, logdetA, gjc, gjr, a.lds_inverse ? r64_lds : nullptr)
+    const int badA = n <= R64_LDS_POINTS ? r64_inverse(A1, n, ld, logdetA, gjc, gjr, a.lds_inverse ? r64_lds : nullptr, a.stop != -1)
                                          : r64_inverse_blocked(A1, n, ld, logdetA, gjc, gjr, r64_lds, scr);
+    R64_STOP(2);   // + A, A^-1
     float* Ai32 = a.Ainv + (size_t)t * ld * ld;
     for (int e = tid; e < n * n; e += R64_NT) { const int i = e / n, j = e % n; Ai32[(size_t)i * ld + j] = (float)A1[(size_t)i * ld + j]; }
     r64_mv(n, n, [=](int i, int k) { return A1[(size_t)i * ld + k]; }, [=](int k) { return (double)ys[k]; },
            [=](int i, double v) { v_al[i] = v; vb[V_ALPHA * vld + i] = (float)v; });
 
+    R64_STOP(3);   // + copy-out, alpha
     // ---- inner scalars and the 3 x 3 Hessian (oracle/closed_form.py::inner_stage)
     {
         for (int e = tid; e < n * n; e += R64_NT) {   // G = dK/dl
@@ -382,6 +443,7 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
                    [=](int i, int j, double v) { A3[(size_t)i * ld + j] = v; }, stage);   // P = A^-1 G
         }
         __syncthreads();
+        R64_STOP(4);   // + G, three mat-vecs, P = A^-1 G
         double trAinv = 0, trAinvG = 0, aGa = 0, trA2 = 0, trPA = 0, trPP = 0, trAinvKll = 0, aKlla = 0;
         for (int e = tid; e < n * n; e += R64_NT) {
             const int i = e / n, j = e % n;
@@ -452,6 +514,7 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
         }
     }
     __syncthreads();
+    R64_STOP(5);   // + traces, reductions, Hessian
     if (m <= 0) return;
 
     // ---- outer: C, mu, r, S, S^-1, e, f_out, C^T e   (oracle/closed_form.py::outer_stage)
@@ -477,6 +540,7 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
         return;
     }
     __syncthreads();
+    R64_STOP(6);   // + K_qs, C, mu
     r64_mm(m, m, n, [=](int i, int k) { return B2[(size_t)i * ld + k]; }, [=](int k, int j) { return B1[(size_t)j * ld + k]; },
            [=](int i, int j, double v) {                                            // Sigma_q = K_qq + noise I - C K_sq, the lower triangle mirrored
                if (j > i) return;
@@ -485,8 +549,9 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
                S1[(size_t)i * ldq + j] = sv; S1[(size_t)j * ldq + i] = sv;
            }, stage);
     double logdetS;
-    const int badS = m <= R64_LDS_POINTS ? r64_inverse(S1, m, ldq, logdetS, gjc, gjr, a.lds_inverse ? r64_lds : nullptr)
+    const int badS = m <= R64_LDS_POINTS ? r64_inverse(S1, m, ldq, logdetS, gjc, gjr, a.lds_inverse ? r64_lds : nullptr, a.stop != -1)
                                          : r64_inverse_blocked(S1, m, ldq, logdetS, gjc, gjr, r64_lds, scr);
+    R64_STOP(7);   // + S, S^-1
     if (a.S) {
         float* S32 = a.S + (size_t)t * ldq * ldq;
         for (int e = tid; e < m * m; e += R64_NT) { const int i = e / m, j = e % m; S32[(size_t)i * ldq + j] = (float)S1[(size_t)i * ldq + j]; }
@@ -531,6 +596,7 @@ struct Cot64Args {
     double* w64; size_t w64_stride; float thresh; int T, with_hessian, flags; float dirscale, corrscale; float *g_phi_out, *v_out;
     float* H_out;   // [T, 9] or null: the float64 path's Hessian (k_refine64 leaves it in the scalars) for the caller
     int lds_stage;  // the launch carries R64_LDS_POINTS^2 doubles of dynamic LDS: the products stage their B operands there
+    int stop;       // diagnostics (ADKF_R64_STOP, tools/r64_phases.sh): leave after phase `stop` (0: run everything)
 };
 
 __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
@@ -577,6 +643,7 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
     __syncthreads();
     r64_mm(m, n, m, [=](int i, int k) { return S1[(size_t)i * ldq + k]; }, [=](int k, int j) { return B2[(size_t)k * ld + j]; },
            [=](int i, int j, double v) { B1[(size_t)i * ld + j] = 0.5 * (v - v_e[i] * v_cte[j]); }, stage);   // Omega C = (S^-1 C - e (C^T e)^T) / 2
+    R64_STOP(9);   // (8 = all of refine64_task) + C^T e, Omega C
     double oc0 = 0, oc1 = 0, ma0 = 0, ma1 = 0, ma2 = 0, qq0 = 0, qq1 = 0, qq2 = 0;
     {   // M_A = C^T (Omega C) + sym(C^T e alpha^T)   (the three reductions ride in the product's epilogue)
         double* pm0 = &ma0; double* pm1 = &ma1; double* pm2 = &ma2;
@@ -590,6 +657,7 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
                    *pm1 += MA * k0; *pm2 += MA * os * k1 * u * gl;
                }, stage);
     }                                               // (barrier inside) Omega C has been read by everybody: it turns into W_qs in place
+    R64_STOP(10);  // + M_A
     for (int e = tid; e < m * n; e += R64_NT) {     // M_B -> W_qs
         const int i = e / n, j = e % n;
         const double MB = -2.0 * B1[(size_t)i * ld + j] - v_e[i] * v_al[j];
@@ -633,6 +701,7 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
         sc[S_CN] = (float)coef[0]; sc[S_CS] = (float)coef[1]; sc[S_CL] = (float)coef[2];
     }
     __syncthreads();
+    R64_STOP(11);  // + W_qs, W_qq, reductions, v
     const double cn = coef[0], cs = coef[1], cl = coef[2];
     if (a.with_hessian) {
         for (int i = tid; i < n; i += R64_NT) {
@@ -665,6 +734,7 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
         for (int e = tid; e < n * n; e += R64_NT) wss_of(e / n, e % n, 0.0);
         __syncthreads();
     }
+    R64_STOP(12);  // + W_ss with the mixed part
     // ---- dL/dZ in the difference form, from the float64 weights
     const int d = a.d;
     const float* Zs = a.Zs + (size_t)t * ld * d;
@@ -680,6 +750,7 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
     r64_mv(n, n, [=](int i, int k) { return A2[(size_t)i * ld + k]; }, [](int) { return 1.0; }, [=](int i, double v) { rs_ss[i] = v; });
     r64_mv(m, n, [=](int i, int k) { return B1[(size_t)i * ld + k]; }, [](int) { return 1.0; }, [=](int i, double v) { rs_qs_row[i] = v; });
     r64_mv(m, m, [=](int i, int k) { return S2[(size_t)i * ldq + k]; }, [](int) { return 1.0; }, [=](int i, double v) { rs_qq[i] = v; });
+    R64_STOP(13);  // + row / column sums of the weights
     if (a.dZs) {
         float* out = a.dZs + (size_t)t * ld * d;
         // dZs_i = 4 (rs_ss_i z_i - sum_k Wss_ik z_k) + 2 (cs_qs_i z_i - sum_q Wqs_qi zq_q): one product over k = [support | query]
@@ -702,6 +773,7 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
 __global__ __launch_bounds__(R64_NT) void k_tail64(Refine64Args ra, Cot64Args ca) {
     refine64_task(ra);
     __syncthreads();
+    if (ra.stop > 0 && ra.stop <= 8) return;
     cotangent64_task(ca);
 }
 
