@@ -22,6 +22,8 @@
 // the blocked path (> 128 points, no pivot ratio at hand) are flagged by (s + noise) / noise itself.  Everything lives in
 // a float64 region of the caller's workspace (L2-resident); plain loops - this is the slow path, it only has to be right.
 #pragma once
+#include <utility>
+
 #include "kernels.h"
 
 namespace adkf {
@@ -103,17 +105,20 @@ __device__ __forceinline__ void r64_mm_staged(int M, int N, int K, FA fa, FB fb,
         for (int m0 = 0; m0 < M; m0 += B) {
             const int ar = m0 + 16 * wv + lr;
             const bool aok = ar < M;
+            // only the 16-column tiles and the k rows that exist are staged and multiplied: the products with a handful of columns
+            // (dL/dZ with d = 4 features) or of k steps (the distances with d = 4) used to pay for all 128 x 128
+            const int nt = min(8, (N - n0 + 15) >> 4), ncol = 16 * nt;
             f64x4_t acc[8];
 #pragma unroll
             for (int x = 0; x < 8; ++x) acc[x] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
             for (int kc = 0; kc < K; kc += B) {
+                const int kend = min(B, K - kc), krows = (kend + 3) & ~3;
                 __syncthreads();                                   // the previous block of B has been read by everybody
-                for (int e = threadIdx.x; e < B * B; e += R64_NT) {
-                    const int kk = e >> 7, j = e & 127;
-                    stage[e] = (kc + kk < K && n0 + j < N) ? fb(kc + kk, n0 + j) : 0.0;
+                for (int e = threadIdx.x; e < krows * ncol; e += R64_NT) {
+                    const int kk = e / ncol, j = e - kk * ncol;
+                    stage[kk * B + j] = (kc + kk < K && n0 + j < N) ? fb(kc + kk, n0 + j) : 0.0;
                 }
                 __syncthreads();
-                const int kend = min(B, K - kc);
                 if (16 * wv < M - m0) {                            // (wave-uniform: this wave's rows exist)
                     double av = (aok && kc + lk < K) ? fa(ar, kc + lk) : 0.0;
                     for (int k0 = 0; k0 < kend; k0 += 4) {
@@ -121,7 +126,8 @@ __device__ __forceinline__ void r64_mm_staged(int M, int N, int K, FA fa, FB fb,
                         const double an = (aok && k0 + 4 < kend && kn < K) ? fa(ar, kn) : 0.0;   // next step's A: in flight under the MFMAs
                         const double* bp = stage + (k0 + lk) * B + lr;
 #pragma unroll
-                        for (int x = 0; x < 8; ++x) acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[16 * x], acc[x], 0, 0, 0);
+                        for (int x = 0; x < 8; ++x)
+                            if (x < nt) acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[16 * x], acc[x], 0, 0, 0);
                         av = an;
                     }
                 }
@@ -132,7 +138,7 @@ __device__ __forceinline__ void r64_mm_staged(int M, int N, int K, FA fa, FB fb,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = m0 + 16 * wv + lk + 4 * r, j = n0 + 16 * x + lr;
-                        if (i < M && j < N) fe(i, j, acc[x][r]);
+                        if (x < nt && i < M && j < N) fe(i, j, acc[x][r]);
                     }
             }
         }
@@ -150,12 +156,23 @@ __device__ __forceinline__ void r64_mm(int M, int N, int K, FA fa, FB fb, FE fe,
 template <class FA, class FX, class FE>
 __device__ __forceinline__ void r64_mv(int M, int K, FA fa, FX fx, FE fe) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int i = wv; i < M; i += R64_NT / 64) {
-        double s = 0.0;
-        for (int k = lane; k < K; k += 64) s += fa(i, k) * fx(k);
+    constexpr int NW = R64_NT / 64, RU = 4;   // four rows of a wave in flight: their loads and the six exchange steps of their reductions overlap
+    for (int i0 = wv; i0 < M; i0 += NW * RU) {
+        double s[RU];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0) fe(i, s);
+        for (int u = 0; u < RU; ++u) {
+            const int i = i0 + u * NW;
+            s[u] = 0.0;
+            if (i < M)
+                for (int k = lane; k < K; k += 64) s[u] += fa(i, k) * fx(k);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < RU; ++u) s[u] += __shfl_xor(s[u], o, 64);
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+            if (lane == 0 && i0 + u * NW < M) fe(i0 + u * NW, s[u]);
     }
     __syncthreads();
 }
@@ -201,61 +218,110 @@ __device__ __forceinline__ double r64_sum(double v, double* red) {
     return s;
 }
 
+// the same for NV values at once: their exchange steps overlap and the whole batch costs two barriers (red: NV * R64_NT / 64 doubles)
+template <int NV>
+__device__ __forceinline__ void r64_sum_n(double (&v)[NV], double* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] += __shfl_xor(v[q], o, 64);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) red[w * NV + q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double t = 0.0;
+        for (int i = 0; i < R64_NT / 64; ++i) t += red[i * NV + q];
+        v[q] = t;
+    }
+}
+
 // M -> M^-1 in place (n x n SPD, leading dimension ld) by Gauss-Jordan steps without pivoting, the whole workgroup; returns the
 // first non-positive pivot (1-based) or 0, log|M| through logdet (the pivots are those of the LDL^T factorisation).  Every step
 // is one fully parallel rank-1 update of the n^2 entries from the pivot column and the scaled pivot row, which are parked in
 // LDS first: 2 n barriers in all.  (Round 2 factored M = L L^T, inverted L one column per thread and formed L^-T L^-1: with
 // 128 points that left 384 of the 512 threads idle through a dependent O(n^2) chain of global loads per column - the float64
 // path cost ~4 ms per launch, i.e. ONE flagged task multiplied the step time by nine; profiles/r03_bench_*_d4.json.)
-// Up to 128 points the matrix makes its n steps in REGISTERS (round 4, second session): thread (i = tid / 4, c = tid % 4) holds
-// columns 32 c .. 32 c + 31 of row i; per step the owners publish pivot row and pivot column to LDS (two buffers in turn: one barrier
-// per step), everybody reads its 32 row entries (16-byte broadcast reads) and its one column entry and makes 32 FMAs.  The in-LDS
+// Up to 128 points the matrix makes its n steps in REGISTERS (round 4, second session): thread (ri = tid / 16, cj = tid % 16) holds the
+// 4 x 8 block of rows 4 ri .. 4 ri + 3 and columns 8 cj .. 8 cj + 7; per step the owners publish pivot row and pivot column to LDS (two
+// buffers in turn: one barrier per step), everybody reads its 8 row entries and its 4 column entries and makes 32 FMAs.  The in-LDS
 // version below ran every step as 32 dependent read-modify-writes per thread with per-element branches and index stepping - 4.6 us per
-// step, 600 us per inverse, 57 % of the float64 path (tools/r64_phases.sh); this one takes ~0.3 us per step.  The register index of
-// the pivot column inside a thread's chunk must be a compile-time constant, hence the unrolled inner loop over the 32 columns of a chunk.
-// `buf`: 512 doubles of LDS, 16-byte aligned.
+// step, 600 us per inverse, 57 % of the float64 path (tools/r64_phases.sh).  A first register version with one row strip of 32 columns
+// per thread still took 1.55 us per step: every thread read 33 doubles per step, 128 KB through the CU's LDS port (tools/r64_inv_bench.hip);
+// the 4 x 8 block reads 13.  The position of the pivot inside a thread's block must be a compile-time constant (a run-time register
+// index would put the block into scratch memory), hence the steps of a chunk of 32 pivots as a template pack.
+// `buf`: 640 doubles of LDS, 16-byte aligned (two row / column buffers and the pivots).
+template <int KK>
+__device__ __forceinline__ void r64_gj_step(double (&m)[4][8], int kc, int n, int ri, int cj, double* buf, int& bad, double* piv) {
+    constexpr int AK = KK & 3, BK = KK & 7;            // the pivot's row / column inside its owners' blocks
+    const int k = 32 * kc + KK;
+    if (k >= n) return;                                // (uniform)
+    double* cb = buf + 256 * (k & 1);
+    double* rb = cb + 128;
+    const bool rowk = ri == (k >> 2), colk = cj == (k >> 3);
+    if (colk) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) cb[4 * ri + a] = m[a][BK];
+    }
+    if (rowk) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) rb[8 * cj + b] = m[AK][b];
+    }
+    __syncthreads();                                   // (the other buffer was last read before the previous barrier)
+    const double p = rb[k];
+    if (!(p > 0.0) && !bad) bad = k + 1;
+    const double ps = p > 0.0 ? p : 1.0, r = 1.0 / ps;
+    if (threadIdx.x == 0) piv[k] = ps;                 // (the logarithms are taken after the last step, one thread per pivot)
+    double rv[8], cr[4];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) rv[b] = rb[8 * cj + b];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) cr[a] = cb[4 * ri + a] * r;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        if (a == AK && rowk) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) m[a][b] = rv[b] * r;
+        } else {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) m[a][b] = fma(-cr[a], rv[b], m[a][b]);
+        }
+    }
+    if (colk) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) m[a][BK] = (a == AK && rowk) ? r : -cr[a];
+    }
+}
+template <int... KK>
+__device__ __forceinline__ void r64_gj_chunk(std::integer_sequence<int, KK...>, double (&m)[4][8], int kc, int n, int ri, int cj, double* buf, int& bad, double* piv) {
+    (r64_gj_step<KK>(m, kc, n, ri, cj, buf, bad, piv), ...);
+}
+
 __device__ int r64_inverse_reg(double* M, int n, int ld, double& logdet, double* buf) {
-    const int tid = threadIdx.x, i = tid >> 2, c = tid & 3;
-    double m[32];
+    const int tid = threadIdx.x, ri = tid >> 4, cj = tid & 15;
+    double m[4][8];
     __syncthreads();   // the callers fill M with another thread-to-element map (the in-LDS version read back its own elements)
 #pragma unroll
-    for (int jj = 0; jj < 32; ++jj) { const int j = 32 * c + jj; m[jj] = (i < n && j < n) ? M[(size_t)i * ld + j] : 0.0; }
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { const int i = 4 * ri + a, j = 8 * cj + b; m[a][b] = (i < n && j < n) ? M[(size_t)i * ld + j] : 0.0; }
     int bad = 0;
-    double ld_acc = 0.0;
+    double* piv = buf + 512;            // [128] the pivots
+#pragma unroll 1
     for (int kc = 0; kc < 4; ++kc) {
         if (32 * kc >= n) break;
-#pragma unroll
-        for (int kk = 0; kk < 32; ++kk) {
-            const int k = 32 * kc + kk;
-            if (k < n) {                                   // (uniform)
-                double* cb = buf + 256 * (k & 1);
-                double* rb = cb + 128;
-                if (c == kc) cb[i] = m[kk];
-                if (i == k) {
-#pragma unroll
-                    for (int jj = 0; jj < 32; ++jj) rb[32 * c + jj] = m[jj];
-                }
-                __syncthreads();                           // (the other buffer was last read before the previous barrier)
-                const double p = rb[k];
-                if (!(p > 0.0) && !bad) bad = k + 1;
-                const double ps = p > 0.0 ? p : 1.0, r = 1.0 / ps;
-                if (tid == (k & (R64_NT - 1))) ld_acc += log(ps);
-                const double ci = cb[i];
-                if (i == k) {
-#pragma unroll
-                    for (int jj = 0; jj < 32; ++jj) m[jj] = rb[32 * c + jj] * r;
-                } else {
-                    const double cr = ci * r;
-#pragma unroll
-                    for (int jj = 0; jj < 32; ++jj) m[jj] = fma(-cr, rb[32 * c + jj], m[jj]);
-                }
-                if (c == kc) m[kk] = (i == k) ? r : -ci * r;
-            }
-        }
+        r64_gj_chunk(std::make_integer_sequence<int, 32>{}, m, kc, n, ri, cj, buf, bad, piv);
     }
     __syncthreads();
 #pragma unroll
-    for (int jj = 0; jj < 32; ++jj) { const int j = 32 * c + jj; if (i < n && j < n) M[(size_t)i * ld + j] = m[jj]; }
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { const int i = 4 * ri + a, j = 8 * cj + b; if (i < n && j < n) M[(size_t)i * ld + j] = m[a][b]; }
+    const double ld_acc = tid < n ? log(piv[tid]) : 0.0;
     logdet = r64_sum(ld_acc, buf);      // (two barriers inside: the stores above are visible to the workgroup afterwards)
     return bad;
 }
@@ -463,9 +529,12 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
             aa += v_al[i] * v_al[i]; ya += (double)ys[i] * v_al[i]; ag += v_al[i] * v_ga[i]; bg += v_be[i] * v_ga[i];
             bd += v_be[i] * v_de[i]; ab += v_al[i] * v_be[i];
         }
-        trAinv = r64_sum(trAinv, red); trAinvG = r64_sum(trAinvG, red); aGa = r64_sum(aGa, red); trA2 = r64_sum(trA2, red);
-        trPA = r64_sum(trPA, red); trPP = r64_sum(trPP, red); trAinvKll = r64_sum(trAinvKll, red); aKlla = r64_sum(aKlla, red);
-        aa = r64_sum(aa, red); ya = r64_sum(ya, red); ag = r64_sum(ag, red); bg = r64_sum(bg, red); bd = r64_sum(bd, red); ab = r64_sum(ab, red);
+        {   // fourteen sums, one pair of barriers (gj_s is free here: 14 x 8 doubles)
+            double sv[14] = {trAinv, trAinvG, aGa, trA2, trPA, trPP, trAinvKll, aKlla, aa, ya, ag, bg, bd, ab};
+            r64_sum_n<14>(sv, gjc);
+            trAinv = sv[0]; trAinvG = sv[1]; aGa = sv[2]; trA2 = sv[3]; trPA = sv[4]; trPP = sv[5]; trAinvKll = sv[6]; aKlla = sv[7];
+            aa = sv[8]; ya = sv[9]; ag = sv[10]; bg = sv[11]; bd = sv[12]; ab = sv[13];
+        }
         for (int i = tid; i < n; i += R64_NT) { vb[V_BETA * vld + i] = (float)v_be[i]; vb[V_GAMMA * vld + i] = (float)v_ga[i]; vb[V_DELTA * vld + i] = (float)v_de[i]; }
         if (a.want_hess && a.P) {
             float* P32 = a.P + (size_t)t * ld * ld;
@@ -675,8 +744,12 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
         if (i == j) qq0 += om;
         qq1 += om * k0; qq2 += om * os * k1 * u * gl;
     }
-    oc0 = r64_sum(oc0, red); oc1 = r64_sum(oc1, red); ma0 = r64_sum(ma0, red); ma1 = r64_sum(ma1, red); ma2 = r64_sum(ma2, red);
-    qq0 = r64_sum(qq0, red); qq1 = r64_sum(qq1, red); qq2 = r64_sum(qq2, red);
+    {   // eight sums, one pair of barriers
+        __shared__ double red8[8 * (R64_NT / 64)];
+        double sv[8] = {oc0, oc1, ma0, ma1, ma2, qq0, qq1, qq2};
+        r64_sum_n<8>(sv, red8);
+        oc0 = sv[0]; oc1 = sv[1]; ma0 = sv[2]; ma1 = sv[3]; ma2 = sv[4]; qq0 = sv[5]; qq1 = sv[6]; qq2 = sv[7];
+    }
     if (tid == 0) {                                 // grad_phi f_out, v = H^-1 grad (solve_v_task)
         const double d1[3] = {sc[S_D1N], sc[S_D1S], sc[S_D1L]};
         const double g[3] = {(qq0 + ma0) * d1[0], (ma1 + oc0 + qq1) * d1[1], (ma2 + oc1 + qq2) * d1[2]};
