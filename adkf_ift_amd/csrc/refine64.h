@@ -177,6 +177,28 @@ __device__ __forceinline__ void r64_mv(int M, int K, FA fa, FX fx, FE fe) {
     __syncthreads();
 }
 
+// y_i = sum_k ft(k, i) fx(k) with the threads along i (coalesced for the COLUMNS of a row-major matrix, i.e. for M^T x - and for M x when
+// M is symmetric: A^-1, G, S^-1, W_ss, W_qq): no cross-lane reduction at all - the four quarters of the workgroup take k = q, q + 4, ...
+// of 128 outputs at a time and their partial sums are added in a fixed order through `part` (512 doubles of LDS).  The wave-per-row
+// version above pays six exchange steps per row; seven of the path's ten mat-vecs and its three column sums run through this one.
+template <class FT, class FX, class FE>
+__device__ __forceinline__ void r64_mv_cols(int N, int K, FT ft, FX fx, FE fe, double* part) {
+    const int il = threadIdx.x & 127, q = threadIdx.x >> 7;
+    for (int i0 = 0; i0 < N; i0 += 128) {
+        const int i = i0 + il;
+        double s = 0.0;
+        if (i < N) {
+#pragma unroll 4
+            for (int k = q; k < K; k += 4) s += ft(k, i) * fx(k);
+        }
+        __syncthreads();
+        part[q * 128 + il] = s;
+        __syncthreads();
+        if (q == 0 && i < N) fe(i, (part[il] + part[128 + il]) + (part[256 + il] + part[384 + il]));
+    }
+    __syncthreads();
+}
+
 // Squared distances of a flagged task in float64, straight from the float32 features.  The GEMM form of the float32 stage
 // (|x|^2 + |y|^2 - 2 x.y) carries eps32 |x|^2 into every entry: nothing for the benchmark shapes, but for clustered
 // low-dimensional features (the flagged tasks) it was the LAST float32 input of the float64 path and the whole remaining error
@@ -194,6 +216,21 @@ __device__ void r64_distances(const float* X, const float* Y, int nx, int ny, in
     r64_mm(nx, ny, d, [=](int i, int k) { return (double)X[(size_t)i * d + k]; }, [=](int k, int j) { return (double)Y[(size_t)j * d + k]; },
        [=](int i, int j, double v) { const double q = sx[i] + sy[j] - 2.0 * v; out[(size_t)i * ldo + j] = (same && i == j) ? 0.0 : (q > 0.0 ? q : 0.0); }, stage);
 }
+
+// The exponential factor of the kernel function alone, and kappa, kappa', kappa'' from it.  A float64 exp is ~40 dependent instructions
+// and the path evaluated it nine times per matrix element; up to 128 points the factors of K_ss, K_qs, K_qq are computed ONCE per launch
+// and parked in the (then unused) scratch region of the blocked inverse (r64_scratch_offset: exactly ns^2 + nq ns + nq^2 doubles).
+__device__ __forceinline__ double exp_term_d(int kind, double u) { return kind == 0 ? exp(-0.5 * u) : exp(-2.23606797749979 * sqrt(u)); }
+__device__ __forceinline__ void kappa3_e(int kind, double u, double e, double& k0, double& k1, double& k2) {
+    if (kind == 0) { k0 = e; k1 = -0.5 * e; k2 = 0.25 * e; }
+    else {
+        const double r = sqrt(u);
+        k0 = (1.0 + 2.23606797749979 * r + (5.0 / 3.0) * u) * e;
+        k1 = -(5.0 / 6.0) * (1.0 + 2.23606797749979 * r) * e;
+        k2 = (25.0 / 12.0) * e;
+    }
+}
+__device__ __forceinline__ double exp_cached(const double* E, size_t idx, int kind, double u) { return E ? E[idx] : exp_term_d(kind, u); }
 
 __device__ __forceinline__ void kappa3_d(int kind, double u, double& k0, double& k1, double& k2) {
     if (kind == 0) { k0 = exp(-0.5 * u); k1 = -0.5 * k0; k2 = 0.25 * k0; }
@@ -462,6 +499,10 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
     double* DDss = W + r64_dd_offset(ld, ldq);      // float64 squared distances (k_cotangent64 reads them again)
     double* DDqs = DDss + (size_t)ld * ld;
     double* DDqq = DDqs + (size_t)ldq * ld;
+    // parked exponential factors (see exp_term_d); null beyond 128 points, where the region is the blocked inverse's scratch
+    double* const Ess = (ld <= R64_LDS_POINTS && ldq <= R64_LDS_POINTS) ? W + r64_scratch_offset(ld, ldq) : nullptr;
+    double* const Eqs = Ess ? Ess + (size_t)ld * ld : nullptr;
+    double* const Eqq = Ess ? Eqs + (size_t)ldq * ld : nullptr;
     const float* Zs = a.Zs + (size_t)t * ld * a.d;
     r64_distances(Zs, Zs, n, n, a.d, DDss, ld, gjc, gjr, true, stage);
     if (m > 0) {
@@ -477,7 +518,9 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
     // ---- A, Cholesky, A^-1, alpha
     for (int e = tid; e < n * n; e += R64_NT) {
         const int i = e / n, j = e % n;
-        double k0, k1, k2; kappa3_d(kind, DDss[(size_t)i * ld + j] * il2, k0, k1, k2);
+        const double u = DDss[(size_t)i * ld + j] * il2, ex = exp_term_d(kind, u);
+        if (Ess) Ess[(size_t)i * ld + j] = ex;
+        double k0, k1, k2; kappa3_e(kind, u, ex, k0, k1, k2);
         A1[(size_t)i * ld + j] = os * k0 + (i == j ? noise : 0.0);
     }
     double logdetA;
@@ -487,8 +530,8 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
     R64_STOP(2);   // + A, A^-1
     float* Ai32 = a.Ainv + (size_t)t * ld * ld;
     for (int e = tid; e < n * n; e += R64_NT) { const int i = e / n, j = e % n; Ai32[(size_t)i * ld + j] = (float)A1[(size_t)i * ld + j]; }
-    r64_mv(n, n, [=](int i, int k) { return A1[(size_t)i * ld + k]; }, [=](int k) { return (double)ys[k]; },
-           [=](int i, double v) { v_al[i] = v; vb[V_ALPHA * vld + i] = (float)v; });
+    r64_mv_cols(n, n, [=](int k, int i) { return A1[(size_t)k * ld + i]; }, [=](int k) { return (double)ys[k]; },
+                [=](int i, double v) { v_al[i] = v; vb[V_ALPHA * vld + i] = (float)v; }, gjc);   // (A^-1 is symmetric)
 
     R64_STOP(3);   // + copy-out, alpha
     // ---- inner scalars and the 3 x 3 Hessian (oracle/closed_form.py::inner_stage)
@@ -496,13 +539,13 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
         for (int e = tid; e < n * n; e += R64_NT) {   // G = dK/dl
             const int i = e / n, j = e % n;
             const double u = DDss[(size_t)i * ld + j] * il2;
-            double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
+            double k0, k1, k2; kappa3_e(kind, u, exp_cached(Ess, (size_t)i * ld + j, kind, u), k0, k1, k2);
             A2[(size_t)i * ld + j] = os * k1 * u * (-2.0 / ls);
         }
         __syncthreads();
-        r64_mv(n, n, [=](int i, int k) { return A2[(size_t)i * ld + k]; }, [=](int k) { return v_al[k]; }, [=](int i, double v) { v_be[i] = v; });
-        r64_mv(n, n, [=](int i, int k) { return A1[(size_t)i * ld + k]; }, [=](int k) { return v_al[k]; }, [=](int i, double v) { v_ga[i] = v; });
-        r64_mv(n, n, [=](int i, int k) { return A1[(size_t)i * ld + k]; }, [=](int k) { return v_be[k]; }, [=](int i, double v) { v_de[i] = v; });
+        r64_mv_cols(n, n, [=](int k, int i) { return A2[(size_t)k * ld + i]; }, [=](int k) { return v_al[k]; }, [=](int i, double v) { v_be[i] = v; }, gjc);
+        r64_mv_cols(n, n, [=](int k, int i) { return A1[(size_t)k * ld + i]; }, [=](int k) { return v_al[k]; }, [=](int i, double v) { v_ga[i] = v; }, gjc);
+        r64_mv_cols(n, n, [=](int k, int i) { return A1[(size_t)k * ld + i]; }, [=](int k) { return v_be[k]; }, [=](int i, double v) { v_de[i] = v; }, gjc);
         if (a.want_hess) {
             __syncthreads();
             r64_mm(n, n, n, [=](int i, int k) { return A1[(size_t)i * ld + k]; }, [=](int k, int j) { return A2[(size_t)k * ld + j]; },
@@ -519,7 +562,7 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
             if (a.want_hess) {
                 const double pij = A3[(size_t)i * ld + j], pji = A3[(size_t)j * ld + i];
                 const double u = DDss[(size_t)i * ld + j] * il2;
-                double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
+                double k0, k1, k2; kappa3_e(kind, u, exp_cached(Ess, (size_t)i * ld + j, kind, u), k0, k1, k2);
                 const double Kll = os * (k2 * 4.0 * u * u + k1 * 6.0 * u) * il2;
                 trPA += pij * ai; trPP += pij * pji; trAinvKll += ai * Kll; aKlla += v_al[i] * v_al[j] * Kll;
             }
@@ -592,7 +635,9 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
     const float* yq = a.y_q ? a.y_q + (size_t)t * ldq : nullptr;
     for (int e = tid; e < m * n; e += R64_NT) {
         const int i = e / n, j = e % n;
-        double k0, k1, k2; kappa3_d(kind, DDqs[(size_t)i * ld + j] * il2, k0, k1, k2);
+        const double u = DDqs[(size_t)i * ld + j] * il2, ex = exp_term_d(kind, u);
+        if (Eqs) Eqs[(size_t)i * ld + j] = ex;
+        double k0, k1, k2; kappa3_e(kind, u, ex, k0, k1, k2);
         B1[(size_t)i * ld + j] = os * k0;
     }
     __syncthreads();
@@ -613,7 +658,9 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
     r64_mm(m, m, n, [=](int i, int k) { return B2[(size_t)i * ld + k]; }, [=](int k, int j) { return B1[(size_t)j * ld + k]; },
            [=](int i, int j, double v) {                                            // Sigma_q = K_qq + noise I - C K_sq, the lower triangle mirrored
                if (j > i) return;
-               double k0, k1, k2; kappa3_d(kind, DDqq[(size_t)i * ldq + j] * il2, k0, k1, k2);
+               const double u = DDqq[(size_t)i * ldq + j] * il2, ex = exp_term_d(kind, u);
+               if (Eqq) { Eqq[(size_t)i * ldq + j] = ex; Eqq[(size_t)j * ldq + i] = ex; }
+               double k0, k1, k2; kappa3_e(kind, u, ex, k0, k1, k2);
                const double sv = os * k0 + (i == j ? noise : 0.0) - v;
                S1[(size_t)i * ldq + j] = sv; S1[(size_t)j * ldq + i] = sv;
            }, stage);
@@ -625,18 +672,15 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
         float* S32 = a.S + (size_t)t * ldq * ldq;
         for (int e = tid; e < m * m; e += R64_NT) { const int i = e / m, j = e % m; S32[(size_t)i * ldq + j] = (float)S1[(size_t)i * ldq + j]; }
     }
-    r64_mv(m, m, [=](int i, int k) { return S1[(size_t)i * ldq + k]; }, [=](int k) { return v_r[k]; }, [=](int i, double v) { v_e[i] = v; });
+    r64_mv_cols(m, m, [=](int k, int i) { return S1[(size_t)k * ldq + i]; }, [=](int k) { return v_r[k]; }, [=](int i, double v) { v_e[i] = v; }, gjc);
     double q = 0.0;
     for (int i = tid; i < m; i += R64_NT) {
         q += v_r[i] * v_e[i];
         vb[V_MU * vld + i] = (float)v_mu[i]; vb[V_R * vld + i] = (float)v_r[i]; vb[V_E * vld + i] = (float)v_e[i];
     }
     q = r64_sum(q, red);
-    for (int j = tid; j < n; j += R64_NT) {
-        double s = 0.0;
-        for (int i = 0; i < m; ++i) s += B2[(size_t)i * ld + j] * v_e[i];
-        vb[V_CTE * vld + j] = (float)s;
-    }
+    r64_mv_cols(n, m, [=](int k, int j) { return B2[(size_t)k * ld + j]; }, [=](int k) { return v_e[k]; },
+                [=](int j, double v) { vb[V_CTE * vld + j] = (float)v; }, gjc);                                      // C^T e
     if (tid == 0) {
         const double f = 0.5 * q + 0.5 * logdetS + 0.5 * (double)m * 1.8378770664093453;
         sc[S_FOUT] = (float)f; sc[S_LOGDETS] = (float)logdetS;
@@ -701,15 +745,16 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
     const double* Dss = W + r64_dd_offset(ld, ldq);  // the float64 squared distances k_refine64 computed
     const double* Dqs = Dss + (size_t)ld * ld;
     const double* Dqq = Dqs + (size_t)ldq * ld;
+    // the exponential factors refine64_task parked for this launch (null beyond 128 points)
+    const double* const Ess = (ld <= R64_LDS_POINTS && ldq <= R64_LDS_POINTS) ? W + r64_scratch_offset(ld, ldq) : nullptr;
+    const double* const Eqs = Ess ? Ess + (size_t)ld * ld : nullptr;
+    const double* const Eqq = Ess ? Eqs + (size_t)ldq * ld : nullptr;
     float* vb = a.vecs + (size_t)t * NVEC * vld;
     const double dir = a.dirscale, corr = a.with_hessian ? (double)a.corrscale : 0.0;
 
-    for (int j = tid; j < n; j += R64_NT) {        // C^T e
-        double s = 0.0;
-        for (int i = 0; i < m; ++i) s += B2[(size_t)i * ld + j] * v_e[i];
-        v_cte[j] = s;
-    }
-    __syncthreads();
+    __shared__ double mvbuf[512];                   // partial sums of r64_mv_cols
+    r64_mv_cols(n, m, [=](int k, int j) { return B2[(size_t)k * ld + j]; }, [=](int k) { return v_e[k]; },
+                [=](int j, double v) { v_cte[j] = v; }, mvbuf);                                                      // C^T e
     r64_mm(m, n, m, [=](int i, int k) { return S1[(size_t)i * ldq + k]; }, [=](int k, int j) { return B2[(size_t)k * ld + j]; },
            [=](int i, int j, double v) { B1[(size_t)i * ld + j] = 0.5 * (v - v_e[i] * v_cte[j]); }, stage);   // Omega C = (S^-1 C - e (C^T e)^T) / 2
     R64_STOP(9);   // (8 = all of refine64_task) + C^T e, Omega C
@@ -721,7 +766,7 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
                    const double MA = v + 0.5 * (v_cte[i] * v_al[j] + v_al[i] * v_cte[j]);
                    A2[(size_t)i * ld + j] = MA;
                    const double u = Dss[(size_t)i * ld + j] * il2;
-                   double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
+                   double k0, k1, k2; kappa3_e(kind, u, exp_cached(Ess, (size_t)i * ld + j, kind, u), k0, k1, k2);
                    if (i == j) *pm0 += MA;
                    *pm1 += MA * k0; *pm2 += MA * os * k1 * u * gl;
                }, stage);
@@ -731,7 +776,7 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
         const int i = e / n, j = e % n;
         const double MB = -2.0 * B1[(size_t)i * ld + j] - v_e[i] * v_al[j];
         const double u = Dqs[(size_t)i * ld + j] * il2;
-        double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
+        double k0, k1, k2; kappa3_e(kind, u, exp_cached(Eqs, (size_t)i * ld + j, kind, u), k0, k1, k2);
         B1[(size_t)i * ld + j] = dir * MB * os * k1 * il2;
         oc0 += MB * k0; oc1 += MB * os * k1 * u * gl;
     }
@@ -739,7 +784,7 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
         const int i = e / m, j = e % m;
         const double om = 0.5 * (S1[(size_t)i * ldq + j] - v_e[i] * v_e[j]);
         const double u = Dqq[(size_t)i * ldq + j] * il2;
-        double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
+        double k0, k1, k2; kappa3_e(kind, u, exp_cached(Eqq, (size_t)i * ldq + j, kind, u), k0, k1, k2);
         S2[(size_t)i * ldq + j] = dir * om * os * k1 * il2;
         if (i == j) qq0 += om;
         qq1 += om * k0; qq2 += om * os * k1 * u * gl;
@@ -789,7 +834,7 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
     // A^-1 B_v = (cn - cs noise) A^-1 + cs I + cl P comes out of the matrix pipe, the rest is its epilogue
     auto wss_of = [=](int i, int j, double xa) {
         const double u = Dss[(size_t)i * ld + j] * il2;
-        double k0, k1, k2; kappa3_d(kind, u, k0, k1, k2);
+        double k0, k1, k2; kappa3_e(kind, u, exp_cached(Ess, (size_t)i * ld + j, kind, u), k0, k1, k2);
         double wss = dir * A2[(size_t)i * ld + j] * os * k1 * il2;
         if (corr != 0.0) {
             const double dgdA = (-0.5 * xa + 0.5 * (v_w[i] * v_al[j] + v_al[i] * v_w[j])) / fn;
@@ -815,14 +860,10 @@ __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {
     // (float64: z_i sum_k W_ik - sum_k W_ik z_k loses cond digits of sixteen, not of seven - the difference form was what the
     // float32 kernels could not afford to skip; the W Z products run on the matrix pipe)
     double* rs_ss = v_be; double* rs_qs_col = v_ga; double* rs_qs_row = v_de; double* rs_qq = v_w;   // (all spent by now)
-    for (int i = tid; i < n; i += R64_NT) {          // column sums: a thread per column is coalesced
-        double s2 = 0.0;
-        for (int q = 0; q < m; ++q) s2 += B1[(size_t)q * ld + i];
-        rs_qs_col[i] = s2;
-    }
-    r64_mv(n, n, [=](int i, int k) { return A2[(size_t)i * ld + k]; }, [](int) { return 1.0; }, [=](int i, double v) { rs_ss[i] = v; });
+    r64_mv_cols(n, m, [=](int k, int i) { return B1[(size_t)k * ld + i]; }, [](int) { return 1.0; }, [=](int i, double v) { rs_qs_col[i] = v; }, mvbuf);
+    r64_mv_cols(n, n, [=](int k, int i) { return A2[(size_t)k * ld + i]; }, [](int) { return 1.0; }, [=](int i, double v) { rs_ss[i] = v; }, mvbuf);   // (W_ss, W_qq: symmetric)
     r64_mv(m, n, [=](int i, int k) { return B1[(size_t)i * ld + k]; }, [](int) { return 1.0; }, [=](int i, double v) { rs_qs_row[i] = v; });
-    r64_mv(m, m, [=](int i, int k) { return S2[(size_t)i * ldq + k]; }, [](int) { return 1.0; }, [=](int i, double v) { rs_qq[i] = v; });
+    r64_mv_cols(m, m, [=](int k, int i) { return S2[(size_t)k * ldq + i]; }, [](int) { return 1.0; }, [=](int i, double v) { rs_qq[i] = v; }, mvbuf);
     R64_STOP(13);  // + row / column sums of the weights
     if (a.dZs) {
         float* out = a.dZs + (size_t)t * ld * d;
