@@ -309,15 +309,19 @@ __device__ __forceinline__ void r64_gj_step(double (&m)[4][8], int kc, int n, in
         for (int b = 0; b < 8; ++b) rb[8 * cj + b] = m[AK][b];
     }
     __syncthreads();                                   // (the other buffer was last read before the previous barrier)
-    const double p = rb[k];
-    if (!(p > 0.0) && !bad) bad = k + 1;
-    const double ps = p > 0.0 ? p : 1.0, r = 1.0 / ps;
-    if (threadIdx.x == 0) piv[k] = ps;                 // (the logarithms are taken after the last step, one thread per pivot)
+    // (all thirteen LDS reads of the step are issued before the reciprocal starts: its ~150 cycles of dependent operations cover their latency)
     double rv[8], cr[4];
+    const double p = rb[k];
 #pragma unroll
     for (int b = 0; b < 8; ++b) rv[b] = rb[8 * cj + b];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) cr[a] = cb[4 * ri + a] * r;
+    for (int a = 0; a < 4; ++a) cr[a] = cb[4 * ri + a];
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(p > 0.0) && !bad) bad = k + 1;
+    const double ps = p > 0.0 ? p : 1.0, r = 1.0 / ps;
+    if (threadIdx.x == 0) piv[k] = ps;                 // (the logarithms are taken after the last step, one thread per pivot)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) cr[a] *= r;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         if (a == AK && rowk) {
