@@ -1,4 +1,5 @@
 # round-4: kernel timeline of C5 with two task groups: tools/r04_c5_trace.sh (through gpurun)
+# (historical: the task groups exist at commit ef34797 only, profiles/r04_c5_groups.txt; on later trees this traces the single-stream path)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export ADKF_LG_GROUPS=${1:-2} ADKF_LG_SPREAD=${2:-1}
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_c5g -o c5g -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-meta-test --converge-steps 0 --tasks 8 --n-support 1024 --n-query 1024 --d 512 > gpurun_out/prof_c5g.log 2>&1
