@@ -151,3 +151,31 @@ def test_batchnorm_running_statistics_round_trip():
     del ref["graph_feature_extractor.final_norm_layer.running_var"]
     with pytest.raises(KeyError):
         GraphFeatureExtractor(cfg).double().load_reference_state_dict(ref)
+
+
+def test_readout_projection_of_pooled_hidden_states_is_the_same_algebra():
+    """What the device path does by default (csrc/readout.h, k_readout_h_*): pool the HIDDEN activations of the value MLPs per
+    head, p[h, g, :] = sum_v w[v, h] r_v, then project, W2[h] p + b2[h] sum_v w[v, h] - against the module's own order (project every
+    node, then pool: fs_mol/modules/graph_readout.py:219-223, 242-252).  Pure torch in float64 on the CPU: the identity behind
+    ``CombinedGraphReadout._project_pooled``, for the softmax-weighted and the sigmoid-weighted head, an empty graph included."""
+    from adkf_ift_amd.gnn import CombinedGraphReadout, _segment_softmax
+
+    torch.manual_seed(4)
+    nh, hd, D, sizes = 3, 5, 11, [4, 0, 7, 1]
+    n2g = torch.cat([torch.full((n,), g, dtype=torch.long) for g, n in enumerate(sizes)])
+    G, V, hid = len(sizes), int(n2g.shape[0]), nh * hd
+    ro = CombinedGraphReadout(D, 9, nh, hd).double()
+    x = torch.randn(V, D, dtype=torch.float64)
+    h = torch.relu(ro.first(x))
+    h_ms, h_mv, h_ss, h_sv = h.split(hid, dim=1)
+    for scores, hval, layer, softmax in ((ro.mean_score_out(h_ms), h_mv, ro.mean_value_out, True), (ro.sum_score_out(h_ss), h_sv, ro.sum_value_out, False)):
+        w = _segment_softmax(scores, n2g, G) if softmax else torch.sigmoid(scores)                      # [V, nh]
+        want = torch.zeros(G, hid, dtype=torch.float64).index_add(0, n2g, (w.unsqueeze(-1) * layer(hval).view(V, nh, hd)).reshape(V, hid))
+        p = torch.zeros(nh, G, hid, dtype=torch.float64)
+        for hh in range(nh):
+            p[hh].index_add_(0, n2g, w[:, hh:hh + 1] * hval)
+        wtot = torch.zeros(G, nh, dtype=torch.float64).index_add(0, n2g, w)
+        got = ro._project_pooled(p, wtot, layer)
+        assert torch.allclose(got, want, rtol=1e-12, atol=1e-13)
+        if softmax:   # the weights of a graph sum to one (zero for the empty graph): the kernel returns exactly that
+            assert torch.allclose(wtot, torch.tensor([[1.0] * nh if n > 0 else [0.0] * nh for n in sizes], dtype=torch.float64), atol=1e-12)
