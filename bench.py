@@ -61,6 +61,10 @@ def parse(argv=None):
     ap.add_argument("--no-meta-test", action="store_true",
                     help="skip the `meta_test` object (the reference's published wall-clock protocol on synthetic molecular tasks)")
     ap.add_argument("--meta-test-tasks", type=int, default=157)
+    ap.add_argument("--side-configs", choices=("auto", "on", "off"), default="auto",
+                    help="the other BASELINE.json configurations as side objects of the line, measured AFTER the headline loop like `converged` / "
+                         "`meta_test`: c1 (64 x 32 x 64), t512 (512 tasks/GPU), c5 (8 x 1024 x 512), c3 (default GNN+ECFP+fc model, 16-shot) and c3 at "
+                         "the reference's CLI shape (support 64 / query 256).  auto: only on the default C2 command, one GPU")
     ap.add_argument("--gemm-tuning", choices=("off", "shipped"), default="shipped",
                     help="algorithm choice of the two library GEMMs of the theta = W feature map (adkf_ift_amd/gemm_tuning.py): "
                          "hipBLASLt's heuristic, or the recorded choice for these shapes (same float32 arithmetic)")
@@ -120,6 +124,16 @@ def launch_ranks(n: int, argv, timeout_s: float = 3000.0) -> int:
     sys.stdout.write(f0.read().decode())
     sys.stdout.flush()
     return rc
+
+
+def profile_json(name: str):
+    """The newest committed PMC summary of that name (profiles/r05_<name>, else r04_<name>) and its path, or (None, None)."""
+    for rnd in ("r05", "r04"):
+        f = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
+        if os.path.exists(f):
+            with open(f) as fh:
+                return json.load(fh), f"profiles/{rnd}_{name}"
+    return None, None
 
 
 def metric_name(N: int, d: int) -> str:
@@ -206,18 +220,6 @@ def main():
 
     T = args.global_tasks // world if args.global_tasks else args.tasks
     N, Nq, d, I = args.n_support, args.n_query, args.d, args.inner_evals
-    tasks = make_tasks(T, N, d, N_q=Nq, regression=args.regression, first_task=rank * T)
-    X_s, X_q, y_s, y_q = (a.to(dev) for a in (tasks.X_s, tasks.X_q, tasks.y_s, tasks.y_q))
-    W = tasks.W.to(dev).clone().requires_grad_(True)
-    opt = ClipAdam([W], lr=1e-4)  # fs_mol/adaptive_dkt_train.py --lr default; mean + clip + Adam in the library (2 launches)
-
-    def step_cfg(converge: bool) -> MetaStepConfig:
-        return MetaStepConfig(gp_kernel=args.kernel, inner_max_evals=(200 if converge else I),
-                              inner_exact_evals=not converge, clip_value=1.0, use_ard=args.ard, use_numeric_labels=args.regression)
-
-    cfg = step_cfg(args.converge)
-    backend = GraphedGPBackend() if args.graph else None
-    features = LinearFeatureMap(X_s, X_q, W)  # one GEMM for support+query rows; chunked-bmm backward
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -225,31 +227,57 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    class Workload:
+        """Synthetic tasks of one shape resident in HBM + the meta-step over them."""
+
+        def __init__(self, T_, N_, Nq_, d_, regression=False, first_task=0):
+            self.T, self.N, self.Nq, self.d = T_, N_, Nq_, d_
+            self.tasks = make_tasks(T_, N_, d_, N_q=Nq_, regression=regression, first_task=first_task)
+            self.X_s, self.X_q, self.y_s, self.y_q = (a.to(dev) for a in (self.tasks.X_s, self.tasks.X_q, self.tasks.y_s, self.tasks.y_q))
+            self.W = self.tasks.W.to(dev).clone().requires_grad_(True)
+            self.opt = ClipAdam([self.W], lr=1e-4)  # fs_mol/adaptive_dkt_train.py --lr default; mean + clip + Adam in the library (2 launches)
+            self.features = LinearFeatureMap(self.X_s, self.X_q, self.W)  # one GEMM for support+query rows; chunked-bmm backward
+
+        def timed_loop(self, cfg_, steps, warmup, events=None, backend=None, dist_=False):
+            for _ in range(warmup):
+                meta_step(self.features, [self.W], self.opt, self.y_s, self.y_q, cfg_, distributed=dist_, backend=backend)
+            sync()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                meta_step(self.features, [self.W], self.opt, self.y_s, self.y_q, cfg_, distributed=dist_, backend=backend,
+                          fit_events=events[k] if events else None)
+            t_host = time.perf_counter() - t0   # when the host finished ENQUEUEING the steps (== dt would mean host-bound)
+            sync()
+            dt = time.perf_counter() - t0
+            if dist_:
+                tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt = float(tmax.item())
+            return dt, t_host
+
+    def make_events(n):
+        ev_ = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b_ in ev_:  # create the underlying hipEvents
+            a.record()
+            b_.record()
+        return ev_
+
+    wl = Workload(T, N, Nq, d, regression=args.regression, first_task=rank * T)
+    tasks, X_s, X_q, y_s, y_q, W, features = wl.tasks, wl.X_s, wl.X_q, wl.y_s, wl.y_q, wl.W, wl.features
+
+    def step_cfg(converge: bool, kernel=None, evals=None) -> MetaStepConfig:
+        return MetaStepConfig(gp_kernel=kernel or args.kernel, inner_max_evals=(200 if converge else (evals or I)),
+                              inner_exact_evals=not converge, clip_value=1.0, use_ard=args.ard, use_numeric_labels=args.regression)
+
+    cfg = step_cfg(args.converge)
+    backend = GraphedGPBackend() if args.graph else None
+
     def timed_loop(cfg_, steps, warmup, events=None):
-        for _ in range(warmup):
-            meta_step(features, [W], opt, y_s, y_q, cfg_, distributed=distributed, backend=backend)
-        sync()
-        t0 = time.perf_counter()
-        for k in range(steps):
-            meta_step(features, [W], opt, y_s, y_q, cfg_, distributed=distributed, backend=backend,
-                      fit_events=events[k] if events else None)
-        t_host = time.perf_counter() - t0   # when the host finished ENQUEUEING the steps (== dt would mean host-bound)
-        sync()
-        dt = time.perf_counter() - t0
-        if distributed:
-            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
-        return dt, t_host
+        return wl.timed_loop(cfg_, steps, warmup, events, backend=backend, dist_=distributed)
 
     # HIP events recorded by the library on the launch stream right around the inner-fit kernel (adkf_fit_options_t).
     # Under --graph the captured launch carries no events, so the roofline object is omitted there.
-    ev = None
-    if not args.graph:
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        for a, b_ in ev:  # create the underlying hipEvents
-            a.record()
-            b_.record()
+    ev = make_events(args.steps) if not args.graph else None
     dt, t_host = timed_loop(cfg, args.steps, args.warmup, ev)
     fit_ms = sum(a.elapsed_time(b_) for a, b_ in ev) / len(ev) if ev else None
 
@@ -349,6 +377,100 @@ def main():
         except Exception as e:   # context only: never a reason to lose the headline line
             print(f"[bench] meta_test not measured ({type(e).__name__}: {e})", file=sys.stderr)
 
+    # ---- the other BASELINE.json configurations, measured after the headline loop and outside its clock (like `converged` and
+    # `meta_test`): side objects of the SAME line, so that the driver's record holds every config and not only C2 ----
+    side = {}
+    is_c2 = (T, N, Nq, d, I) == (256, 128, 128, 256, 20) and args.kernel == "rbf" and not (args.ard or args.regression or args.converge or args.graph)
+    want_side = args.side_configs == "on" or (args.side_configs == "auto" and world == 1 and is_c2)
+    if rank == 0 and want_side:
+        def gp_side(name, T_, N_, d_, steps, warmup, label):
+            """One more GP workload through the same meta_step: ms/step, tasks/s, the fit's share of the FP32 peak (HIP events of
+            adkf_fit_options_t on the launch stream, like the headline's roofline object)."""
+            try:
+                w_ = Workload(T_, N_, N_, d_)
+                ev_ = make_events(steps)
+                dt_, th_ = w_.timed_loop(step_cfg(False), steps, warmup, ev_)
+                fms = sum(a.elapsed_time(b_) for a, b_ in ev_) / len(ev_)
+                fl_ = roofline.flops_per_task(N_, N_, d_, I)
+                ach = fl_["inner_fit"] * T_ / (fms * 1e-3) / 1e12
+                side[name] = {"workload": label, "ms_per_step": dt_ / steps * 1e3, "tasks_per_s": T_ * steps / dt_, "steps": steps,
+                              "host_enqueue_ms_per_step": th_ / steps * 1e3,
+                              "fit": {"avg_ms": fms, "algorithmic_flops": fl_["inner_fit"] * T_, "achieved_tflops": ach,
+                                      "frac_of_fp32_peak": ach / roofline.PEAK_FP32_TFLOPS},
+                              "whole_path_frac_of_fp32_peak": T_ * steps / dt_ * fl_["total"] / 1e12 / roofline.PEAK_FP32_TFLOPS}
+                del w_
+            except Exception as e:   # side objects never cost the headline line
+                print(f"[bench] side config {name} not measured ({type(e).__name__}: {e})", file=sys.stderr)
+            torch.cuda.empty_cache()
+
+        gp_side("c1", 64, 32, 64, 50, 10, f"C1: 64 tasks, N_support = N_query = 32, d = 64, exactly {I} evaluations (host-enqueue-bound: compare host_enqueue_ms_per_step)")
+        gp_side("t512", 512, 128, 256, 20, 5, f"512 tasks/GPU/step at the C2 shape (two tasks per CU in the inner fit), exactly {I} evaluations")
+        gp_side("c5", 8, 1024, 512, 5, 2, f"C5: 8 tasks, N_support = N_query = 1024, d = 512, blocked sweep, exactly {I} evaluations (a throughput point: not converged at {I})")
+        if "c5" in side:
+            pm, src = profile_json("c5_fit_pmc.json")
+            if pm is not None:
+                tr = (2.0 * pm["FETCH_SIZE_KB_per_fit"] + pm["WRITE_SIZE_KB_per_fit"]) * 1024.0
+                comp = roofline.bytes_per_task(1024, 1024, 512) * 8
+                side["c5"]["fit"].update({"traffic": tr, "compulsory_bytes": comp, "traffic_ratio": tr / comp, "traffic_source": src,
+                                          "launches_per_fit": pm.get("launches_per_fit")})
+
+        # C3: the full inner loop with the default 25 M-parameter model on synthetic 16-shot molecular tasks (tools/bench_c3.py is the
+        # stand-alone form), plus the same step at the reference's CLI shape (support 64, query 256: fs_mol/adaptive_dkt_train.py:50-61)
+        def c3_side(name, n_tasks, support, query, steps, warmup, with_cpu):
+            try:
+                from adkf_ift_amd.meta_batch import collate_meta_batch, model_meta_step
+                from adkf_ift_amd.models import ADKTModel, ADKTModelConfig
+                from adkf_ift_amd.synthetic import molecular_task
+                gen = torch.Generator().manual_seed(0)
+                mtasks = [molecular_task(support, query, gen) for _ in range(n_tasks)]
+                mb = collate_meta_batch(mtasks).to(dev)
+                torch.manual_seed(0)
+                model = ADKTModel(ADKTModelConfig()).to(dev)   # reference defaults: gnn+ecfp+fc, Matern-5/2, 2048-d features
+                opt_ = torch.optim.Adam(model.feature_extractor_params(), lr=1e-4, fused=True)
+                mcfg = MetaStepConfig(gp_kernel="matern", clip_value=1.0, inner_max_evals=200)
+                for _ in range(warmup):
+                    model_meta_step(model, opt_, mb, mcfg)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    model_meta_step(model, opt_, mb, mcfg)
+                torch.cuda.synchronize(dev)
+                dt_ = (time.perf_counter() - t0) / steps
+                V = int(mb.molecules.node_features.shape[0])
+                E = 2 * sum(int(a.shape[0]) for a in mb.molecules.adjacency_lists)
+                G = int(mb.molecules.num_graphs)
+                fl_ = roofline.dense_flops_c3(V, E, G)
+                gp_fl = sum(roofline.flops_per_task(support, query, 2048, 20)["total"] for _ in range(n_tasks))
+                ach = fl_["step"] / dt_ / 1e12
+                obj = {"workload": f"C3: {n_tasks} tasks/step, {support}-shot, {query} query molecules per task, default GNN+ECFP+fc model "
+                                   f"({sum(p.numel() for p in model.parameters()) / 1e6:.1f} M parameters, random weights), Matern-5/2, inner fit to "
+                                   "convergence, one extractor forward / backward per meta-batch, Adam + clip 1.0",
+                       "ms_per_step": dt_ * 1e3, "tasks_per_s": n_tasks / dt_, "steps": steps, "nodes": V, "message_edges": E, "molecules": G,
+                       "roofline": {"bound": "mfma", "model": "dense layers of the extractor and head, 3 x forward (adkf_ift_amd/roofline.py::dense_flops_c3); "
+                                                               "the GP section's FLOPs are listed beside it, not added",
+                                    "dense_flops_per_step": fl_["step"], "gp_flops_per_step_at_20_evals": gp_fl, "achieved": ach,
+                                    "peak": roofline.PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / roofline.PEAK_FP32_TFLOPS}}
+                del model, opt_, mb
+                torch.cuda.empty_cache()
+                if with_cpu and not args.no_cpu_baseline:
+                    from oracle import gp_oracle as O_
+                    from oracle import ref_cpu_path
+                    torch.manual_seed(0)
+                    cpu_model = ADKTModel(ADKTModelConfig())
+                    rate, n_done, cores, nfev = ref_cpu_path.time_model_tasks(cpu_model, mtasks, O_.KERNEL_MATERN52, budget_s=min(args.cpu_baseline_seconds, 10.0))
+                    obj["cpu_baseline"] = {"value": rate, "unit": "tasks/s", "cores": cores, "kind": "port",
+                                           "sample": f"first {n_done} task(s) of the same meta-batch, sequential, the reference algorithm through the whole model in "
+                                                     f"float32 PyTorch on the host (per task: SciPy L-BFGS-B fit, mean {nfev:.0f} evals; dense Hessian + nested-Jacobian "
+                                                     f"hypergradient = 3 double-backward passes through the extractor), torch threads = {cores}"}
+                    del cpu_model
+                side[name] = obj
+            except Exception as e:
+                print(f"[bench] side config {name} not measured ({type(e).__name__}: {e})", file=sys.stderr)
+            torch.cuda.empty_cache()
+
+        c3_side("c3", 16, 16, 128, 4, 2, True)
+        c3_side("c3_cli_defaults", 16, 64, 256, 3, 1, False)
+
     if rank == 0:
         fl = roofline.flops_per_task(N, Nq, d, I)
         total_tasks = T * world * args.steps
@@ -368,19 +490,16 @@ def main():
             traffic = traffic_src = None
             # the <= 128-register build (two tasks per CU) is taken when the batch has more tasks than the chip has CUs (adkf_gp.hip: num_cus())
             low = T > torch.cuda.get_device_properties(dev).multi_processor_count
-            pmc = os.path.join(ROOT, "profiles", "r04_k_inner_pmc.json")
-            if os.path.exists(pmc) and (T, N, Nq, d, I) == (256, 128, 128, 256, 20) and args.kernel == "rbf" and not args.ard and not args.regression:
-                with open(pmc) as fh:
-                    pm = json.load(fh)
+            plain = args.kernel == "rbf" and not args.ard and not args.regression
+            pm, pm_file = profile_json("k_inner_pmc.json")
+            if pm is not None and (T, N, Nq, d, I) == (256, 128, 128, 256, 20) and plain:
                 traffic = (2.0 * pm["FETCH_SIZE_KB_per_launch"] + pm["WRITE_SIZE_KB_per_launch"]) * 1024.0
-                traffic_src = {"file": "profiles/r04_k_inner_pmc.json", "commit": pm.get("commit"),
-                               "correction": "2 x FETCH_SIZE + WRITE_SIZE"}
-            pmc5 = os.path.join(ROOT, "profiles", "r04_c5_fit_pmc.json")
-            if os.path.exists(pmc5) and (T, N, Nq, d, I) == (8, 1024, 1024, 512, 20) and args.kernel == "rbf" and not args.ard and not args.regression:
-                with open(pmc5) as fh:
-                    pm = json.load(fh)
+                traffic_src = {"file": pm_file, "commit": pm.get("commit"), "correction": "2 x FETCH_SIZE + WRITE_SIZE"}
+            pm, pm_file = profile_json("c5_fit_pmc.json")
+            if pm is not None and (T, N, Nq, d, I) == (8, 1024, 1024, 512, 20) and plain:
                 traffic = (2.0 * pm["FETCH_SIZE_KB_per_fit"] + pm["WRITE_SIZE_KB_per_fit"]) * 1024.0
-                traffic_src = {"file": "profiles/r04_c5_fit_pmc.json", "commit": pm.get("commit"),
+                traffic_src = {"file": pm_file, "commit": pm.get("commit"), "launches_per_fit": pm.get("launches_per_fit"),
+                               "compulsory_bytes": roofline.bytes_per_task(N, Nq, d) * T,
                                "correction": "2 x FETCH_SIZE + WRITE_SIZE, summed over the launches of one adkf_fit call (by dispatch order)"}
             if args.ard:
                 fit_kernel, bound = "ARD inner fit (all launches between the two events)", "mfma"
@@ -417,6 +536,19 @@ def main():
             "cpu_baseline_twin": cpu_twin,
             "parity": parity,
         }
+        # second roofline entry: the outer / hypergradient kernel of the C2 step, from this round's rocprofv3 runs of this command
+        if is_c2 and world == 1:
+            hy, hy_src = profile_json("k_hyper_pmc.json")
+            if hy is not None and hy.get("avg_duration_us"):
+                hf = 13 * N ** 3 * T
+                ach = hf / (hy["avg_duration_us"] * 1e-6) / 1e12
+                tr = (2.0 * hy["FETCH_SIZE_KB_per_launch"] + hy["WRITE_SIZE_KB_per_launch"]) * 1024.0
+                line["roofline_k_hyper"] = {"kernel": "k_hyper<true,0> (the whole outer / hypergradient stage of a task in one workgroup)", "bound": "mfma",
+                                            "achieved": ach, "peak": roofline.PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / roofline.PEAK_FP32_TFLOPS,
+                                            "traffic": tr, "compulsory_bytes": 7 * N * N * 4 * T, "traffic_ratio": tr / (7 * N * N * 4 * T),
+                                            "flops_per_launch": hf, "avg_launch_ms": hy["avg_duration_us"] * 1e-3,
+                                            "source": hy_src + " (rocprofv3 --kernel-trace average and the two --pmc passes of this command; not measured live)"}
+        line.update(side)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()

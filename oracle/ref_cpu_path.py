@@ -57,3 +57,56 @@ def time_tasks(tasks, kind: int, budget_s: float = 15.0, min_tasks: int = 2, thr
         n += 1
     dt = time.perf_counter() - t0
     return n / dt, n, cores, float(np.mean(nfev))
+
+
+# ---- config C3: the same algorithm through the FULL deep-kernel model (GNN + ECFP + fc head) on host cores ---------------------
+def one_model_task(model, batch, kind: int):
+    """One task of fs_mol/utils/adaptive_dkt_utils.py:361-403 with the default model on the CPU in float32: a forward of the
+    extractor on support + query for the re-initialisation, the SciPy L-BFGS-B fit of the three GP parameters on detached
+    features (:87-91), then the reference's dense hypergradient with the closures running the WHOLE model, i.e. one more
+    forward per Hessian / Jacobian / outer call and h = 3 double-backward passes through the extractor
+    (cauchy_hypergradient.py:43-46,78-87,120-121).  ``model`` is this package's torch module on the CPU (pure PyTorch there)."""
+    from torch.func import functional_call
+
+    from adkf_ift_amd.models import _Features
+
+    names = [n for n, _ in model.named_parameters() if not n.startswith("gp_")]
+    theta = tuple(p.detach().clone().requires_grad_(True) for n, p in model.named_parameters() if not n.startswith("gp_"))
+    feat = _Features(model)
+
+    def features(po):
+        return functional_call(feat, {"m." + n: p for n, p in zip(names, po)}, (batch,))
+
+    with torch.no_grad():
+        Zs0, ys, _, yq = features(theta)
+    phi0, pri = O.init_phi(Zs0.double(), bool(model.config.use_numeric_labels), True)
+    phi_star, res = O.fit_phi(Zs0, ys, phi0.float(), pri, kind, dtype=torch.float32)
+    phi = phi_star.float().clone().requires_grad_(True)
+
+    def f_in(po, pi):
+        Zs, y_s, _, _ = features(po)
+        return O.f_inner(Zs, y_s, pi[0], pri, kind)
+
+    def f_out(po, pi):
+        Zs, y_s, Zq, y_q = features(po)
+        return O.f_outer(Zs, y_s, Zq, y_q, pi[0], kind)
+
+    val = dense_ift_hypergradient(f_out, f_in, theta, (phi,))
+    return val.item(), res.nfev
+
+
+def time_model_tasks(model, tasks, kind: int, budget_s: float = 15.0, min_tasks: int = 1, threads=None):
+    """C3's ``cpu_baseline``: tasks strictly sequential until ``budget_s`` seconds are spent; returns (tasks/s, n, cores, nfev)."""
+    import os
+
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = threads or min(avail, 16)
+    torch.set_num_threads(cores)
+    n, nfev = 0, []
+    t0 = time.perf_counter()
+    while n < len(tasks) and (n < min_tasks or time.perf_counter() - t0 < budget_s):
+        _, k = one_model_task(model, tasks[n], kind)
+        nfev.append(k)
+        n += 1
+    dt = time.perf_counter() - t0
+    return n / dt, n, cores, float(np.mean(nfev))
