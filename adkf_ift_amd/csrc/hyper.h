@@ -82,22 +82,30 @@ __device__ __forceinline__ void hy_k3(int kind, float u, float ex, float& k0, fl
 // buf[r][c] = f(src[r][c], r, c) for r < rows, c < cols, 0 elsewhere (r, c < 128).  Two halves so that the loads can be in flight
 // across other work: hy_fetch issues all eight 16-byte loads of a lane (clamped addresses, no branch around a load), hy_put
 // transforms and stores.  FULL (ld = 128, 16-byte alignment): no clamps, affine addresses.
+// (Addresses: a uniform base plus a 32-bit lane offset that is made OPAQUE per call.  hipcc otherwise merges the identical address
+// computations of the passes that visit the same matrix - A^-1 twice, D2_ss three times, the parked factors, W_ss - into 64-bit
+// per-lane addresses that stay alive across the whole kernel, sixteen registers per matrix, and spills them.)
+#define HY_OPAQUE1(v_) asm volatile("" : "+v"(v_))
+// (the same for LDS: every helper derives its lane addresses from a copy of the thread index the optimiser cannot see through)
+__device__ __forceinline__ int hy_tid() { int t = threadIdx.x; HY_OPAQUE1(t); return t; }
 template <bool FULL>
 __device__ __forceinline__ void hy_fetch(float4 (&v)[8], const float* src, int src_ld, int rows) {
     const int tid = threadIdx.x;
+    unsigned base = (unsigned)((tid >> 5) * HY_N + (tid & 31) * 4);
+    if (FULL) HY_OPAQUE1(base);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int r = (tid >> 5) + 16 * u, c4 = (tid & 31) * 4;
-        if (FULL) v[u] = *reinterpret_cast<const float4*>(src + r * HY_N + c4);
+        if (FULL) v[u] = *reinterpret_cast<const float4*>(src + (base + 16u * u * HY_N));
         else {
             const int rc = r < rows ? r : rows - 1, cc = c4 + 3 < src_ld ? c4 : 0;
-            v[u] = *reinterpret_cast<const float4*>(src + (size_t)rc * src_ld + cc);
+            v[u] = *reinterpret_cast<const float4*>(src + (unsigned)(rc * src_ld + cc));   // (32-bit offset from the uniform base: no 64-bit address per load)
         }
     }
 }
 template <bool FULL, class F>
 __device__ __forceinline__ void hy_put(float* buf, int ld, const float4 (&v)[8], int rows, int cols, F f) {
-    const int tid = threadIdx.x;
+    const int tid = hy_tid();
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int r = (tid >> 5) + 16 * u, c4 = (tid & 31) * 4;
@@ -118,7 +126,7 @@ __device__ __forceinline__ void hy_load(float* buf, int ld, const float* src, in
     } else {
         for (int e = threadIdx.x; e < HY_N * HY_N; e += HY_NT) {
             const int r = e >> 7, c = e & 127;
-            buf[r * ld + c] = (r < rows && c < cols) ? f(src[(size_t)r * src_ld + c], r, c) : 0.f;
+            buf[r * ld + c] = (r < rows && c < cols) ? f(src[(unsigned)(r * src_ld + c)], r, c) : 0.f;
         }
     }
 }
@@ -129,26 +137,31 @@ template <bool FULL, bool SYM>
 __device__ __forceinline__ void hy_dist(float (&dv)[8][4], const float* D, int ld, int rows, int cols) {
     const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
     if (FULL && SYM) {
-        const float* q = D + p * HY_N + 16 * w + 4 * g;
+        unsigned q = (unsigned)(p * HY_N + 16 * w + 4 * g);
+        HY_OPAQUE1(q);
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
-            const float4 t = *reinterpret_cast<const float4*>(q + 16 * x * HY_N);
+            const float4 t = *reinterpret_cast<const float4*>(D + (q + 16u * x * HY_N));
             dv[x][0] = t.x; dv[x][1] = t.y; dv[x][2] = t.z; dv[x][3] = t.w;
         }
     } else if (FULL) {
-        const float* q = D + (16 * w + 4 * g) * HY_N + p;
+        unsigned q = (unsigned)((16 * w + 4 * g) * HY_N + p);
+        HY_OPAQUE1(q);
 #pragma unroll
         for (int x = 0; x < 8; ++x)
 #pragma unroll
-            for (int y = 0; y < 4; ++y) dv[x][y] = q[y * HY_N + 16 * x];
+            for (int y = 0; y < 4; ++y) dv[x][y] = D[q + (unsigned)(y * HY_N + 16 * x)];
     } else {
+        // clamped once per row and per column: four row offsets and eight column offsets, 32-bit, from the uniform base
+        unsigned ro[4];
 #pragma unroll
-        for (int x = 0; x < 8; ++x)
+        for (int y = 0; y < 4; ++y) ro[y] = (unsigned)(min(16 * w + 4 * g + y, rows - 1) * ld);
 #pragma unroll
-            for (int y = 0; y < 4; ++y) {
-                const int i = min(16 * w + 4 * g + y, rows - 1), j = min(16 * x + p, cols - 1);
-                dv[x][y] = D[(size_t)i * ld + j];
-            }
+        for (int x = 0; x < 8; ++x) {
+            const unsigned co = (unsigned)min(16 * x + p, cols - 1);
+#pragma unroll
+            for (int y = 0; y < 4; ++y) dv[x][y] = D[ro[y] + co];
+        }
     }
 }
 
@@ -191,7 +204,7 @@ struct HyFrag {
 // (k_dz: four accumulator sets) fetches and multiplies in turn - the SIMD's other wave covers the LDS latency.
 template <bool A_MN, bool B_MN, bool DB = true>
 __device__ __forceinline__ void hy_gemm(f32x4_t (&acc)[8], const float* A, int lda, const float* B, int ldb, int kblocks) {
-    const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
+    const int tid = hy_tid(), lane = tid & 63, p = lane & 15, g = lane >> 4, w = tid >> 6;
     const float* ap = A_MN ? A + (4 * g) * lda + 16 * w + p : A + (16 * w + p) * lda + 4 * g;
     const float* bp = B_MN ? B + (4 * g) * ldb + p : B + p * ldb + 4 * g;
     if constexpr (!DB) {
@@ -224,7 +237,7 @@ __device__ __forceinline__ void hy_zero(f32x4_t (&acc)[8]) {
 // buf[j][i] = sign * M[i][j] for the accumulator matrix M: eight 16-byte stores per lane (registers 0..3 of tile x = rows
 // 16 w + 4 g + {0..3}, column 16 x + p)
 __device__ __forceinline__ void hy_store_t(const f32x4_t (&acc)[8], float* buf, int ld, float sign = 1.f) {
-    const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
+    const int tid = hy_tid(), lane = tid & 63, p = lane & 15, g = lane >> 4, w = tid >> 6;
 #pragma unroll
     for (int x = 0; x < 8; ++x)
         *reinterpret_cast<float4*>(buf + (16 * x + p) * ld + 16 * w + 4 * g) =
@@ -235,16 +248,29 @@ __device__ __forceinline__ void hy_store_t(const f32x4_t (&acc)[8], float* buf, 
 // (element (i, j) of the lane's tile x, registers 0..3, lands at G[16 x + p][16 w + 4 g + {0..3}] = its mirror image): 8 accesses per lane
 __device__ __forceinline__ void hy_sym_store(float* G, const float (&v)[8][4]) {
     const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
-    float* q = G + p * HY_N + 16 * w + 4 * g;
+    unsigned q = (unsigned)(p * HY_N + 16 * w + 4 * g);
+    HY_OPAQUE1(q);
 #pragma unroll
-    for (int x = 0; x < 8; ++x) *reinterpret_cast<float4*>(q + 16 * x * HY_N) = make_float4(v[x][0], v[x][1], v[x][2], v[x][3]);
+    for (int x = 0; x < 8; ++x) *reinterpret_cast<float4*>(G + (q + 16u * x * HY_N)) = make_float4(v[x][0], v[x][1], v[x][2], v[x][3]);
+}
+// ... one tile at a time, from inside a pass (the lane offset q as hy_sym_offset() gives it): what a tile leaves behind goes out
+// at once instead of sitting in 32 registers until the pass is over
+__device__ __forceinline__ unsigned hy_sym_offset() {
+    const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
+    unsigned q = (unsigned)(p * HY_N + 16 * w + 4 * g);
+    HY_OPAQUE1(q);
+    return q;
+}
+__device__ __forceinline__ void hy_sym_store_tile(float* G, unsigned q, int x, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(G + (q + 16u * x * HY_N)) = make_float4(v[0], v[1], v[2], v[3]);
 }
 __device__ __forceinline__ void hy_sym_load(float (&v)[8][4], const float* G) {
     const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4, w = threadIdx.x >> 6;
-    const float* q = G + p * HY_N + 16 * w + 4 * g;
+    unsigned q = (unsigned)(p * HY_N + 16 * w + 4 * g);
+    HY_OPAQUE1(q);
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
-        const float4 t = *reinterpret_cast<const float4*>(q + 16 * x * HY_N);
+        const float4 t = *reinterpret_cast<const float4*>(G + (q + 16u * x * HY_N));
         v[x][0] = t.x; v[x][1] = t.y; v[x][2] = t.z; v[x][3] = t.w;
     }
 }
@@ -255,7 +281,7 @@ __device__ __forceinline__ void hy_sym_load(float (&v)[8][4], const float* G) {
 // tasks).  `part`: K * 32 floats, `out`: K doubles, visible to everybody on return (two barriers).
 template <int K>
 __device__ __forceinline__ void hy_sum(const float (&v)[K], float* part, double* out) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = hy_tid(), lane = tid & 63, w = tid >> 6;
 #pragma unroll
     for (int q = 0; q < K; ++q) {
         float s = v[q];
@@ -279,7 +305,7 @@ __device__ __forceinline__ void hy_sum(const float (&v)[K], float* part, double*
 // TWO: a second image / output with the same x, 1024 floats).  One barrier inside, a second at the end (out visible on return).
 template <bool TWO>
 __device__ __forceinline__ void hy_colsum(const float* M, int ld, const float* M2, int ld2, int rows, const float* x, float* scratch, float* out, float* out2) {
-    const int tid = threadIdx.x, j = tid & 127, part = tid >> 7;
+    const int tid = hy_tid(), j = tid & 127, part = tid >> 7;
     const int per = (rows + 3) >> 2, i0 = part * per, i1 = min(rows, i0 + per);
     float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
     int i = i0;
@@ -378,7 +404,7 @@ __global__ __launch_bounds__(HY_NT, 1) void k_hyper(HyperArgs a) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int r = (tid >> 5) + 16 * u, c4 = (tid & 31) * 4;
-                *reinterpret_cast<float4*>(st_qs + r * HY_N + c4) = *reinterpret_cast<const float4*>(X + r * HY_LDK + c4);
+                *reinterpret_cast<float4*>(st_qs + (unsigned)(r * HY_N + c4)) = *reinterpret_cast<const float4*>(X + r * HY_LDK + c4);
             }
         }
     }
@@ -410,7 +436,7 @@ __global__ __launch_bounds__(HY_NT, 1) void k_hyper(HyperArgs a) {
 #pragma unroll
             for (int y = 0; y < 4; ++y) {
                 const int i = i0 + y, j = j0 + 16 * x;
-                const float u = Dqs[(size_t)min(j, m - 1) * lds + min(i, n - 1)] * il2;
+                const float u = Dqs[(unsigned)(min(j, m - 1) * lds + min(i, n - 1))] * il2;
                 rr[x][y] = (i < n && j < m) ? os * hy_k0(kind, u, hy_ex(kind, u)) - rr[x][y] : 0.f;
             }
             HY_OPAQUE4(rr[x]);
@@ -457,22 +483,24 @@ __global__ __launch_bounds__(HY_NT, 1) void k_hyper(HyperArgs a) {
     ADKF_SST(4);
     float mm[8][4];
     {
-        float dv[8][4], eqq[8][4];
+        float dv[8][4];
         hy_dist<FULL, true>(dv, Dqq, ldq, m, m);
+        const unsigned sq = hy_sym_offset();
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
+            float eqq[4];
 #pragma unroll
             for (int y = 0; y < 4; ++y) {
                 const int i = i0 + y, j = j0 + 16 * x;
                 const float u = dv[x][y] * il2;
-                eqq[x][y] = hy_ex(kind, u);
-                const float sv = os * hy_k0(kind, u, eqq[x][y]) + (i == j ? noise : 0.f) - acc[x][y];
+                eqq[y] = hy_ex(kind, u);
+                const float sv = os * hy_k0(kind, u, eqq[y]) + (i == j ? noise : 0.f) - acc[x][y];
                 mm[x][y] = (in_q(i) && in_q(j)) ? sv : (i == j ? 1.f : 0.f);
             }
+            if (FULL) hy_sym_store_tile(st_qq, sq, x, eqq);    // the exponential factor of K_qq: parked for the W_qq pass behind the sweep
             HY_OPAQUE4(mm[x]);
             HY_FENCE();
         }
-        if (FULL) hy_sym_store(st_qq, eqq);                    // the exponential factor of K_qq: parked for the W_qq pass behind the sweep
     }
     __syncthreads();                                           // vec_in complete; everybody is done with X and Y
     ADKF_SST(5);
@@ -500,56 +528,63 @@ __global__ __launch_bounds__(HY_NT, 1) void k_hyper(HyperArgs a) {
     ADKF_SST(7);
     // W_qq and its reductions from the registers; S^-1 into X (the K_qs image is spent) for the next product
     float r8[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // qq0 qq1 qq2 | oc0 oc1 | ma0 ma1 ma2 | (spare)
-    float e_i[4], e_j[8], al_i[4], al_j[8];
+    // a vector's entries at this lane's rows / columns of the accumulator layout; fetched from LDS where a pass starts, not kept in
+    // registers across the products in between (12 registers per vector: with four of them resident the Matern and the ragged
+    // instances spilled)
+    auto rows_cols = [&](const float* vsrc, float (&vi)[4], float (&vj)[8]) {
 #pragma unroll
-    for (int y = 0; y < 4; ++y) { e_i[y] = ev[i0 + y]; al_i[y] = al[i0 + y]; }
+        for (int y = 0; y < 4; ++y) vi[y] = vsrc[i0 + y];
 #pragma unroll
-    for (int x = 0; x < 8; ++x) { e_j[x] = ev[j0 + 16 * x]; al_j[x] = al[j0 + 16 * x]; }
+        for (int x = 0; x < 8; ++x) vj[x] = vsrc[j0 + 16 * x];
+    };
     {
+        float e_i[4], e_j[8];
+        rows_cols(ev, e_i, e_j);
         f32x4_t si[8];
 #pragma unroll
         for (int x = 0; x < 8; ++x) si[x] = (f32x4_t){mm[x][0], mm[x][1], mm[x][2], mm[x][3]};
         hy_store_t(si, X, HY_LDK, -1.f);                       // S^-1 (identity beyond m)
         float* Wo = a.Wqq + (size_t)t * ldq * ldq;
-        float dv[8][4], eqq[8][4], wq[8][4];
+        float dv[8][4], eqq[8][4];
         hy_dist<FULL, true>(dv, Dqq, ldq, m, m);
         if (FULL) hy_sym_load(eqq, st_qq);
         const float wsc = a.dirscale * os * il2;
+        const unsigned sq = hy_sym_offset();
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
+            float wq[4];
 #pragma unroll
             for (int y = 0; y < 4; ++y) {
                 const int i = i0 + y, j = j0 + 16 * x;
-                wq[x][y] = 0.f;
+                wq[y] = 0.f;
                 if (in_q(i) && in_q(j)) {
                     const float om = 0.5f * (-mm[x][y] - e_i[y] * e_j[x]);
                     float k0, k1, k2; const float u = dv[x][y] * il2; hy_k3(kind, u, FULL ? eqq[x][y] : hy_ex(kind, u), k0, k1, k2);
-                    wq[x][y] = wsc * om * k1;
-                    if (!FULL) Wo[(size_t)i * ldq + j] = wq[x][y];
+                    wq[y] = wsc * om * k1;
+                    if (!FULL) Wo[(unsigned)(i * ldq + j)] = wq[y];
                     if (i == j) r8[0] += om;
                     r8[1] += om * k0;
                     r8[2] += om * os * k1 * u * gl;
                 }
             }
-            HY_OPAQUE3(r8[0], r8[1], r8[2]); HY_OPAQUE4(wq[x]);
+            if (FULL) hy_sym_store_tile(Wo, sq, x, wq);        // (W_qq is symmetric: the transposed 16-byte groups)
+            HY_OPAQUE3(r8[0], r8[1], r8[2]);
             HY_FENCE();
         }
-        if (FULL) hy_sym_store(Wo, wq);                        // (W_qq is symmetric: the transposed 16-byte groups)
     }
     ADKF_SST(8);
     hy_colsum<false>(Y, HY_LDM, nullptr, 0, m, ev, scratch, cte, nullptr);   // C^T e   (barriers inside: X is complete after them)
     if (tid < n) vb[V_CTE * vld + tid] = cte[tid];
-    float cte_i[4], cte_j[8];
-#pragma unroll
-    for (int y = 0; y < 4; ++y) cte_i[y] = cte[i0 + y];
-#pragma unroll
-    for (int x = 0; x < 8; ++x) cte_j[x] = cte[j0 + 16 * x];
     ADKF_SST(9);
     hy_zero(acc);
     hy_gemm<false, true>(acc, X, HY_LDK, Y, HY_LDM, km);       // (S^-1 C)[i][j] = sum_k S^-1[i][k] C[k][j]
     ADKF_SST(10);
     {
         float* Wo = a.Wqs + (size_t)t * ldq * lds;
+        float e_i[4], e_j[8], al_i[4], al_j[8], cte_i[4], cte_j[8];
+        rows_cols(ev, e_i, e_j);
+        rows_cols(al, al_i, al_j);
+        rows_cols(cte, cte_i, cte_j);
         float dv[8][4], kq[8][4];
         hy_dist<FULL, false>(dv, Dqs, lds, m, n);
         if (FULL) hy_dist<true, false>(kq, st_qs, HY_N, HY_N, HY_N);   // kappa_qs as parked by the load pass
@@ -565,7 +600,7 @@ __global__ __launch_bounds__(HY_NT, 1) void k_hyper(HyperArgs a) {
                     const float MB = -2.f * oc - e_i[y] * al_j[x];
                     float k0, k1, k2; const float u = dv[x][y] * il2;
                     hy_k3(kind, u, FULL ? hy_ex_of_k0(kind, u, kq[x][y] / os) : hy_ex(kind, u), k0, k1, k2);
-                    Wo[(size_t)i * lds + j] = wsc * MB * k1;
+                    Wo[(unsigned)(i * lds + j)] = wsc * MB * k1;
                     r8[3] += MB * k0;
                     r8[4] += MB * os * k1 * u * gl;
                 }
@@ -584,23 +619,28 @@ __global__ __launch_bounds__(HY_NT, 1) void k_hyper(HyperArgs a) {
     ADKF_SST(12);
     float* Wss_o = a.Wss + (size_t)t * lds * lds;
     {
-        float dv[8][4], ess[8][4], wss[8][4];
+        float al_i[4], al_j[8], cte_i[4], cte_j[8];
+        rows_cols(al, al_i, al_j);
+        rows_cols(cte, cte_i, cte_j);
+        float dv[8][4];
         hy_dist<FULL, true>(dv, Dss, lds, n, n);
         const float wsc = a.dirscale * os * il2;
+        const unsigned sq = hy_sym_offset();
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
+            float ess[4], wss[4];
 #pragma unroll
             for (int y = 0; y < 4; ++y) {
                 const int i = i0 + y, j = j0 + 16 * x;
-                wss[x][y] = 0.f; ess[x][y] = 0.f;
+                wss[y] = 0.f; ess[y] = 0.f;
                 float gv = 0.f;
                 if (in_s(i) && in_s(j)) {
                     const float MA = acc[x][y] + 0.5f * (cte_i[y] * al_j[x] + al_i[y] * cte_j[x]);
                     const float u = dv[x][y] * il2;
-                    ess[x][y] = hy_ex(kind, u);
-                    float k0, k1, k2; hy_k3(kind, u, ess[x][y], k0, k1, k2);
-                    wss[x][y] = wsc * MA * k1;
-                    if (!FULL) Wss_o[(size_t)i * lds + j] = wss[x][y];
+                    ess[y] = hy_ex(kind, u);
+                    float k0, k1, k2; hy_k3(kind, u, ess[y], k0, k1, k2);
+                    wss[y] = wsc * MA * k1;
+                    if (!FULL) Wss_o[(unsigned)(i * lds + j)] = wss[y];
                     gv = os * k1 * u * gl;                      // G = dK/dl
                     if (i == j) r8[5] += MA;
                     r8[6] += MA * k0;
@@ -608,12 +648,12 @@ __global__ __launch_bounds__(HY_NT, 1) void k_hyper(HyperArgs a) {
                 }
                 acc[x][y] = gv;
             }
+            // the direct part of W_ss goes out now (symmetric: transposed 16-byte groups); the mixed-partial pass updates it in place.
+            // The exponential factor of K_ss is parked for the traces and that pass.
+            if (FULL) { hy_sym_store_tile(Wss_o, sq, x, wss); hy_sym_store_tile(st_ss, sq, x, ess); }
             HY_OPAQUE3(r8[5], r8[6], r8[7]); HY_OPAQUE4(acc[x]);
             HY_FENCE();
         }
-        // the direct part of W_ss goes out now (symmetric: transposed 16-byte groups); the mixed-partial pass updates it in place.
-        // The exponential factor of K_ss is parked for the traces and that pass.
-        if (FULL) { hy_sym_store(Wss_o, wss); hy_sym_store(st_ss, ess); }
     }
     ADKF_SST(13);
     hy_sum<9>(r8, scratch, dsum);                              // (barriers inside: everybody is done with X and Y)
@@ -646,6 +686,8 @@ __global__ __launch_bounds__(HY_NT, 1) void k_hyper(HyperArgs a) {
         ADKF_SST(17);
         float h9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // trA2, trPA, trPP, trAinvKll, aKlla, ag, bg, bd, ab
         {
+            float al_i[4], al_j[8];
+            rows_cols(al, al_i, al_j);
             float dv[8][4], ess[8][4];
             hy_dist<FULL, true>(dv, Dss, lds, n, n);
             if (FULL) hy_sym_load(ess, st_ss);
@@ -721,9 +763,10 @@ __global__ __launch_bounds__(HY_NT, 1) void k_hyper(HyperArgs a) {
         if (a.corrscale != 0.f) {
             // X[k][i] <- B'[i][k] = (cn - cs noise) A^-1[i][k] + cs [i == k] + cl P[i][k]   (X holds P^T; A^-1 is symmetric)
             const float ca = cn - cs * noise;
+            const int tb = hy_tid();
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int r = (tid >> 5) + 16 * u, c4 = (tid & 31) * 4;
+                const int r = (tb >> 5) + 16 * u, c4 = (tb & 31) * 4;
                 float4 xv = *reinterpret_cast<float4*>(X + r * HY_LDK + c4);
                 const float4 yv = *reinterpret_cast<const float4*>(Y + r * HY_LDK + c4);
                 xv.x = cl * xv.x + ca * yv.x + ((r == c4 + 0 && r < n) ? cs : 0.f);
@@ -741,11 +784,10 @@ __global__ __launch_bounds__(HY_NT, 1) void k_hyper(HyperArgs a) {
             hy_dist<FULL, true>(dv, Dss, lds, n, n);
             if (FULL) { hy_sym_load(ess, st_ss); hy_sym_load(wss, Wss_o); }
             const float ifn = 1.f / (float)n;
-            float w_i[4], w_j[8];
-#pragma unroll
-            for (int y = 0; y < 4; ++y) w_i[y] = wv[i0 + y];
-#pragma unroll
-            for (int x = 0; x < 8; ++x) w_j[x] = wv[j0 + 16 * x];
+            const unsigned sq = hy_sym_offset();
+            float w_i[4], w_j[8], al_i[4], al_j[8];
+            rows_cols(wv, w_i, w_j);
+            rows_cols(al, al_i, al_j);
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
 #pragma unroll
@@ -758,13 +800,12 @@ __global__ __launch_bounds__(HY_NT, 1) void k_hyper(HyperArgs a) {
                         const float dBv = cs * os * k1 + cl * os * gl * (k1 + u * k2);
                         const float corr = a.corrscale * (dgdA * os * k1 * il2 + Q * dBv * il2);
                         if (FULL) wss[x][y] -= corr;
-                        else Wss_o[(size_t)i * lds + j] -= corr;
+                        else Wss_o[(unsigned)(i * lds + j)] -= corr;
                     }
                 }
-                HY_OPAQUE4(wss[x]);
+                if (FULL) hy_sym_store_tile(Wss_o, sq, x, wss[x]);
                 HY_FENCE();
             }
-            if (FULL) hy_sym_store(Wss_o, wss);
         }
     } else if (tid == 0) {
         sc[S_V0] = sc[S_V1] = sc[S_V2] = 0.f;
