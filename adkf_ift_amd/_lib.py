@@ -45,6 +45,7 @@ SIGNATURES = {
     "adkf_version": (C.c_char_p, []),
     "adkf_last_hip_error": (C.c_char_p, []),
     "adkf_max_points": (C.c_int, []),
+    "adkf_path_info": (C.c_int, [C.c_int32, C.c_int32]),
     "adkf_workspace_bytes": (C.c_size_t, [C.c_int32] * 4),
     "adkf_median_lengthscale": (C.c_int, [C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "adkf_init_params": (C.c_int, [C.POINTER(Batch), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

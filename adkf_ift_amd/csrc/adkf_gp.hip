@@ -13,6 +13,7 @@
 #include "outer_step.h"
 #include "refine64.h"
 #include "hyper.h"
+#include "large_fused.h"
 #if ADKF_VARIANT_DZ   // A/B experiment only (measured slower than the two ProbDZ launches: see its header)
 #include "../../tools/variants/dz.h"
 #endif
@@ -49,16 +50,18 @@ void launch_gemm(const P& p, int T, int M, int N, hipStream_t st) {
 struct Workspace {
     float *mean, *D2ss, *D2qs, *D2qq, *Ainv, *P, *C, *S, *OC, *Wss, *Wqs, *Wqq, *vecs, *scal, *part_oc, *part_ma, *l0;
     // blocked path only (max(ns, nq) > REG_POINTS)
-    float *lg_Dinv, *lg_C, *lg_F, *lg_logdet, *lg_part, *lg_pext;
-    int32_t *lg_info, *lg_med;  // lg_med: prefix[T], rank[T], hist[T, 256]
+    float *lg_Dinv, *lg_C, *lg_F, *lg_logdet, *lg_part, *lg_pext;   // lg_Dinv: [2, T, LB, LB] (the fused block step alternates between the two)
+    int32_t *lg_info, *lg_med, *lg_cnt;  // lg_med: prefix[T], rank[T], hist[T, 256]; lg_cnt: [T] arrival counters of large_fused.h
     FitShared* lg_fit;
     double* w64; size_t w64_stride;   // float64 region of the ill-conditioned-task path (refine64.h); null beyond R64_MAXN points
     int vld, nt_oc, nt_ma;
+    bool lg_unfused;   // ADKF_BATCH_LG_UNFUSED of the batch this view was carved for
     size_t bytes;
 };
 
 Workspace carve(void* base, int T, int ns, int nq, int d) {
     Workspace w;
+    w.lg_unfused = false;
     size_t off = 0;
     auto take = [&](size_t nfloat) { float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr; off += align_up(nfloat * sizeof(float)); return p; };
     const size_t Tz = (size_t)T;
@@ -82,9 +85,9 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
     w.part_oc = take(Tz * (w.nt_oc > 0 ? w.nt_oc : 1) * 4);
     w.part_ma = take(Tz * w.nt_ma * 4);
     w.l0 = take(Tz);
-    w.lg_Dinv = w.lg_C = w.lg_F = w.lg_logdet = w.lg_part = w.lg_pext = nullptr; w.lg_info = w.lg_med = nullptr; w.lg_fit = nullptr;
+    w.lg_Dinv = w.lg_C = w.lg_F = w.lg_logdet = w.lg_part = w.lg_pext = nullptr; w.lg_info = w.lg_med = w.lg_cnt = nullptr; w.lg_fit = nullptr;
     if (w.vld > REG_POINTS) {
-        w.lg_Dinv = take(Tz * LB * LB);
+        w.lg_Dinv = take(2 * Tz * LB * LB);
         w.lg_C = take(Tz * LB * w.vld);
         w.lg_F = take(Tz * LB * w.vld);
         w.lg_logdet = take(Tz);
@@ -93,6 +96,7 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
         const size_t ts = (size_t)((ns + GT - 1) / GT) * ((ns + GT - 1) / GT);
         w.lg_part = take(Tz * (ts > tq ? ts : tq) * 8);
         w.lg_info = reinterpret_cast<int32_t*>(take(Tz));
+        w.lg_cnt = reinterpret_cast<int32_t*>(take(Tz));
         w.lg_med = reinterpret_cast<int32_t*>(take(Tz * 258));
         w.lg_fit = reinterpret_cast<FitShared*>(take(Tz * ((sizeof(FitShared) + 3) / 4)));
     }
@@ -106,6 +110,12 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
         w.w64 = reinterpret_cast<double*>(take(2 * Tz * w.w64_stride));
     }
     w.bytes = off;
+    return w;
+}
+
+Workspace carve_for(const adkf_batch_t* b, void* ws) {
+    Workspace w = carve_for(b, ws);
+    w.lg_unfused = (b->flags & ADKF_BATCH_LG_UNFUSED) != 0;
     return w;
 }
 
@@ -216,17 +226,40 @@ void launch_inner_k(const InnerArgs& a, hipStream_t st) {
     launch_inner_kl<NMAX, NT, false>(a, st);
 }
 
+// ADKF_LG_FUSED (read once): 0 keeps the three launches per block step (k_lg_diag, panel, update) for A/B runs; default: the update
+// of block step k and the sweep of block step k + 1 share a launch (large_fused.h)
+bool lg_fused() {
+    static const bool on = [] { const char* e = getenv("ADKF_LG_FUSED"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 LgMat lg_mat(const Workspace& w, float* M, int ld, const int32_t* n_arr, const FitShared* fit, int T) {
     LgMat m;
     m.M = M; m.ld = ld; m.n_arr = n_arr; m.fit = fit;
     m.Dinv = w.lg_Dinv; m.Cbuf = w.lg_C; m.Fbuf = w.lg_F; m.logdet = w.lg_logdet; m.pext = w.lg_pext; m.info = w.lg_info;
+    m.cnt = (lg_fused() && !w.lg_unfused) ? w.lg_cnt : nullptr;
     m.T = T; m.vec = (ld & 3) == 0;
     return m;
 }
 
-// M -> -(M^-1) in place by 128-pivot block steps (large.h)
-void lg_sweep(const LgMat& m, hipStream_t st) {
-    const int nb = ceil_div(m.ld, LB), tn = ceil_div(m.ld, GT);
+// M -> -(M^-1) in place by 128-pivot block steps (large.h; large_fused.h)
+void lg_sweep(const LgMat& m0, hipStream_t st) {
+    const int nb = ceil_div(m0.ld, LB), tn = ceil_div(m0.ld, GT);
+    LgMat m = m0;
+    if (m.cnt) {
+        // D(0) | P(0) | U(0) + D(1) | P(1) | U(1) + D(2) | ... | P(nb - 1) | U(nb - 1): 2 nb + 1 launches instead of 3 nb
+        float* dinv[2] = {m0.Dinv, m0.Dinv + (size_t)m0.T * LB * LB};
+        const int npair = ceil_div(tn * (tn + 1) / 2, 2);
+        k_lg_diag<<<grid_for(m.T, 1), 512, 0, st>>>(m, 0);
+        for (int step = 0; step < nb; ++step) {
+            m.Dinv = dinv[step & 1];
+            ProbLgPanel pp; pp.m = m; pp.step = step;
+            k_bgemm<ProbLgPanel><<<grid_for(m.T, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn);
+            LgStepArgs sa{m, dinv[(step + 1) & 1], m.cnt, step, tn, npair, step + 1 < nb ? 1 : 0};
+            k_lg_update_sweep<<<grid_for(m.T, npair), LGF_NT, 0, st>>>(sa);
+        }
+        return;
+    }
     for (int step = 0; step < nb; ++step) {
         k_lg_diag<<<grid_for(m.T, 1), 512, 0, st>>>(m, step);
         ProbLgPanel pp; pp.m = m; pp.step = step;
@@ -799,6 +832,17 @@ const char* adkf_last_hip_error(void) { return hipGetErrorString(g_last_hip_erro
 
 const char* adkf_version(void) { return "adkf_gp 0.1 (gfx950)"; }
 
+int adkf_path_info(int32_t ns_max, int32_t nq_max) {
+    if (ns_max <= 0 || nq_max < 0 || ns_max > MAX_POINTS || nq_max > MAX_POINTS) return ADKF_E_SIZE;
+    int bits = 0;
+    const int hi = ns_max > nq_max ? ns_max : nq_max;
+    if (nq_max > 0 && use_fused_outer(ns_max, nq_max)) bits |= ADKF_PATH_FUSED_OUTER;
+    if (hi > REG_POINTS) { bits |= ADKF_PATH_BLOCKED; if (lg_fused()) bits |= ADKF_PATH_BLOCKED_FUSED; }
+    if (carve(nullptr, 1, ns_max, nq_max > 0 ? nq_max : 1, 4).w64_stride != 0) bits |= ADKF_PATH_R64_REGION;
+    if (refine64_lds_optin()) bits |= ADKF_PATH_R64_LDS;
+    return bits;
+}
+
 int adkf_max_points(void) { return MAX_POINTS; }
 
 size_t adkf_workspace_bytes(int32_t T, int32_t ns_max, int32_t nq_max, int32_t d) {
@@ -830,7 +874,7 @@ int adkf_median_lengthscale(const adkf_batch_t* b, float* l0, void* ws, size_t w
     int rc = check_batch(b, false);
     if (rc) return rc;
     if (!l0 || !ws) return ADKF_E_BADARG;
-    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
+    Workspace w = carve_for(b, ws);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     bool fused;
     return median_core(b, w, l0, InitArgs{0, 0, nullptr, nullptr}, &fused, static_cast<hipStream_t>(stream));
@@ -841,7 +885,7 @@ int adkf_init_params(const adkf_batch_t* b, int32_t use_numeric_labels, int32_t 
     int rc = check_batch(b, false);
     if (rc) return rc;
     if (!phi || !priors || !ws) return ADKF_E_BADARG;
-    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
+    Workspace w = carve_for(b, ws);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     float* l0p = l0 ? l0 : w.l0;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -880,7 +924,7 @@ int adkf_mll_value_grad(const adkf_batch_t* b, const float* phi, float* f_in, fl
         }
         return 0;
     }
-    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
+    Workspace w = carve_for(b, ws);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = stage_dist(b, w, has_query(b), st);
@@ -909,7 +953,7 @@ int adkf_fit(const adkf_batch_t* b, float* phi, const adkf_fit_options_t* opt, f
     if (rc) return rc;
     if (!phi || !opt || !info || !ws || !b->y_s || !b->priors || opt->max_evals < 2) return ADKF_E_BADARG;
     if (is_ard(b)) return ard_fit(b, phi, opt, f_final, gnorm, n_evals, info, ws, ws_bytes, static_cast<hipStream_t>(stream));
-    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
+    Workspace w = carve_for(b, ws);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = stage_dist(b, w, has_query(b), st);
@@ -942,7 +986,7 @@ int adkf_predict(const adkf_batch_t* b, const float* phi, float* mean, float* va
         adkf_batch_t bq = c.bt;
         return predict_core(&bq, c.w, mean, var, cov, info, c.st);
     }
-    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
+    Workspace w = carve_for(b, ws);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = stage_dist(b, w, true, st);
@@ -964,7 +1008,7 @@ int adkf_outer_nll_value_grad(const adkf_batch_t* b, const float* phi, float* f_
     if (!phi || !f_out || !info || !ws || !b->y_s || !b->y_q || !b->priors) return ADKF_E_BADARG;
     if (is_ard(b))
         return ard_ift(b, phi, 0, false, 0, 0.f, f_out, dZ_s, dZ_q, g_phi, nullptr, nullptr, info, ws, ws_bytes, static_cast<hipStream_t>(stream));
-    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
+    Workspace w = carve_for(b, ws);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     return outer_pipeline(b, w, phi, 0, false, f_out, dZ_s, dZ_q, g_phi, nullptr, nullptr, info, static_cast<hipStream_t>(stream));
 }
@@ -979,7 +1023,7 @@ int adkf_ift_hypergrad(const adkf_batch_t* b, const float* phi, int32_t flags, f
         return ard_ift(b, phi, flags, true, ADKF_CG_DEFAULT_MAXITER, ADKF_CG_DEFAULT_TOL, f_out, dZ_s, dZ_q, g_phi_out, v, nullptr, info,
                        ws, ws_bytes, static_cast<hipStream_t>(stream));
     }
-    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
+    Workspace w = carve_for(b, ws);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     return outer_pipeline(b, w, phi, flags, true, f_out, dZ_s, dZ_q, g_phi_out, v, H, info, static_cast<hipStream_t>(stream));
 }
@@ -988,7 +1032,7 @@ int adkf_double_path_tasks(const adkf_batch_t* b, int32_t* flagged, void* ws, si
     int rc = check_batch(b, true);
     if (rc) return rc;
     if (!flagged || !ws || is_ard(b)) return ADKF_E_BADARG;
-    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
+    Workspace w = carve_for(b, ws);
     if (ws_bytes < w.bytes) return ADKF_E_WORKSPACE;
     (void)hipGetLastError();
     k_double_path_tasks<<<ceil_div(b->T, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(w.scal, b->ns_max, b->nq_max, w.w64 ? r64_threshold() : INFINITY, b->T, flagged);

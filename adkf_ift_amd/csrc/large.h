@@ -38,6 +38,7 @@ struct LgMat {
     float* logdet;          // [T] running log-determinant
     float* pext;            // [T, 2] smallest / largest pivot so far: the condition estimate that picks the float64 path (refine64.h)
     int32_t* info;          // [T] first non-positive pivot (1-based) or 0
+    int32_t* cnt;           // [T] arrival counters of the fused block step (large_fused.h); null on the three-launch path
     int T; bool vec;
     __device__ __forceinline__ bool active(int t) const { return !fit || fit[t].phase != PH_DONE; }
     __device__ __forceinline__ int n(int t) const { return n_arr ? n_arr[t] : ld; }
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(512) void k_lg_diag(LgMat a, int step) {
     if ((threadIdx.x & 63) == 0) { sm.red[2 * (threadIdx.x >> 6)] = plo; sm.red[2 * (threadIdx.x >> 6) + 1] = phi; }
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (a.cnt && step == 0) a.cnt[t] = 0;   // (a sweep starts here: the counters of large_fused.h are zero from now on)
         a.logdet[t] = (step == 0 ? 0.f : a.logdet[t]) + logdet;
         const int prev = step == 0 ? 0 : a.info[t];
         a.info[t] = prev != 0 ? prev : (info != 0 ? p0 + info : 0);

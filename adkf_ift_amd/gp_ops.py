@@ -19,6 +19,7 @@ from ._lib import KERNEL_MATERN52, KERNEL_RBF, Batch, FitOptions
 KERNELS = {"rbf": KERNEL_RBF, "RBF": KERNEL_RBF, "matern": KERNEL_MATERN52}
 REUSE_DIST = 1
 REUSE_INNER = 2
+LG_UNFUSED = 16     # blocked path: three launches per block step (A/B; include/adkf_gp.h)
 DEFER_REFINE = 8   # adkf_fit: leave the float64 re-evaluation of ill-conditioned tasks to the next call (include/adkf_gp.h)
 ARD = 4
 

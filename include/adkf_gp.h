@@ -61,6 +61,10 @@ extern "C" {
                                     this workspace, which redo those tasks in float64 themselves; f_final / gnorm of such tasks are
                                     then the float32 values */
 
+#define ADKF_BATCH_LG_UNFUSED 16 /* more than 128 points only, A/B runs and tests: the blocked sweep as three launches per block step
+                                    (k_lg_diag, panel, update: csrc/large.h) instead of the update of step k and the diagonal sweep of
+                                    step k + 1 in one launch (csrc/large_fused.h).  Both give bit-identical results. */
+
 /* ARD kernel (``use_ard``: fs_mol/models/adaptive_dkt.py:107-108 -> gpytorch ``ard_num_dims``): one lengthscale per
  * feature dimension.  With this flag EVERY phi / g_phi / v argument has h = 2 + d entries per task, laid out
  * (raw_noise, raw_outputscale, raw_lengthscale[0..d)); priors stay [T,4] (the lengthscale prior applies to each
@@ -106,6 +110,18 @@ const char* adkf_version(void);
 
 /* Diagnostics: the HIP runtime's description of the error behind the calling thread's last ADKF_E_LAUNCH. */
 const char* adkf_last_hip_error(void);
+
+/* Diagnostics: which kernels a batch padded to (ns_max, nq_max) takes ON THIS DEVICE (needs a GPU: it asks the runtime for the
+ * dynamic-LDS opt-ins exactly as the entry points do), as a mask of ADKF_PATH_* bits, or ADKF_E_SIZE.  The library never computes
+ * anything else than what the header promises, but two of its fast paths depend on an opt-in the runtime may refuse, and then the
+ * slower pipeline runs silently: this is where a caller (bench.py prints it) sees which one is live. */
+#define ADKF_PATH_FUSED_OUTER 1    /* 64 < max(ns, nq) <= 128: the outer / hypergradient stage of a task as ONE kernel (csrc/hyper.h, 159 KB of
+                                      dynamic LDS); clear: the sixteen-launch pipeline */
+#define ADKF_PATH_BLOCKED 2        /* max(ns, nq) > 128: blocked sweep through L2 / HBM (csrc/large.h) */
+#define ADKF_PATH_BLOCKED_FUSED 4  /* ... with update k + sweep k + 1 in one launch (csrc/large_fused.h); clear: ADKF_LG_FUSED=0 */
+#define ADKF_PATH_R64_REGION 8     /* the workspace of this shape carries the float64 region of the ill-conditioned-task path (csrc/refine64.h) */
+#define ADKF_PATH_R64_LDS 16       /* that path's inverses run in 128 KB of dynamic LDS; clear: in global memory */
+int adkf_path_info(int32_t ns_max, int32_t nq_max);
 
 /* Largest support/query set this build handles in its LDS-resident factorisation. */
 int adkf_max_points(void);

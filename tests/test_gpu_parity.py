@@ -222,6 +222,43 @@ def test_blocked_path_against_live_oracle(dev, N, Nq, d, kernel):
         assert gn[t].item() <= 5e-4
 
 
+@pytest.mark.parametrize("N,Nq,d,kernel", [(516, 132, 40, "matern"), (384, 300, 64, "rbf"), (1024, 1024, 64, "rbf"), (250, 130, 24, "rbf")])
+def test_fused_block_step_equals_three_launches(dev, N, Nq, d, kernel):
+    """csrc/large_fused.h (the update of block step k and the diagonal sweep of block step k + 1 in one launch, the next diagonal
+    block handed from the tile workgroups to the sweeping one through write-through stores, an agent-scope arrival counter and one
+    acquire) against the three launches per block step of csrc/large.h (batch flag ADKF_BATCH_LG_UNFUSED): the same arithmetic in
+    the same order, so EVERY output of the fit and of the hypergradient stage must be equal bit for bit - a stale read of the
+    handed-over block would show up as a difference.  Ragged sizes, block counts from 2 to 8, sizes that are not a multiple of the
+    64-point tiles; run three times (a visibility bug comes and goes)."""
+    from adkf_ift_amd import gp_ops
+    from adkf_ift_amd.synthetic import make_tasks
+
+    T = 5
+    tasks = make_tasks(T, N, d, N_q=Nq, first_task=140)
+    Zs, Zq = tasks.features()
+    n_s = torch.tensor([N, N - 7, max(N - 64, 5), max(N - 129, 3), N - 1])
+    n_q = torch.tensor([Nq, Nq - 1, max(Nq - 100, 2), Nq, max(Nq - 65, 1)])
+
+    def run(flag):
+        pri = torch.empty(T, 4, device=dev)
+        b = gp_ops.GPBatch(Zs.to(dev), tasks.y_s.to(dev), pri, kernel, Z_q=Zq.to(dev), y_q=tasks.y_q.to(dev), n_s=n_s, n_q=n_q)
+        b.flags = flag
+        phi0, _ = gp_ops.init_params_batch(b)
+        b.flags = gp_ops.REUSE_DIST | flag
+        phi, f, gn, ne, info = gp_ops.fit(b, phi0, max_evals=12, exact_evals=True)
+        gp_ops.check_info(info)
+        b.flags = gp_ops.REUSE_DIST | gp_ops.REUSE_INNER | flag
+        out = gp_ops.ift_hypergrad(b, phi)
+        gp_ops.check_info(out["info"])
+        return [phi, f, gn, out["f_out"], out["H"], out["v"], out["dZ_s"], out["dZ_q"]]
+
+    want = run(gp_ops.LG_UNFUSED)
+    for rep in range(3):
+        got = run(0)
+        for k, (a, b_) in enumerate(zip(got, want)):
+            assert torch.equal(a, b_), (rep, k, (a - b_).abs().max().item())
+
+
 def test_c5_large_support_regime(dev):
     """BASELINE.json config C5: N_support = 1024, d = 512 (one task against the live float64 oracle)."""
     from adkf_ift_amd import gp_ops
