@@ -114,7 +114,7 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
 }
 
 Workspace carve_for(const adkf_batch_t* b, void* ws) {
-    Workspace w = carve_for(b, ws);
+    Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
     w.lg_unfused = (b->flags & ADKF_BATCH_LG_UNFUSED) != 0;
     return w;
 }

@@ -32,6 +32,9 @@ struct LgStepArgs {
 };
 
 constexpr int LGF_NT = 512;
+#ifndef ADKF_LGF_WPS
+#define ADKF_LGF_WPS 4   // waves per SIMD the register budget allows: 4 = two workgroups per CU (tools/lgf_bench.hip measures 2 = one per CU as well)
+#endif
 constexpr int LGF_LDK = GT + 16;   // [k][mn] operand images of gemm.h (both operands of the update are MN-contiguous)
 
 // relaxed agent-scope stores: global_store_dword ... sc1 (write-through; MI355X_MICROARCH.md, fence table)
@@ -47,7 +50,7 @@ __device__ __forceinline__ void lgf_tri_tile(int tn, int v, int& ti, int& tj) {
     ti = r; tj = r + (v - (r * tn - r * (r - 1) / 2));
 }
 
-__global__ __launch_bounds__(LGF_NT, 4) void k_lg_update_sweep(LgStepArgs a) {
+__global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStepArgs a) {
     using SW = Sweep<128, 512>;
     constexpr int RB = SW::RB, CB = SW::CB;
     __shared__ SweepSmem<128, 512> sm;

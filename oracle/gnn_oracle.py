@@ -60,7 +60,7 @@ def scatter_softmax(src, index, n):
     return out
 
 
-def multi_aggr_mp(x, adj_lists, p, name: str, cfg, std_mask=None, argmax=None, relu_mask=None) -> torch.Tensor:
+def multi_aggr_mp(x, adj_lists, p, name: str, cfg, std_mask=None, argmax=None, relu_mask=None, msg_hook=None) -> torch.Tensor:
     """One tower: RelationalMultiAggrMP with PNA scalers (cfg.type == 'PNA').
     ``std_mask`` [E, m] bool (tests only): the indicator [b_e^2 > mean^2] of the std aggregation is TAKEN from the caller instead of
     being evaluated here.  The reference's relu(b^2 - mean^2) has a kink with slope up to 1 / (2 sqrt(1e-7)) = 1581 behind it, so
@@ -78,6 +78,8 @@ def multi_aggr_mp(x, adj_lists, p, name: str, cfg, std_mask=None, argmax=None, r
         e0 += m.shape[0]
         tgts_all.append(tgts)
     messages, targets = torch.cat(msgs), torch.cat(tgts_all)
+    if msg_hook is not None:   # tests only: the post-ReLU messages [E_all, 3 m] of this tower pass through the caller (e.g. a float32 rounding)
+        messages = msg_hook(name, messages, targets)
     V, m = x.shape[0], cfg.per_head_dim
     if cfg.type.lower() == "plain":
         return scatter_sum(messages, targets, V)
@@ -101,12 +103,12 @@ def multi_aggr_mp(x, adj_lists, p, name: str, cfg, std_mask=None, argmax=None, r
     return out
 
 
-def gnn_block(x, adj_lists, p, name: str, cfg, std_mask=None, argmax=None, relu_mask=None) -> torch.Tensor:
+def gnn_block(x, adj_lists, p, name: str, cfg, std_mask=None, argmax=None, relu_mask=None, msg_hook=None) -> torch.Tensor:
     """``std_mask`` [E, heads, m], ``argmax`` [V, heads, m], ``relu_mask`` [E, heads, 3 m] (see multi_aggr_mp)."""
     in_dim = cfg.hidden_dim // cfg.num_heads
     agg = [multi_aggr_mp(x[:, h * in_dim:(h + 1) * in_dim], adj_lists, p, f"{name}.mp_layers.{h}", cfg,
                          None if std_mask is None else std_mask[:, h], None if argmax is None else argmax[:, h],
-                         None if relu_mask is None else relu_mask[:, h]) for h in range(cfg.num_heads)]
+                         None if relu_mask is None else relu_mask[:, h], msg_hook) for h in range(cfg.num_heads)]
     new = _linear(torch.cat(agg, dim=-1), p, f"{name}.msg_out_projection")
     if cfg.use_rezero_scaling:
         new = p[f"{name}.alpha"] * new
@@ -129,9 +131,10 @@ def weighted_readout(x, n2g, G, p, name: str, rcfg, kind: str):
 
 
 def graph_feature_extractor(batch, p: Dict[str, torch.Tensor], cfg, prefix: str = "graph_feature_extractor.", std_masks=None,
-                            argmaxes=None, relu_masks=None) -> torch.Tensor:
+                            argmaxes=None, relu_masks=None, msg_hook=None) -> torch.Tensor:
     """``std_masks`` / ``argmaxes``: one [E_all, heads, m] bool / [V, heads, m] int tensor per block (see multi_aggr_mp), or None for
-    the reference's own indicators / winners."""
+    the reference's own indicators / winners.  ``msg_hook(name, messages, targets) -> messages`` (tests only): every tower's post-ReLU
+    messages pass through it (``name`` = "gnn.gnn_blocks.<b>.mp_layers.<h>")."""
     p = {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
     g, r = cfg.gnn_config, cfg.readout_config
     x = _linear(batch.node_features, p, "init_node_proj", bias=False)
@@ -141,7 +144,7 @@ def graph_feature_extractor(batch, p: Dict[str, torch.Tensor], cfg, prefix: str 
     states = [x]
     for b in range(g.num_layers):
         x = gnn_block(x, adj, p, f"gnn.gnn_blocks.{b}", g, None if std_masks is None else std_masks[b],
-                      None if argmaxes is None else argmaxes[b], None if relu_masks is None else relu_masks[b])
+                      None if argmaxes is None else argmaxes[b], None if relu_masks is None else relu_masks[b], msg_hook)
         states.append(x)
     node_repr = torch.cat(states, dim=-1) if r.use_all_states else states[-1]
     G = batch.num_graphs

@@ -122,3 +122,35 @@ def test_ctypes_structs_mirror_the_header():
             fields.append((name, kind))
         got = [(n, "ptr" if t is C.c_void_p else {C.c_int32: "i32", C.c_float: "f32"}[t]) for n, t in mirror._fields_]
         assert fields == got, (cname, fields, got)
+
+
+@pytest.mark.parametrize("ns,nq", [(32, 32), (128, 128), (200, 256)])
+def test_entry_points_fail_cleanly_without_a_device(lib, ns, nq):
+    """Host side of the entry points on a box WITHOUT a GPU: argument checks, workspace carving and the launch sequence run, every
+    launch is refused by the runtime and the call returns ADKF_E_LAUNCH - it must not crash (round 5: a host-side recursion in the
+    workspace helper took the whole process down on the first call, and no CPU test went through an entry point).  Host memory stands
+    in for device memory: nothing is ever dereferenced on the host."""
+    import ctypes as C
+
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this is the no-device check")
+    from adkf_ift_amd import _lib
+
+    T, d = 3, 8
+    nb = lib.adkf_workspace_bytes(T, ns, nq, d)
+    ws = torch.zeros(nb // 4 + 64)
+    Zs, Zq, ys, yq = torch.zeros(T, ns, d), torch.zeros(T, nq, d), torch.zeros(T, ns), torch.zeros(T, nq)
+    pri, phi, l0, f, g, info = torch.zeros(T, 4), torch.zeros(T, 3), torch.zeros(T), torch.zeros(T), torch.zeros(T, 3), torch.zeros(T, dtype=torch.int32)
+    b = _lib.Batch()
+    b.T, b.ns_max, b.nq_max, b.d, b.kernel, b.flags = T, ns, nq, d, 0, 0
+    b.n_s = b.n_q = None
+    b.Z_s, b.y_s, b.Z_q, b.y_q, b.priors = Zs.data_ptr(), ys.data_ptr(), Zq.data_ptr(), yq.data_ptr(), pri.data_ptr()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for flags in (0, 16):   # ADKF_BATCH_LG_UNFUSED
+        b.flags = flags
+        assert lib.adkf_init_params(C.byref(b), 0, 1, p(phi), p(pri), p(l0), p(ws), nb, None) == -4
+        assert lib.adkf_mll_value_grad(C.byref(b), p(phi), p(f), p(g), None, p(info), p(ws), nb, None) == -4
+        opt = _lib.FitOptions(5, 1, 1e-5, 2.22e-9, None, None)
+        assert lib.adkf_fit(C.byref(b), p(phi), C.byref(opt), p(f), p(l0), None, p(info), p(ws), nb, None) == -4
+    assert b"device" in lib.adkf_last_hip_error() or lib.adkf_last_hip_error()

@@ -28,6 +28,7 @@ static void sweep3(LgMat m, hipStream_t st) {
     }
 }
 
+static int g_dyn = 0;   // extra dynamic LDS per workgroup of the fused kernel: 40000 leaves ONE workgroup per CU (the sweeping workgroup then has its CU to itself)
 static void sweepf(LgMat m, float* dinv2, hipStream_t st) {
     const int nb = ceil_div(m.ld, LB), tn = ceil_div(m.ld, GT), npair = ceil_div(tn * (tn + 1) / 2, 2);
     float* buf[2] = {m.Dinv, dinv2};
@@ -37,13 +38,15 @@ static void sweepf(LgMat m, float* dinv2, hipStream_t st) {
         ProbLgPanel pp; pp.m = m; pp.step = step;
         k_bgemm<ProbLgPanel><<<grid_for(m.T, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn);
         LgStepArgs sa{m, buf[(step + 1) & 1], m.cnt, step, tn, npair, step + 1 < nb ? 1 : 0};
-        k_lg_update_sweep<<<grid_for(m.T, npair), LGF_NT, 0, st>>>(sa);
+        k_lg_update_sweep<<<grid_for(m.T, npair), LGF_NT, g_dyn, st>>>(sa);
     }
 }
 
 int main(int argc, char** argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 8, n = argc > 2 ? atoi(argv[2]) : 1024, ld = argc > 3 ? atoi(argv[3]) : n;
     const bool ragged = ld != n;
+    g_dyn = argc > 4 ? atoi(argv[4]) : 0;
+    if (g_dyn > 0 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lg_update_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, g_dyn) != hipSuccess) { printf("no LDS opt-in\n"); return 2; }
     std::vector<float> h((size_t)T * ld * ld, 0.f);
     std::vector<int32_t> narr(T);
     unsigned s = 12345u;
@@ -107,5 +110,26 @@ int main(int argc, char** argv) {
             if (rep) printf("T=%d n=%d ld=%d %s  %.1f us per sweep (%d block steps: %.1f us each)\n", T, n, ld, which == 0 ? "three launches" : "fused         ", ms * 1000 / reps,
                             ceil_div(ld, LB), ms * 1000 / reps / ceil_div(ld, LB));
         }
+    // the launches of one block step on their own (step 3 of 8: the state of M does not matter for the time)
+    {
+        const int tn = ceil_div(ld, GT), npair = ceil_div(tn * (tn + 1) / 2, 2), step = ceil_div(ld, LB) > 3 ? 3 : 0;
+        ProbLgPanel pp; pp.m = m; pp.step = step;
+        ProbLgUpdate pu; pu.m = m; pu.step = step; pu.tri = tn * (tn + 1) / 2;
+        const char* nm[5] = {"k_lg_diag", "panel", "update (three-launch path)", "update + sweep (fused)", "update alone in the fused kernel (look = 0)"};
+        for (int which = 0; which < 5; ++which)
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEventRecord(e0);
+                for (int i = 0; i < 50; ++i) {
+                    if (which == 0) k_lg_diag<<<grid_for(T, 1), 512>>>(m, step);
+                    if (which == 1) k_bgemm<ProbLgPanel><<<grid_for(T, 2 * tn), 256>>>(pp, T, 2, tn);
+                    if (which == 2) k_bgemm<ProbLgUpdate><<<grid_for(T, pu.tri), 256>>>(pu, T, tn, tn);
+                    if (which >= 3) { LgStepArgs sa{m, dinv2, m.cnt, step, tn, npair, which == 3 ? 1 : 0}; k_lg_update_sweep<<<grid_for(T, npair), LGF_NT, g_dyn>>>(sa); }
+                }
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (rep) printf("   %-46s %.2f us per launch\n", nm[which], ms * 1000 / 50);
+            }
+    }
     return bad_total ? 1 : 0;
 }
