@@ -255,7 +255,7 @@ void lg_sweep(const LgMat& m0, hipStream_t st) {
             m.Dinv = dinv[step & 1];
             ProbLgPanel pp; pp.m = m; pp.step = step;
             k_bgemm<ProbLgPanel><<<grid_for(m.T, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn);
-            LgStepArgs sa{m, dinv[(step + 1) & 1], m.cnt, step, tn, npair, step + 1 < nb ? 1 : 0};
+            LgStepArgs sa{m, dinv[(step + 1) & 1], m.cnt, step, tn, npair, step + 1 < nb ? 1 : 0, LGF_STAGGER, LGF_PRIO};
             k_lg_update_sweep<<<grid_for(m.T, npair), LGF_NT, 0, st>>>(sa);
         }
         return;

@@ -29,12 +29,18 @@ struct LgStepArgs {
     float* Dinv_next;   // [T, LB, LB] where the sweep of block step + 1 leaves its inverse (the other parity)
     int32_t* cnt;       // [T] arrivals at the next diagonal block; zero between launches (the sweeping workgroup resets it)
     int step, tn, npair, look;   // tn = ceil(ld / 64) tiles per edge, npair = workgroups per task, look = 1: sweep block step + 1 in this launch
+    int stagger;        // look = 1: the workgroups WITHOUT a tile of the next diagonal block start this many s_sleep(127) (~3.4 us each) late
+    int prio;           // look = 1: wave priority of the sweeping workgroup (s_setprio)
 };
 
 constexpr int LGF_NT = 512;
+#ifndef ADKF_LGF_EXP
+#define ADKF_LGF_EXP 0   // timing experiments of tools/lgf_bench.hip ONLY (results are wrong or unordered): 1 plain stores for the handed-over tiles, 2 no acquire, 4 workgroup 0 sweeps at once (no tiles, no hand-off)
+#endif
 #ifndef ADKF_LGF_WPS
 #define ADKF_LGF_WPS 4   // waves per SIMD the register budget allows: 4 = two workgroups per CU (tools/lgf_bench.hip measures 2 = one per CU as well)
 #endif
+constexpr int LGF_STAGGER = 0, LGF_PRIO = 0;   // what the library launches with: neither a late start of the other workgroups nor a raised priority of the sweeping one changed the launch time (tools/lgf_bench.hip, profiles/r05_lgf_bench.txt)
 constexpr int LGF_LDK = GT + 16;   // [k][mn] operand images of gemm.h (both operands of the update are MN-contiguous)
 
 // relaxed agent-scope stores: global_store_dword ... sc1 (write-through; MI355X_MICROARCH.md, fence table)
@@ -91,6 +97,15 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
     }
     const int m0 = ti * GT, n0 = tj * GT;
     if (m0 >= n || n0 >= n) valid = false;       // tile outside this (ragged) task
+#if (ADKF_LGF_EXP & 4)
+    const bool direct = nd > 0 && pair == 0;
+    if (nd > 0 && u < nd) valid = false;
+#endif
+    // The tiles of the next diagonal block are the head of the launch's critical path (tiles -> sweep: 20 us of hand-off chain), the
+    // other tiles have slack.  Started together, the three tiles take as long as a tile of a full launch takes (15 us: every CU of the
+    // XCD is loading operands); started alone they take 5.  So everybody else sleeps first.
+    if (nd > 0 && 2 * pair >= nd)
+        for (int q = 0; q < a.stagger; ++q) __builtin_amdgcn_s_sleep(127);
     auto in_p = [&](int i) { return i >= p0 && i < p0 + LB; };
     const bool piv_i = in_p(m0), piv_j = in_p(n0);
     const bool compute = valid && !piv_i && !piv_j;
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
 
     // ---- epilogue: the expressions of ProbLgUpdate (epi / epi4 / epi4p), tile by tile ----
     if (valid) {
-        auto put = [&](float* dst, float v) { if (next_diag) st_sc1(dst, v); else *dst = v; };
+        auto put = [&](float* dst, float v) { if (next_diag && !(ADKF_LGF_EXP & 1)) st_sc1(dst, v); else *dst = v; };
         auto epi = [&](int i, int j, float ac) {
             float* dst = Mi + (size_t)i * ld + j;
             const bool pi = in_p(i), pj = in_p(j);
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
                     for (int r = 0; r < 4; ++r) { v[r] = pre[i][j][r] - acc[i][j][r]; put(Mi + (size_t)(gi0 + r) * ld + gj, v[r]); }
                     if (ti < tj) {
                         float* mp = Mi + (size_t)gj * ld + gi0;
-                        if (next_diag) { st_sc1(mp, v[0]); st_sc1(mp + 1, v[1]); st_sc1(mp + 2, v[2]); st_sc1(mp + 3, v[3]); }
+                        if (next_diag && !(ADKF_LGF_EXP & 1)) { st_sc1(mp, v[0]); st_sc1(mp + 1, v[1]); st_sc1(mp + 2, v[2]); st_sc1(mp + 3, v[3]); }
                         else *reinterpret_cast<float4*>(mp) = make_float4(v[0], v[1], v[2], v[3]);
                     }
                 } else if (gi0 + 3 < n && gj < n && a.m.vec && ti != tj && !next_diag) {
@@ -245,18 +260,23 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
     if (nd == 0) return;
     const int mine = (2 * pair < nd ? 1 : 0) + (2 * pair + 1 < nd ? 1 : 0);   // tiles of the next diagonal block in this workgroup (uniform)
     if (mine == 0) return;
+#if (ADKF_LGF_EXP & 4)
+    if (!direct) return;
+    s_last = 1;
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its write-through stores have left
     __syncthreads();
     if (tid == 0) {
         const int before = __hip_atomic_fetch_add(a.cnt + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (before + mine == nd) ? 1 : 0;
         if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv sc1: this CU's L1 drops what it holds of the block
+            if (!(ADKF_LGF_EXP & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv sc1: this CU's L1 drops what it holds of the block
             __hip_atomic_store(a.cnt + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }
         s_last = last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate has completed before anybody passes the barrier
     }
+#endif
     __syncthreads();
     if (!s_last) return;
 
@@ -274,7 +294,9 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
             if (i == SW::col(c) && i >= nnext) m[r][c] = 1.f;
     }
     __syncthreads();
+    if (a.prio > 0) __builtin_amdgcn_s_setprio(3);   // the chain's instructions go first on SIMDs it shares with an updating workgroup
     SW::run(m, nnext, sm);
+    if (a.prio > 0) __builtin_amdgcn_s_setprio(0);
     float logdet;
     const int info = SW::finish(nnext, sm, logdet);
     float* Dn = a.Dinv_next + (size_t)t * LB * LB;

@@ -179,3 +179,77 @@ def test_readout_projection_of_pooled_hidden_states_is_the_same_algebra():
         assert torch.allclose(got, want, rtol=1e-12, atol=1e-13)
         if softmax:   # the weights of a graph sum to one (zero for the empty graph): the kernel returns exactly that
             assert torch.allclose(wtot, torch.tensor([[1.0] * nh if n > 0 else [0.0] * nh for n in sizes], dtype=torch.float64), atol=1e-12)
+
+
+def c3_test_graphs():
+    """The molecules of tests/test_gpu_gnn.py::test_c3_default_model_meta_step_vs_per_task_oracle_loop as ONE disconnected graph
+    (2 tasks x (16 support + 32 query), graph seeds 20 ... 23)."""
+    parts = [random_graphs(n, seed=s) for n, s in ((16, 20), (32, 21), (16, 22), (32, 23))]
+    feats, adj, n2g, v0, g0 = [], [[], [], []], [], 0, 0
+    for gb in parts:
+        feats.append(gb.node_features.float().double())   # (the GPU test's molecules carry float32 node features)
+        for t in range(3):
+            adj[t].append(gb.adjacency_lists[t] + v0)
+        n2g.append(gb.node_to_graph + g0)
+        v0 += gb.node_features.shape[0]
+        g0 += gb.num_graphs
+    return GraphBatch(torch.cat(feats), [torch.cat(a) for a in adj], torch.cat(n2g), g0)
+
+
+@pytest.mark.parametrize("which,floor_lo,floor_hi", [("extractor", 1.5e-4, 4.5e-4), ("c3", 3e-4, 8e-4)])
+def test_float32_node_states_set_the_gradient_error_floor(which, floor_lo, floor_hi):
+    """WHERE the 3e-4 ... 1e-3 (of the largest entry) between ANY float32 evaluation of the default-width extractor's parameter
+    gradients and the float64 restatement comes from, on the exact inputs of the two default-width GPU tests (tests/test_gpu_gnn.py).
+    Everything below runs in float64; ONE kind of intermediate at a time is rounded to float32 (straight-through, so the gradient
+    still flows):
+
+      * the post-ReLU messages of every tower and block (what a float32 message GEMM rounds):          2e-5
+      * the aggregates sum | mean | std | max of every block:                                          5e-6
+      * the NODE STATES between blocks (what any implementation that stores them in float32 rounds):   2.8e-4 / 5.3e-4
+      * float32 PyTorch on the CPU, everything in float32 (the reference's arithmetic):                1.0e-3 / 1.1e-3
+
+    So the error is not a property of a kernel: 6e-8 relative on the stored node states is amplified 5 000 x on these two draws
+    (the reference's std aggregation sqrt(sum relu(b^2 - mean^2) + 1e-7), fs_mol/modules/gnn.py:231-240, at a node whose incoming
+    messages are nearly equal; other seeds give floors of 5e-6 ... 7e-5), and no float32-state implementation can be closer to
+    float64 than that floor.  Round 4 blamed the rounding of the MESSAGES (it is 10 x too small) and before that the indicator flips
+    (< 1 %).  The GPU tests hold the device to FIXED bounds of about twice this floor: 6e-4 and 1.5e-3."""
+    cfg = GraphFeatureExtractorConfig()
+    if which == "extractor":
+        batch, sd0, wseed = random_graphs(40, seed=11), unit_gain_reference_state_dict(cfg, seed=2), 1
+    else:
+        batch, sd0, wseed = c3_test_graphs(), unit_gain_reference_state_dict(cfg, seed=5), 1
+    w = torch.randn(batch.num_graphs, 512, dtype=torch.float64, generator=torch.Generator().manual_seed(wseed))
+    through = lambda o: o + (o.float().double() - o).detach()
+
+    def run(dtype, hooks=None):
+        net = GraphFeatureExtractor(cfg)
+        net.load_reference_state_dict({k: v.detach().float() for k, v in sd0.items()})
+        net = net.to(dtype)
+        b = batch.to("cpu")
+        b.node_features = b.node_features.to(dtype)
+        hs = hooks(net) if hooks else []
+        (net(b) * w.to(dtype)).sum().backward()
+        for h in hs:
+            h.remove()
+        return {k: v.double() for k, v in grads_under_reference_names(net).items()}
+
+    g64 = run(torch.float64)
+    scale = max(g.abs().max().item() for g in g64.values())
+    err = lambda g: max((g[k] - g64[k]).abs().max().item() / scale for k in g64)
+    e32 = err(run(torch.float32))
+    e_states = err(run(torch.float64, lambda net: [blk.register_forward_hook(lambda m, i, o: through(o)) for blk in net.gnn.gnn_blocks]))
+    e_aggr = err(run(torch.float64, lambda net: [blk.mp.register_forward_hook(lambda m, i, o: through(o)) for blk in net.gnn.gnn_blocks]))
+    print("%s inputs: float32 everywhere %.2e | float64 with float32 node states %.2e | ... with float32 aggregates %.2e" % (which, e32, e_states, e_aggr))
+    assert floor_lo <= e_states <= floor_hi, e_states
+    assert e_aggr <= 0.1 * e_states, (e_aggr, e_states)
+    assert e32 >= e_states, (e32, e_states)
+    if which == "extractor":   # the messages, through the naive restatement's hook (the module computes them inside one function)
+        sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+        (GO.graph_feature_extractor(batch, sd, cfg) * w).sum().backward()
+        ref = {k: v.grad for k, v in sd.items() if v.grad is not None}
+        sd2 = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+        (GO.graph_feature_extractor(batch, sd2, cfg, msg_hook=lambda name, m, t: through(m)) * w).sum().backward()
+        sc = max(g.abs().max().item() for g in ref.values())
+        e_msg = max((sd2[k].grad - g).abs().max().item() / sc for k, g in ref.items())
+        print("          ... with float32 messages %.2e" % e_msg)
+        assert e_msg <= 0.2 * e_states, (e_msg, e_states)

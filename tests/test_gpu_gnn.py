@@ -20,29 +20,25 @@ def dev():
     return torch.device("cuda:0")
 
 
-def test_default_width_extractor_forward_and_gradients_vs_oracle(dev):
+@pytest.mark.parametrize("seeds,bound", [((2, 11), 6e-4), ((3, 33), 1e-4)])
+def test_default_width_extractor_forward_and_gradients_vs_oracle(dev, seeds, bound):
     """Forward and every parameter gradient of the default-width extractor against the float64 restatement.
 
-    Forward: 2e-5 (observed 4e-7).  Gradients: what limits them is ONE ill-conditioned spot of the reference's formula, not this
-    build's arithmetic.  The std aggregation sqrt(sum_e relu(b_e^2 - mean^2) + 1e-7) (fs_mol/modules/gnn.py:231-240) has slope
-    1 / (2 std) ~ 1e3 where a node's incoming messages are nearly equal, and b_e^2 - mean^2 is then a difference of nearly equal numbers
-    of the size of the 1e-7 floor: the float32 rounding of the MESSAGES (6e-8 relative; they come out of a float32 GEMM in any float32
-    implementation) moves std - hence every gradient that flows through that node - by per cent.  Measured (tools/diag_gnn_states.py,
-    tools/diag_gnn_ab.py): the gradient at the last node state is exact to 5e-7, the error appears in the backward of the last block at
-    ONE node and is carried down from there; two float32 evaluations of the same graph (the fused and the unfused element-wise stage,
-    csrc/block.h - equally accurate in isolation, 1e-7, tools/diag_block_kernel.py) differ from the float64 restatement along the
-    SAME direction by -1 and +2.4 units, float32 PyTorch on the CPU by about 4: a signed random multiple of one rounding.  Forcing the
-    device's std indicators, arg-max winners and ReLU pattern on the restatement (oracle/gnn_oracle.py: std_masks / argmaxes /
-    relu_masks) changes none of this (< 1 %): it is not the kink round 3 blamed.  So the bound is a yardstick computed HERE - the error
-    of float32 PyTorch on the CPU (the reference's own arithmetic) on the same inputs - times 2 for the spread between float32
-    evaluations; observed 0.23 x ... 0.56 x (2.0e-4 ... 4.8e-4 against 8.5e-4)."""
+    Forward: 2e-5 (observed 4e-7).  Gradients, of the largest entry, FIXED bounds:
+      * weights seed 2 / graphs seed 11 (the draw of rounds 2 - 4): 6e-4.  This draw contains a node whose std aggregation
+        (fs_mol/modules/gnn.py:231-240) sits at its 1e-7 floor; tests/test_gnn.py::test_float32_node_states_set_the_gradient_error_floor
+        shows on these very inputs that float64 arithmetic with nothing but the NODE STATES stored in float32 between blocks is
+        already 2.8e-4 away from float64 (messages rounded: 2e-5, aggregates: 5e-6; float32 PyTorch on the CPU: 1.0e-3) - the floor of
+        every float32-state implementation.  Observed here: 2.0e-4 ... 4.8e-4 over rounds 3 - 5, i.e. 0.7 ... 1.7 x that floor.
+      * weights seed 3 / graphs seed 33 (a draw without such a node; floor 5e-6, float32 PyTorch on the CPU 2.5e-4): 1e-4.
+    The yardstick that round 4 computed in the test (2 x the error of float32 PyTorch) is gone; the CPU error is still printed."""
     from adkf_ift_amd.gnn import GraphFeatureExtractor, GraphFeatureExtractorConfig
     from oracle import gnn_oracle as GO
     from test_gnn import grads_under_reference_names, random_graphs, unit_gain_reference_state_dict
 
     cfg = GraphFeatureExtractorConfig()
-    sd = {k: v.requires_grad_(True) for k, v in unit_gain_reference_state_dict(cfg, seed=2).items()}
-    batch = random_graphs(40, seed=11)          # isolated nodes and a single-atom graph included
+    sd = {k: v.requires_grad_(True) for k, v in unit_gain_reference_state_dict(cfg, seed=seeds[0]).items()}
+    batch = random_graphs(40, seed=seeds[1])    # isolated nodes and a single-atom graph included
     want = GO.graph_feature_extractor(batch, sd, cfg)
     model = GraphFeatureExtractor(cfg)
     model.load_reference_state_dict({k: v.detach().float() for k, v in sd.items()})
@@ -71,9 +67,46 @@ def test_default_width_extractor_forward_and_gradients_vs_oracle(dev):
             continue
         e = (mine[k].double().cpu() - v.grad).abs().max().item() / scale
         worst = max(worst, e)
-        assert e <= 2.0 * e32, (k, e, e32)
-    print("default-width extractor: forward rel err %.2e; worst parameter-gradient err %.2e of the largest entry "
-          "(float32 PyTorch on the CPU: %.2e)" % (err, worst, e32))
+        assert e <= bound, (k, e, bound, e32)
+    print("default-width extractor, seeds %s: forward rel err %.2e; worst parameter-gradient err %.2e of the largest entry, bound %.0e "
+          "(float32 PyTorch on the CPU: %.2e)" % (seeds, err, worst, bound, e32))
+
+
+def test_fused_block_stage_equals_the_unfused_one_where_the_problem_is_well_conditioned(dev):
+    """csrc/block.h (combination of the three scaled projections + ReZero + layer norm in one kernel) against PyTorch's element-wise
+    ops for the same stage (``gnn._FUSED_BLOCK = False``), both on the device at the default width, weights seed 3 / graphs seed 33
+    (no node at the std floor: tests/test_gnn.py).  Two float32 evaluations of one function: every parameter gradient within
+    1e-4 of the largest entry, the features within 2e-6.  (On the draw with the ill-conditioned node the same two evaluations
+    differ by 1e-3 - as far as each is from float64; that is the input's conditioning, not the kernel: see the test above.)"""
+    from adkf_ift_amd import gnn as G
+    from test_gnn import grads_under_reference_names, random_graphs, unit_gain_reference_state_dict
+
+    cfg = G.GraphFeatureExtractorConfig()
+    sd = unit_gain_reference_state_dict(cfg, seed=3)
+    batch = random_graphs(40, seed=33).to(dev)
+    batch.node_features = batch.node_features.float()
+    w = torch.randn(40, 512, generator=torch.Generator().manual_seed(1)).to(dev)
+
+    def grads(fused):
+        old = G._FUSED_BLOCK
+        G._FUSED_BLOCK = fused
+        try:
+            model = G.GraphFeatureExtractor(cfg)
+            model.load_reference_state_dict({k: v.detach().float() for k, v in sd.items()})
+            model = model.to(dev)
+            z = model(batch)
+            (z * w).sum().backward()
+            return z.detach(), grads_under_reference_names(model)
+        finally:
+            G._FUSED_BLOCK = old
+
+    zf, gf = grads(True)
+    zu, gu = grads(False)
+    assert (zf - zu).abs().max().item() <= 2e-6 * zu.abs().max().item()
+    scale = max(v.abs().max().item() for v in gu.values())
+    worst = max((gf[k] - gu[k]).abs().max().item() / scale for k in gu)
+    print("fused vs unfused block stage: worst parameter-gradient difference %.2e of the largest entry" % worst)
+    assert worst <= 1e-4, worst
 
 
 @pytest.mark.parametrize("kind,empty_type,hidden", [("PNA", None, 16), ("PNA", 1, 16), ("MultiAggr", 2, 16), ("PNA", 1, 64), ("PNA", None, 192)])
@@ -239,9 +272,11 @@ def test_c3_default_model_meta_step_vs_per_task_oracle_loop(dev):
 
     # ---- oracle side (CPU): ONE extractor pass over all molecules of both tasks (disconnected graphs: equal to the per-part passes,
     # tests/test_gnn.py::test_concatenated_tasks_equal_separate_forwards), then per task the float64 GP oracle at the device's phi.
-    # Run twice: in float64 (the expected values) and with the extractor + head in float32 PyTorch (the yardstick: what the
-    # reference's own arithmetic reaches on these inputs; see the test above for why a fixed bound would be a guess, and for the
-    # factor 2 - observed here: 7.4e-4 (unfused) / 1.24e-3 (fused element-wise stage) against 7.1e-4) ----
+    # Run twice: in float64 (the expected values) and with the extractor + head in float32 PyTorch (printed for comparison: what the
+    # reference's own arithmetic reaches on these inputs).  The bound is FIXED: 1.5e-3 of the largest entry.  On these molecules and
+    # weights float64 arithmetic with only the node states stored in float32 is 5.3e-4 from float64 and float32 PyTorch 1.1e-3
+    # (tests/test_gnn.py::test_float32_node_states_set_the_gradient_error_floor, same inputs): the floor of any float32-state
+    # implementation; observed on the device 7.4e-4 (unfused) / 1.24e-3 (fused element-wise stage, csrc/block.h) = 1.4 / 2.3 x it ----
     mols = mb_cpu.molecules
     T = len(tasks)
 
@@ -282,4 +317,4 @@ def test_c3_default_model_meta_step_vs_per_task_oracle_loop(dev):
 
     e_dev, e32 = worst(mine, mine_fc), worst(g32, f32)
     print("C3 default model: worst theta.grad error %.2e of the largest entry (float32 PyTorch on the CPU through the same loop: %.2e)" % (e_dev, e32))
-    assert e_dev <= 2.0 * e32, (e_dev, e32)
+    assert e_dev <= 1.5e-3, (e_dev, e32)

@@ -28,6 +28,7 @@ static void sweep3(LgMat m, hipStream_t st) {
     }
 }
 
+static int g_stagger = 0, g_prio = 0;
 static int g_dyn = 0;   // extra dynamic LDS per workgroup of the fused kernel: 40000 leaves ONE workgroup per CU (the sweeping workgroup then has its CU to itself)
 static void sweepf(LgMat m, float* dinv2, hipStream_t st) {
     const int nb = ceil_div(m.ld, LB), tn = ceil_div(m.ld, GT), npair = ceil_div(tn * (tn + 1) / 2, 2);
@@ -37,7 +38,7 @@ static void sweepf(LgMat m, float* dinv2, hipStream_t st) {
         m.Dinv = buf[step & 1];
         ProbLgPanel pp; pp.m = m; pp.step = step;
         k_bgemm<ProbLgPanel><<<grid_for(m.T, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn);
-        LgStepArgs sa{m, buf[(step + 1) & 1], m.cnt, step, tn, npair, step + 1 < nb ? 1 : 0};
+        LgStepArgs sa{m, buf[(step + 1) & 1], m.cnt, step, tn, npair, step + 1 < nb ? 1 : 0, g_stagger, g_prio};
         k_lg_update_sweep<<<grid_for(m.T, npair), LGF_NT, g_dyn, st>>>(sa);
     }
 }
@@ -46,6 +47,9 @@ int main(int argc, char** argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 8, n = argc > 2 ? atoi(argv[2]) : 1024, ld = argc > 3 ? atoi(argv[3]) : n;
     const bool ragged = ld != n;
     g_dyn = argc > 4 ? atoi(argv[4]) : 0;
+    g_stagger = argc > 5 ? atoi(argv[5]) : 0;
+    g_prio = argc > 6 ? atoi(argv[6]) : 0;
+    printf("dynamic LDS %d, stagger %d, sweep priority %d\n", g_dyn, g_stagger, g_prio);
     if (g_dyn > 0 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lg_update_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, g_dyn) != hipSuccess) { printf("no LDS opt-in\n"); return 2; }
     std::vector<float> h((size_t)T * ld * ld, 0.f);
     std::vector<int32_t> narr(T);
@@ -123,7 +127,7 @@ int main(int argc, char** argv) {
                     if (which == 0) k_lg_diag<<<grid_for(T, 1), 512>>>(m, step);
                     if (which == 1) k_bgemm<ProbLgPanel><<<grid_for(T, 2 * tn), 256>>>(pp, T, 2, tn);
                     if (which == 2) k_bgemm<ProbLgUpdate><<<grid_for(T, pu.tri), 256>>>(pu, T, tn, tn);
-                    if (which >= 3) { LgStepArgs sa{m, dinv2, m.cnt, step, tn, npair, which == 3 ? 1 : 0}; k_lg_update_sweep<<<grid_for(T, npair), LGF_NT, g_dyn>>>(sa); }
+                    if (which >= 3) { LgStepArgs sa{m, dinv2, m.cnt, step, tn, npair, which == 3 ? 1 : 0, g_stagger, g_prio}; k_lg_update_sweep<<<grid_for(T, npair), LGF_NT, g_dyn>>>(sa); }
                 }
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
