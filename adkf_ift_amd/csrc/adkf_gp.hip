@@ -55,13 +55,13 @@ struct Workspace {
     FitShared* lg_fit;
     double* w64; size_t w64_stride;   // float64 region of the ill-conditioned-task path (refine64.h); null beyond R64_MAXN points
     int vld, nt_oc, nt_ma;
-    bool lg_unfused;   // ADKF_BATCH_LG_UNFUSED of the batch this view was carved for
+    int lg_mode;       // ADKF_BATCH_LG_UNFUSED / ADKF_BATCH_LG_FUSED of the batch this view was carved for: -1 three launches, +1 fused, 0 by size
     size_t bytes;
 };
 
 Workspace carve(void* base, int T, int ns, int nq, int d) {
     Workspace w;
-    w.lg_unfused = false;
+    w.lg_mode = 0;
     size_t off = 0;
     auto take = [&](size_t nfloat) { float* p = base ? reinterpret_cast<float*>(static_cast<char*>(base) + off) : nullptr; off += align_up(nfloat * sizeof(float)); return p; };
     const size_t Tz = (size_t)T;
@@ -96,7 +96,7 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
         const size_t ts = (size_t)((ns + GT - 1) / GT) * ((ns + GT - 1) / GT);
         w.lg_part = take(Tz * (ts > tq ? ts : tq) * 8);
         w.lg_info = reinterpret_cast<int32_t*>(take(Tz));
-        w.lg_cnt = reinterpret_cast<int32_t*>(take(Tz));
+        w.lg_cnt = reinterpret_cast<int32_t*>(take(2 * Tz));   // [T] next-diagonal-block arrivals, [T] trace-tile arrivals
         w.lg_med = reinterpret_cast<int32_t*>(take(Tz * 258));
         w.lg_fit = reinterpret_cast<FitShared*>(take(Tz * ((sizeof(FitShared) + 3) / 4)));
     }
@@ -115,7 +115,7 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
 
 Workspace carve_for(const adkf_batch_t* b, void* ws) {
     Workspace w = carve(ws, b->T, b->ns_max, b->nq_max, b->d);
-    w.lg_unfused = (b->flags & ADKF_BATCH_LG_UNFUSED) != 0;
+    w.lg_mode = (b->flags & ADKF_BATCH_LG_UNFUSED) ? -1 : (b->flags & ADKF_BATCH_LG_FUSED) ? 1 : 0;
     return w;
 }
 
@@ -237,7 +237,12 @@ LgMat lg_mat(const Workspace& w, float* M, int ld, const int32_t* n_arr, const F
     LgMat m;
     m.M = M; m.ld = ld; m.n_arr = n_arr; m.fit = fit;
     m.Dinv = w.lg_Dinv; m.Cbuf = w.lg_C; m.Fbuf = w.lg_F; m.logdet = w.lg_logdet; m.pext = w.lg_pext; m.info = w.lg_info;
-    m.cnt = (lg_fused() && !w.lg_unfused) ? w.lg_cnt : nullptr;
+    // by size: from four block steps on (tools/lgf_bench.hip, profiles/r05_lgf_bench.txt: 8 x 1024 points 0.85 x the time of the three
+    // launches, 16 x 1024 0.90 x; but 64 x 256, 5 x 515 and 3 x 300 points 1.06 - 1.10 x: with two or three block steps the sweep that
+    // rides in the update launch is most of that launch)
+    const bool fused = lg_fused() && (w.lg_mode > 0 || (w.lg_mode == 0 && ld >= 4 * LB));
+    m.cnt = fused ? w.lg_cnt : nullptr;
+    m.D2 = nullptr; m.kind = 0;
     m.T = T; m.vec = (ld & 3) == 0;
     return m;
 }
@@ -249,7 +254,7 @@ void lg_sweep(const LgMat& m0, hipStream_t st) {
     if (m.cnt) {
         // D(0) | P(0) | U(0) + D(1) | P(1) | U(1) + D(2) | ... | P(nb - 1) | U(nb - 1): 2 nb + 1 launches instead of 3 nb
         float* dinv[2] = {m0.Dinv, m0.Dinv + (size_t)m0.T * LB * LB};
-        const int npair = ceil_div(tn * (tn + 1) / 2, 2);
+        const int npair = lgf_npair(tn);
         k_lg_diag<<<grid_for(m.T, 1), 512, 0, st>>>(m, 0);
         for (int step = 0; step < nb; ++step) {
             m.Dinv = dinv[step & 1];
@@ -310,16 +315,21 @@ int launch_inner_large(const InnerArgs& a, const Workspace& w, hipStream_t st) {
     li.in = a; li.fit = w.lg_fit; li.part = w.lg_part;
     li.tiles_1d = ceil_div(a.ld, GT); li.ntiles = li.tiles_1d * li.tiles_1d;
     li.mat = lg_mat(w, a.Ainv, a.ld, a.n_s, w.lg_fit, a.T);
+    // round 5 (with the fused block step): no k_lg_build - block step 0 generates the matrix from the squared distances while it
+    // stages its operands; no k_lg_advance - the last trace tile of a task runs it; the sign of M is flipped by the final evaluation only
+    const bool fused = li.mat.cnt != nullptr;
+    li.cnt_tr = fused ? w.lg_cnt + a.T : nullptr;
+    if (fused) { li.mat.D2 = a.D2ss; li.mat.kind = a.kind; }
     LgMatvecArgs mv{li.mat, a.y_s, (size_t)a.ld, a.vecs + (size_t)V_ALPHA * a.vld, (size_t)NVEC * a.vld, -1.f};
     k_lg_begin<<<ceil_div(a.T, 64), 64, 0, st>>>(li);
     const int n_evals = a.max_evals > 0 ? a.max_evals : 1;
     FitPoll poll(a.max_evals > 0 && !a.exact_evals, a.max_evals, w.lg_info, st);   // lg_info[0] is free between block sweeps
     for (int e = 0; e < n_evals; ++e) {
-        k_lg_build<<<grid_for(a.T, li.ntiles), 256, 0, st>>>(li);
+        if (!fused) k_lg_build<<<grid_for(a.T, li.ntiles), 256, 0, st>>>(li);
         lg_sweep(li.mat, st);
         k_lg_matvec<<<dim3(ceil_div(a.ld, 4), a.T), 256, 0, st>>>(mv);
         k_lg_traces<<<grid_for(a.T, li.ntiles), 256, 0, st>>>(li);
-        k_lg_advance<<<a.T, 64, 0, st>>>(li);
+        if (!fused) k_lg_advance<<<a.T, 64, 0, st>>>(li);
         if (poll.finished(e, w.lg_fit, sizeof(FitShared), offsetof(FitShared, phase), a.T, st)) break;
     }
     LAUNCH_OK();
@@ -837,7 +847,7 @@ int adkf_path_info(int32_t ns_max, int32_t nq_max) {
     int bits = 0;
     const int hi = ns_max > nq_max ? ns_max : nq_max;
     if (nq_max > 0 && use_fused_outer(ns_max, nq_max)) bits |= ADKF_PATH_FUSED_OUTER;
-    if (hi > REG_POINTS) { bits |= ADKF_PATH_BLOCKED; if (lg_fused()) bits |= ADKF_PATH_BLOCKED_FUSED; }
+    if (hi > REG_POINTS) { bits |= ADKF_PATH_BLOCKED; if (lg_fused() && hi >= 4 * LB) bits |= ADKF_PATH_BLOCKED_FUSED; }
     if (carve(nullptr, 1, ns_max, nq_max > 0 ? nq_max : 1, 4).w64_stride != 0) bits |= ADKF_PATH_R64_REGION;
     if (refine64_lds_optin()) bits |= ADKF_PATH_R64_LDS;
     return bits;

@@ -56,6 +56,9 @@ __device__ __forceinline__ void lgf_tri_tile(int tn, int v, int& ti, int& tj) {
     ti = r; tj = r + (v - (r * tn - r * (r - 1) / 2));
 }
 
+// workgroups per task: three for the tiles of the next diagonal block (one each), the other tiles in pairs
+inline __host__ __device__ int lgf_npair(int tn) { return 3 + (tn * (tn + 1) / 2 + 1) / 2; }
+
 __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStepArgs a) {
     using SW = Sweep<128, 512>;
     constexpr int RB = SW::RB, CB = SW::CB;
@@ -76,15 +79,27 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
     const float* Cb = a.m.Cbuf + (size_t)t * LB * ld;
     const float* Fb = a.m.Fbuf + (size_t)t * LB * ld;
     const int tn = a.tn, ntri = tn * (tn + 1) / 2;
+    // block step 0 of the inner side: the matrix entries a computed tile is subtracted from come out of the squared distances
+    // (LgMat::D2 - there was no k_lg_build launch), with k_lg_build's expressions
+    const bool gen = a.m.gen(a.step);
+    const float* Msrc = gen ? a.m.D2 + (size_t)t * ld * ld : Mi;
+    LgKernelAt kf;
+    if (gen) kf.init(a.m, t);
 
     // ---- which tile: the (up to three) tiles of the next diagonal block first, then the upper triangle in row-major order ----
     const int d0 = 2 * (a.step + 1), d1 = d0 + 1;
     const int nd = (a.look && d0 < tn) ? (d1 < tn ? 3 : 1) : 0;
-    const int u = 2 * pair + h;
+    // workgroups [0, nd): ONE tile of the next diagonal block each, on the first half - the second half only keeps the barriers company,
+    // so that the tile's four waves have the CU's four matrix pipes to themselves (two tiles per workgroup share them: 3.4 us of
+    // MFMA issue per tile instead of 1.7, on the critical path of the launch); workgroups [nd, npair): two tiles of the rest each
+    int u = -1;
+    bool next_diag = false;
+    if (pair < nd) { if (h == 0) { u = pair; next_diag = true; } }
+    else if (2 * (pair - nd) + h < ntri - nd) u = nd + 2 * (pair - nd) + h;
     int ti = 0, tj = 0;
-    bool valid = u < ntri, next_diag = false;
+    bool valid = u >= 0;
     if (valid) {
-        if (u < nd) { ti = u < 2 ? d0 : d1; tj = u < 1 ? d0 : d1; next_diag = true; }
+        if (next_diag) { ti = u < 2 ? d0 : d1; tj = u < 1 ? d0 : d1; }
         else {
             int v = u - nd;
             if (nd >= 1) {
@@ -99,12 +114,12 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
     if (m0 >= n || n0 >= n) valid = false;       // tile outside this (ragged) task
 #if (ADKF_LGF_EXP & 4)
     const bool direct = nd > 0 && pair == 0;
-    if (nd > 0 && u < nd) valid = false;
+    if (next_diag) valid = false;
 #endif
     // The tiles of the next diagonal block are the head of the launch's critical path (tiles -> sweep: 20 us of hand-off chain), the
     // other tiles have slack.  Started together, the three tiles take as long as a tile of a full launch takes (15 us: every CU of the
     // XCD is loading operands); started alone they take 5.  So everybody else sleeps first.
-    if (nd > 0 && 2 * pair >= nd)
+    if (nd > 0 && pair >= nd)
         for (int q = 0; q < a.stagger; ++q) __builtin_amdgcn_s_sleep(127);
     auto in_p = [&](int i) { return i >= p0 && i < p0 + LB; };
     const bool piv_i = in_p(m0), piv_j = in_p(n0);
@@ -158,7 +173,7 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pre[i][j][r] = Mi[(size_t)(m0 + wr * 32 + i * 16 + fk * 4 + r) * ld + n0 + wc * 32 + j * 16 + fi];
+                for (int r = 0; r < 4; ++r) pre[i][j][r] = Msrc[(size_t)(m0 + wr * 32 + i * 16 + fk * 4 + r) * ld + n0 + wc * 32 + j * 16 + fi];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
             float* dst = Mi + (size_t)i * ld + j;
             const bool pi = in_p(i), pj = in_p(j);
             float v;
-            if (!pi && !pj) v = *dst - ac;
+            if (!pi && !pj) v = (gen ? kf.at(Msrc[(size_t)i * ld + j], i, j) : *dst) - ac;
             else if (pi && pj) v = -Dv[(i - p0) * LB + (j - p0)];
             else if (pi) v = Fb[(size_t)(i - p0) * ld + j];
             else v = Fb[(size_t)(j - p0) * ld + i];
@@ -228,7 +243,10 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
                 if (mode == 1) {
                     float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { v[r] = pre[i][j][r] - acc[i][j][r]; put(Mi + (size_t)(gi0 + r) * ld + gj, v[r]); }
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = (gen ? kf.at(pre[i][j][r], gi0 + r, gj) : pre[i][j][r]) - acc[i][j][r];
+                        put(Mi + (size_t)(gi0 + r) * ld + gj, v[r]);
+                    }
                     if (ti < tj) {
                         float* mp = Mi + (size_t)gj * ld + gi0;
                         if (next_diag && !(ADKF_LGF_EXP & 1)) { st_sc1(mp, v[0]); st_sc1(mp + 1, v[1]); st_sc1(mp + 2, v[2]); st_sc1(mp + 3, v[3]); }
@@ -241,7 +259,7 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float* dst = Mi + (size_t)(gi0 + r) * ld + gj;
-                        if (!pi && !pj) v[r] = *dst - acc[i][j][r];
+                        if (!pi && !pj) v[r] = (gen ? kf.at(Msrc[(size_t)(gi0 + r) * ld + gj], gi0 + r, gj) : *dst) - acc[i][j][r];
                         else if (pi && pj) v[r] = -Dv[(gi0 + r - p0) * LB + (gj - p0)];
                         else if (pi) v[r] = Fb[(size_t)(gi0 + r - p0) * ld + gj];
                         else v[r] = Fb[(size_t)(gj - p0) * ld + gi0 + r];
@@ -258,7 +276,7 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
 
     // ---- the next diagonal block: whoever completes it sweeps it ----
     if (nd == 0) return;
-    const int mine = (2 * pair < nd ? 1 : 0) + (2 * pair + 1 < nd ? 1 : 0);   // tiles of the next diagonal block in this workgroup (uniform)
+    const int mine = pair < nd ? 1 : 0;          // tiles of the next diagonal block in this workgroup (uniform)
     if (mine == 0) return;
 #if (ADKF_LGF_EXP & 4)
     if (!direct) return;

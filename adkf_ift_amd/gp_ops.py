@@ -20,6 +20,7 @@ KERNELS = {"rbf": KERNEL_RBF, "RBF": KERNEL_RBF, "matern": KERNEL_MATERN52}
 REUSE_DIST = 1
 REUSE_INNER = 2
 LG_UNFUSED = 16     # blocked path: three launches per block step (A/B; include/adkf_gp.h)
+LG_FUSED = 32       # ... the fused block step whatever the size
 DEFER_REFINE = 8   # adkf_fit: leave the float64 re-evaluation of ill-conditioned tasks to the next call (include/adkf_gp.h)
 ARD = 4
 

@@ -64,6 +64,7 @@ extern "C" {
 #define ADKF_BATCH_LG_UNFUSED 16 /* more than 128 points only, A/B runs and tests: the blocked sweep as three launches per block step
                                     (k_lg_diag, panel, update: csrc/large.h) instead of the update of step k and the diagonal sweep of
                                     step k + 1 in one launch (csrc/large_fused.h).  Both give bit-identical results. */
+#define ADKF_BATCH_LG_FUSED 32   /* ... and the fused form whatever the size (without either flag: fused from 512 points on, where it is faster) */
 
 /* ARD kernel (``use_ard``: fs_mol/models/adaptive_dkt.py:107-108 -> gpytorch ``ard_num_dims``): one lengthscale per
  * feature dimension.  With this flag EVERY phi / g_phi / v argument has h = 2 + d entries per task, laid out
@@ -118,7 +119,7 @@ const char* adkf_last_hip_error(void);
 #define ADKF_PATH_FUSED_OUTER 1    /* 64 < max(ns, nq) <= 128: the outer / hypergradient stage of a task as ONE kernel (csrc/hyper.h, 159 KB of
                                       dynamic LDS); clear: the sixteen-launch pipeline */
 #define ADKF_PATH_BLOCKED 2        /* max(ns, nq) > 128: blocked sweep through L2 / HBM (csrc/large.h) */
-#define ADKF_PATH_BLOCKED_FUSED 4  /* ... with update k + sweep k + 1 in one launch (csrc/large_fused.h); clear: ADKF_LG_FUSED=0 */
+#define ADKF_PATH_BLOCKED_FUSED 4  /* ... with update k + sweep k + 1 in one launch (csrc/large_fused.h: from 512 points on); clear: the three launches */
 #define ADKF_PATH_R64_REGION 8     /* the workspace of this shape carries the float64 region of the ill-conditioned-task path (csrc/refine64.h) */
 #define ADKF_PATH_R64_LDS 16       /* that path's inverses run in 128 KB of dynamic LDS; clear: in global memory */
 int adkf_path_info(int32_t ns_max, int32_t nq_max);

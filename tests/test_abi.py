@@ -147,7 +147,7 @@ def test_entry_points_fail_cleanly_without_a_device(lib, ns, nq):
     b.n_s = b.n_q = None
     b.Z_s, b.y_s, b.Z_q, b.y_q, b.priors = Zs.data_ptr(), ys.data_ptr(), Zq.data_ptr(), yq.data_ptr(), pri.data_ptr()
     p = lambda t: C.c_void_p(t.data_ptr())
-    for flags in (0, 16):   # ADKF_BATCH_LG_UNFUSED
+    for flags in (0, 16, 32):   # ADKF_BATCH_LG_UNFUSED, ADKF_BATCH_LG_FUSED
         b.flags = flags
         assert lib.adkf_init_params(C.byref(b), 0, 1, p(phi), p(pri), p(l0), p(ws), nb, None) == -4
         assert lib.adkf_mll_value_grad(C.byref(b), p(phi), p(f), p(g), None, p(info), p(ws), nb, None) == -4

@@ -31,7 +31,7 @@ static void sweep3(LgMat m, hipStream_t st) {
 static int g_stagger = 0, g_prio = 0;
 static int g_dyn = 0;   // extra dynamic LDS per workgroup of the fused kernel: 40000 leaves ONE workgroup per CU (the sweeping workgroup then has its CU to itself)
 static void sweepf(LgMat m, float* dinv2, hipStream_t st) {
-    const int nb = ceil_div(m.ld, LB), tn = ceil_div(m.ld, GT), npair = ceil_div(tn * (tn + 1) / 2, 2);
+    const int nb = ceil_div(m.ld, LB), tn = ceil_div(m.ld, GT), npair = lgf_npair(tn);
     float* buf[2] = {m.Dinv, dinv2};
     k_lg_diag<<<grid_for(m.T, 1), 512, 0, st>>>(m, 0);
     for (int step = 0; step < nb; ++step) {
@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
     hipMemset(b.cnt, 0xff, T * 4);   // garbage: the sweep's first launch has to zero it
     LgMat m;
     m.M = b.M; m.ld = ld; m.n_arr = ragged ? b.narr : nullptr; m.fit = nullptr; m.Dinv = b.Dinv; m.Cbuf = b.C; m.Fbuf = b.F;
-    m.logdet = b.logdet; m.pext = b.pext; m.info = b.info; m.cnt = b.cnt; m.T = T; m.vec = (ld & 3) == 0;
+    m.logdet = b.logdet; m.pext = b.pext; m.info = b.info; m.cnt = b.cnt; m.D2 = nullptr; m.kind = 0; m.T = T; m.vec = (ld & 3) == 0;
     std::vector<float> r3(h.size()), rf(h.size());
     std::vector<float> l3(T), lf(T), p3(2 * T), pf(2 * T);
     std::vector<int32_t> i3(T), if_(T);
@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
         }
     // the launches of one block step on their own (step 3 of 8: the state of M does not matter for the time)
     {
-        const int tn = ceil_div(ld, GT), npair = ceil_div(tn * (tn + 1) / 2, 2), step = ceil_div(ld, LB) > 3 ? 3 : 0;
+        const int tn = ceil_div(ld, GT), npair = lgf_npair(tn), step = ceil_div(ld, LB) > 3 ? 3 : 0;
         ProbLgPanel pp; pp.m = m; pp.step = step;
         ProbLgUpdate pu; pu.m = m; pu.step = step; pu.tri = tn * (tn + 1) / 2;
         const char* nm[5] = {"k_lg_diag", "panel", "update (three-launch path)", "update + sweep (fused)", "update alone in the fused kernel (look = 0)"};
