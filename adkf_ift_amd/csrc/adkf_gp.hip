@@ -258,10 +258,12 @@ void lg_sweep(const LgMat& m0, hipStream_t st) {
         k_lg_diag<<<grid_for(m.T, 1), 512, 0, st>>>(m, 0);
         for (int step = 0; step < nb; ++step) {
             m.Dinv = dinv[step & 1];
-            ProbLgPanel pp; pp.m = m; pp.step = step;
-            k_bgemm<ProbLgPanel><<<grid_for(m.T, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn);
+            const bool gen = m.D2 != nullptr && step == 0;
+            if (gen) { ProbLgPanelT<true> pp; pp.m = m; pp.step = step; k_bgemm<ProbLgPanelT<true>><<<grid_for(m.T, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn); }
+            else { ProbLgPanel pp; pp.m = m; pp.step = step; k_bgemm<ProbLgPanel><<<grid_for(m.T, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn); }
             LgStepArgs sa{m, dinv[(step + 1) & 1], m.cnt, step, tn, npair, step + 1 < nb ? 1 : 0, LGF_STAGGER, LGF_PRIO};
-            k_lg_update_sweep<<<grid_for(m.T, npair), LGF_NT, 0, st>>>(sa);
+            if (gen) k_lg_update_sweep<true><<<grid_for(m.T, npair), LGF_NT, 0, st>>>(sa);
+            else k_lg_update_sweep<false><<<grid_for(m.T, npair), LGF_NT, 0, st>>>(sa);
         }
         return;
     }

@@ -121,23 +121,23 @@ __global__ __launch_bounds__(512) void k_lg_diag(LgMat a, int step) {
     }
 }
 
-struct ProbLgPanel {
+template <bool GEN = false>   // GEN: block step 0 of the fused inner path - the pivot rows come out of the squared distances (LgMat::D2)
+struct ProbLgPanelT {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = false;
     static constexpr int NRED = 0;
     LgMat m; int step;
     int n, p0, nloc; const float *Dv, *Mi; float *Cb, *Fb; bool vec;
-    bool gen; LgKernelAt kf;   // block step 0 of the fused inner path: the pivot rows are generated from the squared distances (LgMat::D2)
+    LgKernelAt kf;
     __device__ bool setup(int t) {
         if (!m.active(t)) return false;
         n = m.n(t); p0 = step * LB; nloc = min(LB, n - p0); vec = m.vec;
         if (nloc <= 0) return false;
-        gen = m.gen(step);
-        if (gen) kf.init(m, t);
-        Dv = m.Dinv + (size_t)t * LB * LB; Mi = (gen ? const_cast<float*>(m.D2) : m.M) + (size_t)t * m.ld * m.ld;
+        if (GEN) kf.init(m, t);
+        Dv = m.Dinv + (size_t)t * LB * LB; Mi = (GEN ? const_cast<float*>(m.D2) : m.M) + (size_t)t * m.ld * m.ld;
         Cb = m.Cbuf + (size_t)t * LB * m.ld; Fb = m.Fbuf + (size_t)t * LB * m.ld;
         return true;
     }
-    __device__ __forceinline__ float val(float raw, int i, int j) const { return gen ? kf.at(raw, i, j) : raw; }   // (i, j) = global row / column
+    __device__ __forceinline__ float val(float raw, int i, int j) const { return GEN ? kf.at(raw, i, j) : raw; }   // (i, j) = global row / column
     __device__ int M() const { return nloc; } __device__ int N() const { return n; } __device__ int K() const { return nloc; }
     __device__ bool skip(int, int n0) const { return n0 >= p0 && n0 < p0 + LB; }  // F_P is never read
     __device__ float a(int i, int k) const { return Dv[i * LB + k]; }
@@ -178,6 +178,8 @@ struct ProbLgPanel {
     }
     __device__ void store_red(int, const float*) const {}
 };
+
+using ProbLgPanel = ProbLgPanelT<false>;
 
 struct ProbLgUpdate {
     static constexpr bool A_KCONTIG = false, B_KCONTIG = false;
@@ -298,7 +300,7 @@ struct LgInner {
                         // advance step itself (no k_lg_advance launch), and M keeps its sign until the final evaluation
 };
 
-__device__ __forceinline__ void lg_advance_task(const LgInner& a, int t, int lane);
+template <int NT> __device__ __forceinline__ void lg_advance_task(const LgInner& a, int t, int tid, float* red);
 
 __global__ void k_lg_begin(LgInner a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -413,27 +415,48 @@ __global__ __launch_bounds__(256) void k_lg_traces(LgInner a) {
     }
     if (!a.cnt_tr) return;
     __syncthreads();
-    if (s_last && threadIdx.x < 64) lg_advance_task(a, t, threadIdx.x);
+    __shared__ float adv_red[8 * 4];
+    if (s_last) lg_advance_task<256>(a, t, threadIdx.x, adv_red);   // (uniform over the workgroup: barriers inside)
 }
 
-// One wave per task: finish the evaluation, then either advance the optimiser or publish the final results.
-__device__ __forceinline__ void lg_advance_task(const LgInner& a, int t, int lane) {
+// NT threads per task (one wave in k_lg_advance; the 256 threads of the last trace tile on the fused path, where a single wave
+// walking the partials and the vectors was a chain of twenty dependent trips to memory): finish the evaluation, then either advance
+// the optimiser or publish the final results.  The sums run over fixed index sets in a fixed order: deterministic.
+template <int NT>
+__device__ __forceinline__ void lg_advance_task(const LgInner& a, int t, int tid, float* red) {
     FitShared& fs = a.fit[t];
     if (fs.phase == PH_DONE) return;
-    const int n = a.mat.n(t);
+    const int n = a.mat.n(t), lane = tid;
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float dmax = 0.f;
-    for (int q = lane; q < a.ntiles; q += 64) {
+    for (int q = tid; q < a.ntiles; q += NT) {
         const float* p = a.part + ((size_t)t * a.ntiles + q) * 4;
         acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2];
         dmax = fmaxf(dmax, p[3]);
     }
-    dmax = wave_max(dmax);
     const float* al = a.in.vecs + ((size_t)t * NVEC + V_ALPHA) * a.in.vld;
     const float* y = a.in.y_s + (size_t)t * a.in.ld;
-    for (int i = lane; i < n; i += 64) { const float v = al[i]; acc[3] += v * v; acc[4] += y[i] * v; }
+    for (int i = tid; i < n; i += NT) { const float v = al[i]; acc[3] += v * v; acc[4] += y[i] * v; }
+    dmax = wave_max(dmax);
 #pragma unroll
     for (int q = 0; q < 5; ++q) acc[q] = wave_sum(acc[q]);
+    if constexpr (NT > 64) {
+        // per-wave totals through LDS, summed in wave order by everybody
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) red[(tid >> 6) * 8 + q] = acc[q];
+            red[(tid >> 6) * 8 + 5] = dmax;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc[q] = 0.f;
+        dmax = 0.f;
+        for (int w = 0; w < NT / 64; ++w) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) acc[q] += red[w * 8 + q];
+            dmax = fmaxf(dmax, red[w * 8 + 5]);
+        }
+    }
     if (lane != 0) return;
     float xe[3] = {fs.xe[0], fs.xe[1], fs.xe[2]}, pri[4], f, g[3], extra[9];
     for (int q = 0; q < 4; ++q) pri[q] = a.in.priors[t * 4 + q];
@@ -461,7 +484,7 @@ __device__ __forceinline__ void lg_advance_task(const LgInner& a, int t, int lan
 
 __global__ __launch_bounds__(64) void k_lg_advance(LgInner a) {
     if ((int)blockIdx.x >= a.in.T) return;
-    lg_advance_task(a, blockIdx.x, threadIdx.x);
+    lg_advance_task<64>(a, blockIdx.x, threadIdx.x, nullptr);
 }
 
 // ---- outer (query) side --------------------------------------------------------------------------------------

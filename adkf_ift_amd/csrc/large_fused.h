@@ -59,6 +59,7 @@ __device__ __forceinline__ void lgf_tri_tile(int tn, int v, int& ti, int& tj) {
 // workgroups per task: three for the tiles of the next diagonal block (one each), the other tiles in pairs
 inline __host__ __device__ int lgf_npair(int tn) { return 3 + (tn * (tn + 1) / 2 + 1) / 2; }
 
+template <bool GEN>   // GEN: block step 0 of the inner side (the matrix comes out of the squared distances)
 __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStepArgs a) {
     using SW = Sweep<128, 512>;
     constexpr int RB = SW::RB, CB = SW::CB;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
     const int tn = a.tn, ntri = tn * (tn + 1) / 2;
     // block step 0 of the inner side: the matrix entries a computed tile is subtracted from come out of the squared distances
     // (LgMat::D2 - there was no k_lg_build launch), with k_lg_build's expressions
-    const bool gen = a.m.gen(a.step);
+    constexpr bool gen = GEN;
     const float* Msrc = gen ? a.m.D2 + (size_t)t * ld * ld : Mi;
     LgKernelAt kf;
     if (gen) kf.init(a.m, t);
