@@ -233,11 +233,16 @@ def restore_optimizer_state(model: ADKTModel, optimizer: torch.optim.Optimizer, 
         n = name_of[id(p)]
         optimizer.state[p] = {"step": torch.as_tensor(float(step)), "exp_avg": moments["exp_avg"][n].detach().to(p).clone(),
                               "exp_avg_sq": moments["exp_avg_sq"][n].detach().to(p).clone()}
-    g0 = opt_sd["param_groups"][0]
-    for g in optimizer.param_groups:
-        for k in ("lr", "betas", "eps", "weight_decay", "amsgrad"):
-            if k in g0 and k in g:
-                g[k] = g0[k]
+    # hyper-parameters group by group when the layouts agree; a saved state with ONE group next to a target with several (the lr / 10
+    # group of load_model_gnn_weights) leaves the target's groups alone - overwriting them would undo the warm-start schedule and leave
+    # ``initial_lr`` stale for its LambdaLR; several saved groups (a reference run saved after a GNN warm start: [other, gnn], built
+    # from state_dict() order) do not map onto this package's registration order and are refused above by the slot count
+    saved_groups = opt_sd["param_groups"]
+    if len(saved_groups) == len(optimizer.param_groups):
+        for g, gs in zip(optimizer.param_groups, saved_groups):
+            for k in ("lr", "betas", "eps", "weight_decay", "amsgrad"):
+                if k in gs and k in g:
+                    g[k] = gs[k]
     return "reference"
 
 

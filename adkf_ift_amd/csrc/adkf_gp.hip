@@ -3,6 +3,7 @@
 // (except adkf_check_info), everything enqueued on the caller's stream.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "../../include/adkf_gp.h"
@@ -331,7 +332,7 @@ int launch_inner_large(const InnerArgs& a, const Workspace& w, hipStream_t st) {
         lg_sweep(li.mat, st);
         k_lg_matvec<<<dim3(ceil_div(a.ld, 4), a.T), 256, 0, st>>>(mv);
         k_lg_traces<<<grid_for(a.T, li.ntiles), 256, 0, st>>>(li);
-        if (!fused) k_lg_advance<<<a.T, 64, 0, st>>>(li);
+        if (!fused) k_lg_advance<<<a.T, 256, 0, st>>>(li);
         if (poll.finished(e, w.lg_fit, sizeof(FitShared), offsetof(FitShared, phase), a.T, st)) break;
     }
     LAUNCH_OK();
@@ -399,7 +400,12 @@ bool refine64_lds_optin() {
 
 // ADKF_R64_STOP (read once; diagnostics, tools/r64_phases.sh): the float64 path leaves after that phase - results are then garbage
 int r64_stop() {
-    static const int stop = [] { const char* e = getenv("ADKF_R64_STOP"); return e ? atoi(e) : 0; }();
+    static const int stop = [] {
+        const char* e = getenv("ADKF_R64_STOP");
+        const int v = e ? atoi(e) : 0;
+        if (v != 0) fprintf(stderr, "libadkf_gp: ADKF_R64_STOP=%d is set - the float64 path leaves after that phase and its RESULTS ARE GARBAGE (phase-timing diagnostics only)\n", v);
+        return v;
+    }();
     return stop;
 }
 
@@ -429,6 +435,9 @@ void launch_refine(const TaskView& tv, const adkf_batch_t* b, const Workspace& w
 // (read once) keeps the sixteen-launch pipeline for A/B measurements.
 bool use_fused_outer(int ns, int nq) {
     static const bool enabled = [] { const char* e = getenv("ADKF_FUSED_OUTER"); return !e || atoi(e) != 0; }();
+    // ADKF_FUSED_OUTER_MIN (read once, experiments): smallest max(support, query) that takes the one-kernel stage; default 1 - round 5
+    // sends the small shapes (C1, 16 / 32 / 64-shot tasks) through the ragged instance too: one launch instead of sixteen
+    static const int min_pts = [] { const char* e = getenv("ADKF_FUSED_OUTER_MIN"); return e ? atoi(e) : 1; }();
     static const bool optin = [] {
         bool ok = true;
         for (const void* f : {reinterpret_cast<const void*>(&k_hyper<true, 0>), reinterpret_cast<const void*>(&k_hyper<true, 1>),
@@ -438,7 +447,7 @@ bool use_fused_outer(int ns, int nq) {
     }();
     if (!optin) (void)hipGetLastError();
     const int hi = ns > nq ? ns : nq;
-    return enabled && optin && hi > 64 && hi <= HY_N;
+    return enabled && optin && hi >= min_pts && hi <= HY_N;
 }
 
 int launch_outer_factor(const OuterArgs& a, const Workspace& w, int nq, hipStream_t st) {

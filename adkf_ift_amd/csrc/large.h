@@ -482,9 +482,11 @@ __device__ __forceinline__ void lg_advance_task(const LgInner& a, int t, int tid
     fs.phase = PH_DONE;
 }
 
-__global__ __launch_bounds__(64) void k_lg_advance(LgInner a) {
+// (256 threads like the last trace tile of the fused path: the same summation order, so both paths run the same fit bit for bit)
+__global__ __launch_bounds__(256) void k_lg_advance(LgInner a) {
+    __shared__ float adv_red[8 * 4];
     if ((int)blockIdx.x >= a.in.T) return;
-    lg_advance_task<64>(a, blockIdx.x, threadIdx.x, nullptr);
+    lg_advance_task<256>(a, blockIdx.x, threadIdx.x, adv_red);
 }
 
 // ---- outer (query) side --------------------------------------------------------------------------------------

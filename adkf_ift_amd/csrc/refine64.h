@@ -412,7 +412,7 @@ __device__ int r64_inverse(double* M, int n, int ld, double& logdet, double* col
 }
 
 // The same for more than R64_LDS_POINTS points: block Gauss-Jordan with 128-pivot blocks - the diagonal block inverted in LDS by
-// r64_inverse, the panel products and the rank-128 update on the FP64 matrix pipe (r64_mm).  `scr`: NB^2 + 2 NB n doubles.
+// r64_inverse (lds = null, i.e. the 128 KB opt-in was refused: in global memory, like r64_inverse itself then), the panel products and the rank-128 update on the FP64 matrix pipe (r64_mm).  `scr`: NB^2 + 2 NB n doubles.
 //   M[K,K] <- D^-1,   M[K,j] <- D^-1 M[K,j],   M[i,K] <- -M[i,K] D^-1,   M[i,j] <- M[i,j] - M[i,K] D^-1 M[K,j]     (i, j outside K)
 __device__ int r64_inverse_blocked(double* M, int n, int ld, double& logdet, double* colv, double* rowv, double* lds, double* scr) {
     constexpr int NB = R64_LDS_POINTS;
@@ -530,7 +530,7 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
     double logdetA;
     double* scr = W + r64_scratch_offset(ld, ldq);
     const int badA = n <= R64_LDS_POINTS ? r64_inverse(A1, n, ld, logdetA, gjc, gjr, a.lds_inverse ? r64_lds : nullptr, a.stop != -1)
-                                         : r64_inverse_blocked(A1, n, ld, logdetA, gjc, gjr, r64_lds, scr);
+                                         : r64_inverse_blocked(A1, n, ld, logdetA, gjc, gjr, a.lds_inverse ? r64_lds : nullptr, scr);
     R64_STOP(2);   // + A, A^-1
     float* Ai32 = a.Ainv + (size_t)t * ld * ld;
     for (int e = tid; e < n * n; e += R64_NT) { const int i = e / n, j = e % n; Ai32[(size_t)i * ld + j] = (float)A1[(size_t)i * ld + j]; }
@@ -670,7 +670,7 @@ __device__ __forceinline__ void refine64_task(const Refine64Args& a) {
            }, stage);
     double logdetS;
     const int badS = m <= R64_LDS_POINTS ? r64_inverse(S1, m, ldq, logdetS, gjc, gjr, a.lds_inverse ? r64_lds : nullptr, a.stop != -1)
-                                         : r64_inverse_blocked(S1, m, ldq, logdetS, gjc, gjr, r64_lds, scr);
+                                         : r64_inverse_blocked(S1, m, ldq, logdetS, gjc, gjr, a.lds_inverse ? r64_lds : nullptr, scr);
     R64_STOP(7);   // + S, S^-1
     if (a.S) {
         float* S32 = a.S + (size_t)t * ldq * ldq;

@@ -125,7 +125,13 @@ class _GraphPlan:
             setattr(new, k, v)
         return new
 
-    def matches(self, num_nodes: int, bidirectional: bool, pna: bool, device, dtype) -> bool:
+    def matches(self, num_nodes: int, bidirectional: bool, pna: bool, device, dtype, adjacency_lists=None) -> bool:
+        """``adjacency_lists`` (when given): the per-edge-type edge counts must be the plan's - a batch whose lists were replaced or
+        filtered after collation must not run on the old CSR lists and degrees."""
+        if adjacency_lists is not None:
+            want = [int(a.shape[0]) * (2 if self.bidirectional else 1) for a in adjacency_lists]
+            if want != [int(s.shape[0]) for s in self.srcs]:
+                return False
         return (self.num_nodes == num_nodes and self.bidirectional == bidirectional and (self.pna or not pna)
                 and self.all_tgts.device == device and self.inv_count.dtype == dtype)
 
@@ -536,7 +542,7 @@ class GNN(nn.Module):
 
     def forward(self, node_features: torch.Tensor, adj_lists: List[torch.Tensor], plan: Optional[_GraphPlan] = None) -> List[torch.Tensor]:
         bidir, pna = self.config.make_edges_bidirectional, self.config.type.lower() == "pna"
-        if plan is None or not plan.matches(node_features.shape[0], bidir, pna, node_features.device, node_features.dtype):
+        if plan is None or not plan.matches(node_features.shape[0], bidir, pna, node_features.device, node_features.dtype, adj_lists):
             plan = _GraphPlan(adj_lists, node_features.shape[0], bidir, pna, node_features.dtype)
         cur, states = node_features, [node_features]
         for blk in self.gnn_blocks:
@@ -695,8 +701,9 @@ class CombinedGraphReadout(nn.Module):
         V, hid = node_embeddings.shape[0], self.nh * self.hd
         h = F.relu(self.first(node_embeddings))
         h_ms, h_mv, h_ss, h_sv = h.split(hid, dim=1)
-        if node_embeddings.is_cuda and node_embeddings.dtype == torch.float32:
-            # GPU: one fused, order-fixed pooling kernel (no fallback: a missing library raises)
+        if node_embeddings.is_cuda and node_embeddings.dtype == torch.float32 and self.nh <= 64:
+            # GPU: one fused, order-fixed pooling kernel (no fallback: a missing library raises); more than 64 heads
+            # (READOUT_MAX_HEADS, csrc/readout.h) is not a shape the kernels take: PyTorch's scatter ops below
             ok = (plan is not None and plan.perm_graph is not None and plan.num_graphs == num_graphs
                   and plan.perm_graph.device == node_embeddings.device and plan.perm_graph.shape[0] == V)
             segs = (plan.perm_graph, plan.rowptr_graph) if ok else (None, None)
