@@ -57,7 +57,22 @@ struct LgKernelAt {
         const float ls = softplus_f(fs.xe[2]);
         il2 = 1.f / (ls * ls); kind = a.kind;
     }
-    __device__ __forceinline__ float at(float d2, int i, int j) const { return os * kappa0(kind, d2 * il2) + (i == j ? noise : 0.f); }
+    // No FMA contraction in here: hipcc contracts a * b + c depending on what surrounds the expression once it is inlined, and this
+    // one is inlined into five kernels (k_lg_build, k_lg_diag, the panel functor and the fused update - operand staging and epilogues)
+    // that must all produce the SAME matrix entry for the fused and the three-launch path to run the same fit bit for bit.
+    __device__ __forceinline__ float at(float d2, int i, int j) const {
+#pragma clang fp contract(off)
+        const float u = d2 * il2;
+        float k0;
+        if (kind == 0) k0 = expf(-0.5f * u);
+        else {
+            const float r = sqrtf(u);
+            const float p1 = SQRT5 * r, p2 = (5.f / 3.f) * u;
+            k0 = ((1.f + p1) + p2) * expf(-p1);
+        }
+        const float sk = os * k0;
+        return sk + (i == j ? noise : 0.f);
+    }
 };
 
 __global__ __launch_bounds__(512) void k_lg_diag(LgMat a, int step) {
@@ -322,9 +337,8 @@ __global__ __launch_bounds__(256) void k_lg_build(LgInner a) {
     const int n = a.mat.n(t), ld = a.in.ld;
     const int m0 = (tile / a.tiles_1d) * GT, n0 = (tile % a.tiles_1d) * GT;
     if (m0 >= n || n0 >= n) return;
-    const FitShared& fs = a.fit[t];
-    const float noise = softplus_f(fs.xe[0]) + NOISE_LB, os = softplus_f(fs.xe[1]), ls = softplus_f(fs.xe[2]);
-    const float il2 = 1.f / (ls * ls);
+    LgKernelAt kf;
+    { LgMat km = a.mat; km.fit = a.fit; km.kind = a.in.kind; kf.init(km, t); }
     const float* D2 = a.in.D2ss + (size_t)t * ld * ld;
     float* Mi = a.mat.M + (size_t)t * ld * ld;
     // sixteen elements per thread: all their loads first, to clamped addresses (no branch around a load: kernels.h), then the
@@ -337,7 +351,7 @@ __global__ __launch_bounds__(256) void k_lg_build(LgInner a) {
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int i = m0 + (threadIdx.x >> 6) + 4 * q;
-        if (i < n && j < n) Mi[(size_t)i * ld + j] = os * kappa0(a.in.kind, d2v[q] * il2) + (i == j ? noise : 0.f);
+        if (i < n && j < n) Mi[(size_t)i * ld + j] = kf.at(d2v[q], i, j);
     }
 }
 
