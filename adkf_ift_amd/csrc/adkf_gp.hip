@@ -97,7 +97,7 @@ Workspace carve(void* base, int T, int ns, int nq, int d) {
         const size_t ts = (size_t)((ns + GT - 1) / GT) * ((ns + GT - 1) / GT);
         w.lg_part = take(Tz * (ts > tq ? ts : tq) * 8);
         w.lg_info = reinterpret_cast<int32_t*>(take(Tz));
-        w.lg_cnt = reinterpret_cast<int32_t*>(take(2 * Tz));   // [T] next-diagonal-block arrivals, [T] trace-tile arrivals
+        w.lg_cnt = reinterpret_cast<int32_t*>(take(Tz));
         w.lg_med = reinterpret_cast<int32_t*>(take(Tz * 258));
         w.lg_fit = reinterpret_cast<FitShared*>(take(Tz * ((sizeof(FitShared) + 3) / 4)));
     }
@@ -243,7 +243,6 @@ LgMat lg_mat(const Workspace& w, float* M, int ld, const int32_t* n_arr, const F
     // rides in the update launch is most of that launch)
     const bool fused = lg_fused() && (w.lg_mode > 0 || (w.lg_mode == 0 && ld >= 4 * LB));
     m.cnt = fused ? w.lg_cnt : nullptr;
-    m.D2 = nullptr; m.kind = 0;
     m.T = T; m.vec = (ld & 3) == 0;
     return m;
 }
@@ -259,12 +258,10 @@ void lg_sweep(const LgMat& m0, hipStream_t st) {
         k_lg_diag<<<grid_for(m.T, 1), 512, 0, st>>>(m, 0);
         for (int step = 0; step < nb; ++step) {
             m.Dinv = dinv[step & 1];
-            const bool gen = m.D2 != nullptr && step == 0;
-            if (gen) { ProbLgPanelT<true> pp; pp.m = m; pp.step = step; k_bgemm<ProbLgPanelT<true>><<<grid_for(m.T, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn); }
-            else { ProbLgPanel pp; pp.m = m; pp.step = step; k_bgemm<ProbLgPanel><<<grid_for(m.T, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn); }
+            ProbLgPanel pp; pp.m = m; pp.step = step;
+            k_bgemm<ProbLgPanel><<<grid_for(m.T, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn);
             LgStepArgs sa{m, dinv[(step + 1) & 1], m.cnt, step, tn, npair, step + 1 < nb ? 1 : 0, LGF_STAGGER, LGF_PRIO};
-            if (gen) k_lg_update_sweep<true><<<grid_for(m.T, npair), LGF_NT, 0, st>>>(sa);
-            else k_lg_update_sweep<false><<<grid_for(m.T, npair), LGF_NT, 0, st>>>(sa);
+            k_lg_update_sweep<<<grid_for(m.T, npair), LGF_NT, 0, st>>>(sa);
         }
         return;
     }
@@ -318,21 +315,16 @@ int launch_inner_large(const InnerArgs& a, const Workspace& w, hipStream_t st) {
     li.in = a; li.fit = w.lg_fit; li.part = w.lg_part;
     li.tiles_1d = ceil_div(a.ld, GT); li.ntiles = li.tiles_1d * li.tiles_1d;
     li.mat = lg_mat(w, a.Ainv, a.ld, a.n_s, w.lg_fit, a.T);
-    // round 5 (with the fused block step): no k_lg_build - block step 0 generates the matrix from the squared distances while it
-    // stages its operands; no k_lg_advance - the last trace tile of a task runs it; the sign of M is flipped by the final evaluation only
-    const bool fused = li.mat.cnt != nullptr;
-    li.cnt_tr = fused ? w.lg_cnt + a.T : nullptr;
-    if (fused) { li.mat.D2 = a.D2ss; li.mat.kind = a.kind; }
     LgMatvecArgs mv{li.mat, a.y_s, (size_t)a.ld, a.vecs + (size_t)V_ALPHA * a.vld, (size_t)NVEC * a.vld, -1.f};
     k_lg_begin<<<ceil_div(a.T, 64), 64, 0, st>>>(li);
     const int n_evals = a.max_evals > 0 ? a.max_evals : 1;
     FitPoll poll(a.max_evals > 0 && !a.exact_evals, a.max_evals, w.lg_info, st);   // lg_info[0] is free between block sweeps
     for (int e = 0; e < n_evals; ++e) {
-        if (!fused) k_lg_build<<<grid_for(a.T, li.ntiles), 256, 0, st>>>(li);
+        k_lg_build<<<grid_for(a.T, li.ntiles), 256, 0, st>>>(li);
         lg_sweep(li.mat, st);
         k_lg_matvec<<<dim3(ceil_div(a.ld, 4), a.T), 256, 0, st>>>(mv);
         k_lg_traces<<<grid_for(a.T, li.ntiles), 256, 0, st>>>(li);
-        if (!fused) k_lg_advance<<<a.T, 256, 0, st>>>(li);
+        k_lg_advance<<<a.T, 256, 0, st>>>(li);
         if (poll.finished(e, w.lg_fit, sizeof(FitShared), offsetof(FitShared, phase), a.T, st)) break;
     }
     LAUNCH_OK();

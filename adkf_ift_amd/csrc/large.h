@@ -39,40 +39,9 @@ struct LgMat {
     float* pext;            // [T, 2] smallest / largest pivot so far: the condition estimate that picks the float64 path (refine64.h)
     int32_t* info;          // [T] first non-positive pivot (1-based) or 0
     int32_t* cnt;           // [T] arrival counters of the fused block step (large_fused.h); null on the three-launch path
-    const float* D2;        // non-null (fused path, inner side): block step 0 takes the matrix from HERE - M = s kappa(D2 / l^2) + noise I at the
-    int kind;               // trial point fit[t].xe, generated while the operands are staged - instead of from M (no k_lg_build launch)
     int T; bool vec;
     __device__ __forceinline__ bool active(int t) const { return !fit || fit[t].phase != PH_DONE; }
     __device__ __forceinline__ int n(int t) const { return n_arr ? n_arr[t] : ld; }
-    __device__ __forceinline__ bool gen(int step) const { return D2 != nullptr && step == 0; }
-};
-
-// (noise, outputscale, 1 / l^2) at the trial point of task t: k_lg_build's own expressions, so that generating the matrix on the fly
-// gives the bits the build kernel would have written
-struct LgKernelAt {
-    float noise, os, il2; int kind;
-    __device__ __forceinline__ void init(const LgMat& a, int t) {
-        const FitShared& fs = a.fit[t];
-        noise = softplus_f(fs.xe[0]) + NOISE_LB; os = softplus_f(fs.xe[1]);
-        const float ls = softplus_f(fs.xe[2]);
-        il2 = 1.f / (ls * ls); kind = a.kind;
-    }
-    // No FMA contraction in here: hipcc contracts a * b + c depending on what surrounds the expression once it is inlined, and this
-    // one is inlined into five kernels (k_lg_build, k_lg_diag, the panel functor and the fused update - operand staging and epilogues)
-    // that must all produce the SAME matrix entry for the fused and the three-launch path to run the same fit bit for bit.
-    __device__ __forceinline__ float at(float d2, int i, int j) const {
-#pragma clang fp contract(off)
-        const float u = d2 * il2;
-        float k0;
-        if (kind == 0) k0 = expf(-0.5f * u);
-        else {
-            const float r = sqrtf(u);
-            const float p1 = SQRT5 * r, p2 = (5.f / 3.f) * u;
-            k0 = ((1.f + p1) + p2) * expf(-p1);
-        }
-        const float sk = os * k0;
-        return sk + (i == j ? noise : 0.f);
-    }
 };
 
 __global__ __launch_bounds__(512) void k_lg_diag(LgMat a, int step) {
@@ -89,20 +58,15 @@ __global__ __launch_bounds__(512) void k_lg_diag(LgMat a, int step) {
     // the diagonal block, identity-padded; M is exactly symmetric (ProbLgUpdate writes every tile together with its mirror image),
     // so the rows are read as they are: 8 sixteen-byte loads per lane instead of 32 conditional dword loads
     float m[RB][CB];
-    const bool gen = a.gen(step);
-    const float* blk = (gen ? a.D2 + (size_t)t * a.ld * a.ld : Mi) + (size_t)p0 * a.ld + p0;
+    const float* blk = Mi + (size_t)p0 * a.ld + p0;
     const bool vec = rows_aligned16(blk, a.ld);
-    LgKernelAt kf;
-    if (gen) kf.init(a, t);
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         const int i = SW::row(r);
         load_segment<CB>(blk + (size_t)i * a.ld, SW::col(0), nloc, i < nloc, vec, m[r]);
 #pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            if (gen && i < nloc && SW::col(c) < nloc) m[r][c] = kf.at(m[r][c], i, SW::col(c));
+        for (int c = 0; c < CB; ++c)
             if (i == SW::col(c) && i >= nloc) m[r][c] = 1.f;
-        }
     }
     __syncthreads();
     SW::run(m, nloc, sm);
@@ -136,46 +100,34 @@ __global__ __launch_bounds__(512) void k_lg_diag(LgMat a, int step) {
     }
 }
 
-template <bool GEN = false>   // GEN: block step 0 of the fused inner path - the pivot rows come out of the squared distances (LgMat::D2)
-struct ProbLgPanelT {
+struct ProbLgPanel {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = false;
     static constexpr int NRED = 0;
     LgMat m; int step;
     int n, p0, nloc; const float *Dv, *Mi; float *Cb, *Fb; bool vec;
-    LgKernelAt kf;
     __device__ bool setup(int t) {
         if (!m.active(t)) return false;
         n = m.n(t); p0 = step * LB; nloc = min(LB, n - p0); vec = m.vec;
         if (nloc <= 0) return false;
-        if (GEN) kf.init(m, t);
-        Dv = m.Dinv + (size_t)t * LB * LB; Mi = (GEN ? const_cast<float*>(m.D2) : m.M) + (size_t)t * m.ld * m.ld;
+        Dv = m.Dinv + (size_t)t * LB * LB; Mi = m.M + (size_t)t * m.ld * m.ld;
         Cb = m.Cbuf + (size_t)t * LB * m.ld; Fb = m.Fbuf + (size_t)t * LB * m.ld;
         return true;
     }
-    __device__ __forceinline__ float val(float raw, int i, int j) const { return GEN ? kf.at(raw, i, j) : raw; }   // (i, j) = global row / column
     __device__ int M() const { return nloc; } __device__ int N() const { return n; } __device__ int K() const { return nloc; }
     __device__ bool skip(int, int n0) const { return n0 >= p0 && n0 < p0 + LB; }  // F_P is never read
     __device__ float a(int i, int k) const { return Dv[i * LB + k]; }
-    __device__ float b(int k, int j) const { return val(Mi[(size_t)(p0 + k) * m.ld + j], p0 + k, j); }
+    __device__ float b(int k, int j) const { return Mi[(size_t)(p0 + k) * m.ld + j]; }
     __device__ void a4(int i, int k, float (&v)[4]) const { ld4(Dv + i * LB + k, v); }
-    __device__ void b4(int k, int j, float (&v)[4]) const {
-        ld4(Mi + (size_t)(p0 + k) * m.ld + j, v);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) v[x] = val(v[x], p0 + k, j + x);
-    }
+    __device__ void b4(int k, int j, float (&v)[4]) const { ld4(Mi + (size_t)(p0 + k) * m.ld + j, v); }
     static constexpr int A_NRAW = 1, B_NRAW = 1;   // two-phase operand path of gemm.h
     __device__ bool raw_ok() const { return true; }
     __device__ void a_raw(int i, int k, float4 (&r)[1]) const { r[0] = ldq(Dv + i * LB + k); }
     __device__ void a_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
     __device__ void b_raw(int k, int j, float4 (&r)[1]) const { r[0] = ldq(Mi + (size_t)(p0 + k) * m.ld + j); }
-    __device__ void b_fin(int k, int j, const float4 (&r)[1], float (&v)[4]) const {
-        unq(r[0], v);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) v[x] = val(v[x], p0 + k, j + x);
-    }
+    __device__ void b_fin(int, int, const float4 (&r)[1], float (&v)[4]) const { unq(r[0], v); }
     __device__ void epi(int i, int j, float acc, float*) const {
         Fb[(size_t)i * m.ld + j] = acc;
-        Cb[(size_t)i * m.ld + j] = val(Mi[(size_t)(p0 + i) * m.ld + j], p0 + i, j);
+        Cb[(size_t)i * m.ld + j] = Mi[(size_t)(p0 + i) * m.ld + j];
     }
     // full block steps (K = 128 = DEEP chunks): all operand loads and the snapshot's source in flight before the first MFMA (gemm.h)
     static constexpr int DEEP = LB / GK;
@@ -189,12 +141,10 @@ struct ProbLgPanelT {
     }
     __device__ void epi4p(int i0, int j, const float (&acc)[4], const float (&pre)[4], float*) const {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { Fb[(size_t)(i0 + r) * m.ld + j] = acc[r]; Cb[(size_t)(i0 + r) * m.ld + j] = val(pre[r], p0 + i0 + r, j); }
+        for (int r = 0; r < 4; ++r) { Fb[(size_t)(i0 + r) * m.ld + j] = acc[r]; Cb[(size_t)(i0 + r) * m.ld + j] = pre[r]; }
     }
     __device__ void store_red(int, const float*) const {}
 };
-
-using ProbLgPanel = ProbLgPanelT<false>;
 
 struct ProbLgUpdate {
     static constexpr bool A_KCONTIG = false, B_KCONTIG = false;
@@ -311,11 +261,8 @@ struct LgInner {
     FitShared* fit;     // [T]
     float* part;        // [T, ntiles, 4] partial reductions of k_lg_traces
     int ntiles, tiles_1d;
-    int32_t* cnt_tr;    // non-null (round 5): [T] arrivals of the trace tiles - the workgroup whose tile is the last one of its task runs the
-                        // advance step itself (no k_lg_advance launch), and M keeps its sign until the final evaluation
 };
 
-template <int NT> __device__ __forceinline__ void lg_advance_task(const LgInner& a, int t, int tid, float* red);
 
 __global__ void k_lg_begin(LgInner a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,7 +273,6 @@ __global__ void k_lg_begin(LgInner a) {
     fs.st.f = INFINITY;
     fs.phase = (a.in.max_evals > 0) ? PH_INIT : PH_FINAL;
     fs.evals = 0;
-    if (a.cnt_tr) a.cnt_tr[t] = 0;
 }
 
 // M = s kappa(D2 / l^2) + noise I at the trial point of the task's state machine (64 x 64 tile per workgroup)
@@ -337,8 +283,9 @@ __global__ __launch_bounds__(256) void k_lg_build(LgInner a) {
     const int n = a.mat.n(t), ld = a.in.ld;
     const int m0 = (tile / a.tiles_1d) * GT, n0 = (tile % a.tiles_1d) * GT;
     if (m0 >= n || n0 >= n) return;
-    LgKernelAt kf;
-    { LgMat km = a.mat; km.fit = a.fit; km.kind = a.in.kind; kf.init(km, t); }
+    const FitShared& fs = a.fit[t];
+    const float noise = softplus_f(fs.xe[0]) + NOISE_LB, os = softplus_f(fs.xe[1]), ls = softplus_f(fs.xe[2]);
+    const float il2 = 1.f / (ls * ls);
     const float* D2 = a.in.D2ss + (size_t)t * ld * ld;
     float* Mi = a.mat.M + (size_t)t * ld * ld;
     // sixteen elements per thread: all their loads first, to clamped addresses (no branch around a load: kernels.h), then the
@@ -351,7 +298,7 @@ __global__ __launch_bounds__(256) void k_lg_build(LgInner a) {
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int i = m0 + (threadIdx.x >> 6) + 4 * q;
-        if (i < n && j < n) Mi[(size_t)i * ld + j] = kf.at(d2v[q], i, j);
+        if (i < n && j < n) Mi[(size_t)i * ld + j] = os * kappa0(a.in.kind, d2v[q] * il2) + (i == j ? noise : 0.f);
     }
 }
 
@@ -359,12 +306,12 @@ __global__ __launch_bounds__(256) void k_lg_build(LgInner a) {
 __global__ __launch_bounds__(256) void k_lg_traces(LgInner a) {
     __shared__ float red[3 * 4];
     __shared__ float redmax[4];
-    __shared__ int s_last;
     int t, tile;
     if (!task_tile(a.in.T, a.ntiles, t, tile)) return;
     if (!a.mat.active(t)) return;
     // (round 5) only the FINAL evaluation has to leave +A^-1 behind: a search evaluation's matrix is overwritten by the next one
-    const bool flip = !a.cnt_tr || a.fit[t].phase == PH_FINAL;
+    // (k_lg_advance, the next launch, is what moves the phase on: every tile of this launch reads the same value)
+    const bool flip = a.fit[t].phase == PH_FINAL;
     const int n = a.mat.n(t), ld = a.in.ld;
     const int m0 = (tile / a.tiles_1d) * GT, n0 = (tile % a.tiles_1d) * GT;
     float acc[3] = {0.f, 0.f, 0.f};
@@ -407,35 +354,16 @@ __global__ __launch_bounds__(256) void k_lg_traces(LgInner a) {
     __syncthreads();
     if (threadIdx.x == 0) {
         float* p = a.part + ((size_t)t * a.ntiles + tile) * 4;
-        const float dm = fmaxf(fmaxf(redmax[0], redmax[1]), fmaxf(redmax[2], redmax[3]));
-        if (!a.cnt_tr) { p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2]; p[3] = dm; }
-        else {
-            // write-through partials, drained, then ONE agent-scope arrival; the last arriver acquires and reads everybody's
-            // (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores + vmcnt(0) + atomic; acquire; plain loads)
-            __hip_atomic_store(p + 0, acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p + 1, acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p + 2, acc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p + 3, dm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int before = __hip_atomic_fetch_add(a.cnt_tr + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = before + 1 == a.ntiles ? 1 : 0;
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                __hip_atomic_store(a.cnt_tr + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            s_last = last;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2];
+        p[3] = fmaxf(fmaxf(redmax[0], redmax[1]), fmaxf(redmax[2], redmax[3]));
     }
-    if (!a.cnt_tr) return;
-    __syncthreads();
-    __shared__ float adv_red[8 * 4];
-    if (s_last) lg_advance_task<256>(a, t, threadIdx.x, adv_red);   // (uniform over the workgroup: barriers inside)
 }
 
-// NT threads per task (one wave in k_lg_advance; the 256 threads of the last trace tile on the fused path, where a single wave
-// walking the partials and the vectors was a chain of twenty dependent trips to memory): finish the evaluation, then either advance
-// the optimiser or publish the final results.  The sums run over fixed index sets in a fixed order: deterministic.
+// NT threads per task (round 5: 256 instead of one wave walking the partials and the vectors - a chain of twenty dependent trips to
+// memory): finish the evaluation, then either advance the optimiser or publish the final results.  The sums run over fixed index
+// sets in a fixed order: deterministic.  (Measured and dropped in round 5: the last trace tile of a task running this step itself
+// through an arrival counter - 41 us for the fused launch against 22 + 9 for the two; and block step 0 generating the matrix from
+// the squared distances instead of k_lg_build - the exponentials cost the three kernels of that step what the build launch costs.)
 template <int NT>
 __device__ __forceinline__ void lg_advance_task(const LgInner& a, int t, int tid, float* red) {
     FitShared& fs = a.fit[t];
@@ -496,7 +424,6 @@ __device__ __forceinline__ void lg_advance_task(const LgInner& a, int t, int tid
     fs.phase = PH_DONE;
 }
 
-// (256 threads like the last trace tile of the fused path: the same summation order, so both paths run the same fit bit for bit)
 __global__ __launch_bounds__(256) void k_lg_advance(LgInner a) {
     __shared__ float adv_red[8 * 4];
     if ((int)blockIdx.x >= a.in.T) return;

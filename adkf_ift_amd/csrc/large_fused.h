@@ -59,7 +59,6 @@ __device__ __forceinline__ void lgf_tri_tile(int tn, int v, int& ti, int& tj) {
 // workgroups per task: three for the tiles of the next diagonal block (one each), the other tiles in pairs
 inline __host__ __device__ int lgf_npair(int tn) { return 3 + (tn * (tn + 1) / 2 + 1) / 2; }
 
-template <bool GEN>   // GEN: block step 0 of the inner side (the matrix comes out of the squared distances)
 __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStepArgs a) {
     using SW = Sweep<128, 512>;
     constexpr int RB = SW::RB, CB = SW::CB;
@@ -80,13 +79,6 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
     const float* Cb = a.m.Cbuf + (size_t)t * LB * ld;
     const float* Fb = a.m.Fbuf + (size_t)t * LB * ld;
     const int tn = a.tn, ntri = tn * (tn + 1) / 2;
-    // block step 0 of the inner side: the matrix entries a computed tile is subtracted from come out of the squared distances
-    // (LgMat::D2 - there was no k_lg_build launch), with k_lg_build's expressions
-    constexpr bool gen = GEN;
-    const float* Msrc = gen ? a.m.D2 + (size_t)t * ld * ld : Mi;
-    LgKernelAt kf;
-    if (gen) kf.init(a.m, t);
-
     // ---- which tile: the (up to three) tiles of the next diagonal block first, then the upper triangle in row-major order ----
     const int d0 = 2 * (a.step + 1), d1 = d0 + 1;
     const int nd = (a.look && d0 < tn) ? (d1 < tn ? 3 : 1) : 0;
@@ -174,7 +166,7 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pre[i][j][r] = Msrc[(size_t)(m0 + wr * 32 + i * 16 + fk * 4 + r) * ld + n0 + wc * 32 + j * 16 + fi];
+                for (int r = 0; r < 4; ++r) pre[i][j][r] = Mi[(size_t)(m0 + wr * 32 + i * 16 + fk * 4 + r) * ld + n0 + wc * 32 + j * 16 + fi];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -229,7 +221,7 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
             float* dst = Mi + (size_t)i * ld + j;
             const bool pi = in_p(i), pj = in_p(j);
             float v;
-            if (!pi && !pj) v = (gen ? kf.at(Msrc[(size_t)i * ld + j], i, j) : *dst) - ac;
+            if (!pi && !pj) v = *dst - ac;
             else if (pi && pj) v = -Dv[(i - p0) * LB + (j - p0)];
             else if (pi) v = Fb[(size_t)(i - p0) * ld + j];
             else v = Fb[(size_t)(j - p0) * ld + i];
@@ -244,10 +236,7 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
                 if (mode == 1) {
                     float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = (gen ? kf.at(pre[i][j][r], gi0 + r, gj) : pre[i][j][r]) - acc[i][j][r];
-                        put(Mi + (size_t)(gi0 + r) * ld + gj, v[r]);
-                    }
+                    for (int r = 0; r < 4; ++r) { v[r] = pre[i][j][r] - acc[i][j][r]; put(Mi + (size_t)(gi0 + r) * ld + gj, v[r]); }
                     if (ti < tj) {
                         float* mp = Mi + (size_t)gj * ld + gi0;
                         if (next_diag && !(ADKF_LGF_EXP & 1)) { st_sc1(mp, v[0]); st_sc1(mp + 1, v[1]); st_sc1(mp + 2, v[2]); st_sc1(mp + 3, v[3]); }
@@ -260,7 +249,7 @@ __global__ __launch_bounds__(LGF_NT, ADKF_LGF_WPS) void k_lg_update_sweep(LgStep
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float* dst = Mi + (size_t)(gi0 + r) * ld + gj;
-                        if (!pi && !pj) v[r] = (gen ? kf.at(Msrc[(size_t)(gi0 + r) * ld + gj], gi0 + r, gj) : *dst) - acc[i][j][r];
+                        if (!pi && !pj) v[r] = *dst - acc[i][j][r];
                         else if (pi && pj) v[r] = -Dv[(gi0 + r - p0) * LB + (gj - p0)];
                         else if (pi) v[r] = Fb[(size_t)(gi0 + r - p0) * ld + gj];
                         else v[r] = Fb[(size_t)(gj - p0) * ld + gi0 + r];

@@ -226,8 +226,7 @@ def test_blocked_path_against_live_oracle(dev, N, Nq, d, kernel):
 def test_fused_block_step_equals_three_launches(dev, N, Nq, d, kernel):
     """csrc/large_fused.h (the update of block step k and the diagonal sweep of block step k + 1 in one launch, the next diagonal
     block handed from the tile workgroups to the sweeping one through write-through stores, an agent-scope arrival counter and one
-    acquire; the matrix of block step 0 generated from the squared distances instead of by k_lg_build; the advance step run by the
-    last trace tile; batch flag ADKF_BATCH_LG_FUSED) against the three launches per block step of csrc/large.h (ADKF_BATCH_LG_UNFUSED): the same arithmetic in
+    acquire; batch flag ADKF_BATCH_LG_FUSED) against the three launches per block step of csrc/large.h (ADKF_BATCH_LG_UNFUSED): the same arithmetic in
     the same order, so EVERY output of the fit and of the hypergradient stage must be equal bit for bit - a stale read of the
     handed-over block would show up as a difference.  Ragged sizes, block counts from 2 to 8, sizes that are not a multiple of the
     64-point tiles; run three times (a visibility bug comes and goes)."""

@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
     hipMemcpy(M, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMemset(logdet, 0, T * 4); hipMemset(info, 0, T * 4);
     m.M = M; m.ld = n; m.n_arr = nullptr; m.fit = nullptr; m.Dinv = Dinv; m.Cbuf = C; m.Fbuf = F; m.logdet = logdet; m.pext = pext; m.info = info;
-    m.cnt = nullptr; m.D2 = nullptr; m.kind = 0; m.T = T; m.vec = true;
+    m.cnt = nullptr; m.T = T; m.vec = true;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     ProbLgPanel pp; pp.m = m; pp.step = step;

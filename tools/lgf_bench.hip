@@ -39,7 +39,7 @@ static void sweepf(LgMat m, float* dinv2, hipStream_t st) {
         ProbLgPanel pp; pp.m = m; pp.step = step;
         k_bgemm<ProbLgPanel><<<grid_for(m.T, 2 * tn), 256, 0, st>>>(pp, m.T, 2, tn);
         LgStepArgs sa{m, buf[(step + 1) & 1], m.cnt, step, tn, npair, step + 1 < nb ? 1 : 0, g_stagger, g_prio};
-        k_lg_update_sweep<false><<<grid_for(m.T, npair), LGF_NT, g_dyn, st>>>(sa);
+        k_lg_update_sweep<<<grid_for(m.T, npair), LGF_NT, g_dyn, st>>>(sa);
     }
 }
 
@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
     g_stagger = argc > 5 ? atoi(argv[5]) : 0;
     g_prio = argc > 6 ? atoi(argv[6]) : 0;
     printf("dynamic LDS %d, stagger %d, sweep priority %d\n", g_dyn, g_stagger, g_prio);
-    if (g_dyn > 0 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lg_update_sweep<false>), hipFuncAttributeMaxDynamicSharedMemorySize, g_dyn) != hipSuccess) { printf("no LDS opt-in\n"); return 2; }
+    if (g_dyn > 0 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lg_update_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, g_dyn) != hipSuccess) { printf("no LDS opt-in\n"); return 2; }
     std::vector<float> h((size_t)T * ld * ld, 0.f);
     std::vector<int32_t> narr(T);
     unsigned s = 12345u;
@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
     hipMemset(b.cnt, 0xff, T * 4);   // garbage: the sweep's first launch has to zero it
     LgMat m;
     m.M = b.M; m.ld = ld; m.n_arr = ragged ? b.narr : nullptr; m.fit = nullptr; m.Dinv = b.Dinv; m.Cbuf = b.C; m.Fbuf = b.F;
-    m.logdet = b.logdet; m.pext = b.pext; m.info = b.info; m.cnt = b.cnt; m.D2 = nullptr; m.kind = 0; m.T = T; m.vec = (ld & 3) == 0;
+    m.logdet = b.logdet; m.pext = b.pext; m.info = b.info; m.cnt = b.cnt; m.T = T; m.vec = (ld & 3) == 0;
     std::vector<float> r3(h.size()), rf(h.size());
     std::vector<float> l3(T), lf(T), p3(2 * T), pf(2 * T);
     std::vector<int32_t> i3(T), if_(T);
@@ -127,7 +127,7 @@ int main(int argc, char** argv) {
                     if (which == 0) k_lg_diag<<<grid_for(T, 1), 512>>>(m, step);
                     if (which == 1) k_bgemm<ProbLgPanel><<<grid_for(T, 2 * tn), 256>>>(pp, T, 2, tn);
                     if (which == 2) k_bgemm<ProbLgUpdate><<<grid_for(T, pu.tri), 256>>>(pu, T, tn, tn);
-                    if (which >= 3) { LgStepArgs sa{m, dinv2, m.cnt, step, tn, npair, which == 3 ? 1 : 0, g_stagger, g_prio}; k_lg_update_sweep<false><<<grid_for(T, npair), LGF_NT, g_dyn>>>(sa); }
+                    if (which >= 3) { LgStepArgs sa{m, dinv2, m.cnt, step, tn, npair, which == 3 ? 1 : 0, g_stagger, g_prio}; k_lg_update_sweep<<<grid_for(T, npair), LGF_NT, g_dyn>>>(sa); }
                 }
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
