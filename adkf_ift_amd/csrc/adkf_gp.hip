@@ -590,7 +590,7 @@ struct ArdWs {
     float *mu, *ell, *Zt_s, *Zt_q, *G, *Gd_s, *Gd_q, *Gdot, *phi3, *pri3, *f3, *g3, *g3o, *S1, *gt, *coldot;
     float *c, *ut2, *wn, *Ddot, *Wdot, *adot, *S2;
     ArdFitState* fst; float *x, *g, *p, *xe, *ge, *S, *Y, *fe; int32_t* info3;
-    ArdCgState* cst; float *cx, *cr, *cp, *cHp, *gout; int32_t* n_eff;
+    ArdCgState* cst; float *cx, *cr, *cp, *cHp, *cz, *gout; int32_t* n_eff;
     size_t bytes;
 };
 
@@ -611,7 +611,7 @@ ArdWs carve_ard(void* base, size_t off0, int T, int ns, int nq, int d) {
     a.S = take(Tz * ARD_M * h); a.Y = take(Tz * ARD_M * h); a.fe = take(Tz);
     a.info3 = reinterpret_cast<int32_t*>(take(Tz));
     a.cst = reinterpret_cast<ArdCgState*>(take(Tz * ((sizeof(ArdCgState) + 3) / 4)));
-    a.cx = take(Tz * h); a.cr = take(Tz * h); a.cp = take(Tz * h); a.cHp = take(Tz * h); a.gout = take(Tz * h);
+    a.cx = take(Tz * h); a.cr = take(Tz * h); a.cp = take(Tz * h); a.cHp = take(Tz * h); a.cz = take(Tz * h); a.gout = take(Tz * h);
     a.n_eff = reinterpret_cast<int32_t*>(take(Tz));
     a.bytes = off;
     return a;
@@ -807,7 +807,12 @@ int ard_ift(const adkf_batch_t* b, const float* phi, int flags, bool with_hessia
     if (g_phi_out) hipMemcpyAsync(g_phi_out, c.a.gout, hb, hipMemcpyDeviceToDevice, st);
     const bool correct = with_hessian && !(flags & ADKF_IGNORE_GRAD_CORRECTION);
     if (correct) {
-        ArdCg cg{c.T, c.h, cg_tol, c.a.cst, c.a.gout, c.a.cx, c.a.cr, c.a.cp, c.a.cHp, b->n_s, c.ns, c.a.n_eff};
+        // preconditioner: the L-BFGS history of the fit that has just run on this workspace (REUSE_INNER); ADKF_ARD_PRECOND=0 (read
+        // once, A/B measurements) keeps plain CG
+        static const bool precond_on = [] { const char* e = getenv("ADKF_ARD_PRECOND"); return !e || atoi(e) != 0; }();
+        const bool pc = precond_on && (b->flags & ADKF_BATCH_REUSE_INNER) != 0;
+        ArdCg cg{c.T, c.h, cg_tol, c.a.cst, c.a.gout, c.a.cx, c.a.cr, c.a.cp, c.a.cHp, b->n_s, c.ns, c.a.n_eff,
+                 c.a.cz, pc ? c.a.fst : nullptr, c.a.S, c.a.Y};
         k_ard_cg_begin<<<c.T, 256, 0, st>>>(cg);
         FitPoll poll(true, cg_maxiter, c.a.info3, st);   // info3 was merged into info above; free as a counter now
         for (int it = 0; it < cg_maxiter; ++it) {

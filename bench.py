@@ -312,6 +312,19 @@ def main():
                   "fit_max_grad": float(gn.max().item()), "fit_mean_evals": float(nev.float().mean().item())}
         if not args.ard:
             parity["float64_path_fraction"] = float(gp_ops.double_path_tasks(b).float().mean().item())
+        else:
+            # conjugate-gradient rounds of H v = grad_phi f_out: plain (the call above: no fit state promised) against preconditioned with
+            # the L-BFGS history the fit left in this workspace (REUSE_INNER: what the meta-step's call carries), and how far the two
+            # solutions are apart
+            it0 = out["cg_iters"].float()
+            b.flags = gp_ops.REUSE_INNER
+            out_pc = gp_ops.ift_hypergrad(b, phi_f)
+            b.flags = 0
+            it1 = out_pc["cg_iters"].float()
+            parity["cg_rounds_plain"] = {"mean": float(it0.mean().item()), "max": float(it0.max().item())}
+            parity["cg_rounds_preconditioned"] = {"mean": float(it1.mean().item()), "max": float(it1.max().item())}
+            parity["v_rel_diff_plain_vs_preconditioned"] = float(((out_pc["v"] - out["v"]).norm(dim=1) / out["v"].norm(dim=1)).max().item())
+            parity["dZ_rel_diff_plain_vs_preconditioned"] = float((out_pc["dZ_s"] - out["dZ_s"]).abs().max().item() / out["dZ_s"].abs().max().item())
         if converged is not None:
             _, _, gn_c, nev_c, _ = gp_ops.fit(b, phi0, 200, exact_evals=False)
             converged["mean_evals"] = float(nev_c.float().mean().item())
