@@ -390,7 +390,7 @@ bool refine64_lds_optin() {
     return ok;
 }
 
-// ADKF_R64_STOP (read once; diagnostics, tools/r64_phases.sh): the float64 path leaves after that phase - results are then garbage
+// ADKF_R64_STOP (read once; diagnostics, tools/history/r64_phases.sh): the float64 path leaves after that phase - results are then garbage
 int r64_stop() {
     static const int stop = [] {
         const char* e = getenv("ADKF_R64_STOP");

@@ -20,7 +20,7 @@
 // Rows/cols >= n are padded with the identity; sweeping them is a no-op that leaves -1 on the diagonal.
 //
 // Scheduling.  The chain  update(next pivot rows) -> D^-1 -> F -> LDS  is the critical path (every block step
-// waits for it; measured ~0.4 us against ~0.23 us of bulk FMAs per step, tools/chain_bench.hip), so:
+// waits for it; measured ~0.4 us against ~0.23 us of bulk FMAs per step, tools/history/chain_bench.hip), so:
 //   * a thread's RB rows are G = RB/CB groups of B rows that lie NMAX/G apart, and consecutive logical block
 //     rows live in DIFFERENT waves: the ownership of the chain rotates over the waves from step to step;
 //   * (measured and rejected: sending the NEXT diagonal block from its holder before step q's update and letting every
@@ -34,7 +34,7 @@
 #pragma once
 #include <limits.h>
 #ifndef ADKF_STAMP
-#define ADKF_STAMP 0  // diagnostic build only (tools/sweep_bench.hip): s_memtime stamps of one block step into sm.stamp[]
+#define ADKF_STAMP 0  // diagnostic build only (tools/history/sweep_bench.hip): s_memtime stamps of one block step into sm.stamp[]
 #endif
 #if ADKF_STAMP
 #define ADKF_TS(slot) do { if (q_stamp == ADKF_STAMP && (threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); sm.stamp[(threadIdx.x >> 6) * 16 + (slot)] = t_; } } while (0)
@@ -42,7 +42,7 @@
 #define ADKF_TS(slot) do {} while (0)
 #endif
 #ifndef ADKF_ABLATE
-#define ADKF_ABLATE 0  // timing-only ablation switches for tools/sweep_bench.hip (1: no inverse, 2: no readlane, 4: no F, 8: no deferral)
+#define ADKF_ABLATE 0  // timing-only ablation switches for tools/history/sweep_bench.hip (1: no inverse, 2: no readlane, 4: no F, 8: no deferral)
 #endif
 
 #include "device_utils.h"
@@ -251,7 +251,7 @@ struct SweepBlk {
             for (int a = 0; a < B; ++a) apply_pivot<R0, R1>(m, slot, a, sm);
         }
     }
-    // (for the ablation harness tools/sweep_bench.hip)
+    // (for the ablation harness tools/history/sweep_bench.hip)
     __device__ static __forceinline__ void step(float (&m)[RB][CB], int q, Smem& sm) {
         apply_step<0, RB>(m, q % 3, sm);
     }

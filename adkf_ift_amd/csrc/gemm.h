@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
         }
     }
 #ifndef ADKF_GEMM_NO_RAW
-    if (deep) {} else   // diagnostics: -DADKF_GEMM_NO_RAW sends every tile through the checked path (tools/ab_lib.py)
+    if (deep) {} else   // diagnostics: -DADKF_GEMM_NO_RAW sends every tile through the checked path (tools/history/ab_lib.py)
     if constexpr (has_raw<P>::value) {
         fast = p.vec && m0 + TM <= M && n0 + TM <= N && K > 0 && (K % GK) == 0 && p.raw_ok();
         if (fast) {

@@ -9,7 +9,7 @@
 #include "factor.h"
 
 #ifndef ADKF_EVAL_STAMP
-#define ADKF_EVAL_STAMP 0   // diagnostic build only (tools/eval_phases.py): s_memtime at the phase boundaries of one evaluation
+#define ADKF_EVAL_STAMP 0   // diagnostic build only (tools/history/eval_phases.py): s_memtime at the phase boundaries of one evaluation
 #endif
 #if ADKF_EVAL_STAMP
 extern "C" __device__ unsigned long long adkf_eval_stamps[16];

@@ -102,7 +102,7 @@ struct ProbC {
 // turns into an absolute error on its small eigenvalues (seen: 2e-4 .. 6e-4 on dL/dZ for clustered low-dimensional features
 // at noise 0.1, cond 150 .. 800).  One refinement step in working precision makes the solve backward stable (Skeel): C is
 // then the exact solution for a slightly perturbed A and the Schur complement keeps its structure - what the reference's
-// Cholesky solves give (tools/emulate_precision.py: configuration refC32+sweep has no failure below cond 1300; above, tasks
+// Cholesky solves give (tools/history/emulate_precision.py: configuration refC32+sweep has no failure below cond 1300; above, tasks
 // take the float64 path of refine64.h).  Tasks whose (s + noise) max_i (A^-1)_ii stays below `thresh` skip both products
 // (every benchmark configuration: 1.5 at C2).
 struct ProbCres {

@@ -5,7 +5,7 @@
 // of dimension >= 64: pivot ratios below 10), wrong by 1e-3 .. 1e-2 on dL/dZ, grad_phi f_out and v for regression tasks
 // with noise ~0.01 on clustered low-dimensional features (cond 1e3 .. 5e3), where the reference - GPyTorch: Cholesky +
 // triangular solves, fs_mol/models/adaptive_dkt.py:183-191 - stays at 1e-5 .. 1e-4.  A CPU emulation of the precision
-// choices (tools/emulate_precision.py, 180 random tasks) shows what it takes to reach 1e-4 everywhere: A^-1, alpha, the
+// choices (tools/history/emulate_precision.py, 180 random tasks) shows what it takes to reach 1e-4 everywhere: A^-1, alpha, the
 // Hessian traces, C = K_qs A^-1, Sigma_q, Sigma_q^-1 and e COMPUTED in float64 and only then rounded to float32 for the
 // cotangent algebra (an explicit inverse ROUNDED to float32 is accurate entry by entry, which is what the element-wise
 // products with kappa' need; the float32 arithmetic that produced it was the problem).  Mixed-precision refinement of
@@ -202,7 +202,7 @@ __device__ __forceinline__ void r64_mv_cols(int N, int K, FT ft, FX fx, FE fe, d
 // Squared distances of a flagged task in float64, straight from the float32 features.  The GEMM form of the float32 stage
 // (|x|^2 + |y|^2 - 2 x.y) carries eps32 |x|^2 into every entry: nothing for the benchmark shapes, but for clustered
 // low-dimensional features (the flagged tasks) it was the LAST float32 input of the float64 path and the whole remaining error
-// of it (tools/diag_stress.py: dL/dZ_s 1.9e-4 -> 1.7e-6 on the one stress task that stayed above 1e-4).  In float64 the same
+// of it (tools/history/diag_stress.py: dL/dZ_s 1.9e-4 -> 1.7e-6 on the one stress task that stayed above 1e-4).  In float64 the same
 // form carries eps64 |x|^2 - nothing - and runs on the matrix pipe (r64_mm); `same`: X == Y, the diagonal is exactly zero.
 // nx / ny: scratch for the squared row norms (nx + ny doubles).
 __device__ void r64_distances(const float* X, const float* Y, int nx, int ny, int d, double* out, int ldo, double* sx, double* sy, bool same, double* stage = nullptr) {
@@ -287,8 +287,8 @@ __device__ __forceinline__ void r64_sum_n(double (&v)[NV], double* red) {
 // 4 x 8 block of rows 4 ri .. 4 ri + 3 and columns 8 cj .. 8 cj + 7; per step the owners publish pivot row and pivot column to LDS (two
 // buffers in turn: one barrier per step), everybody reads its 8 row entries and its 4 column entries and makes 32 FMAs.  The in-LDS
 // version below ran every step as 32 dependent read-modify-writes per thread with per-element branches and index stepping - 4.6 us per
-// step, 600 us per inverse, 57 % of the float64 path (tools/r64_phases.sh).  A first register version with one row strip of 32 columns
-// per thread still took 1.55 us per step: every thread read 33 doubles per step, 128 KB through the CU's LDS port (tools/r64_inv_bench.hip);
+// step, 600 us per inverse, 57 % of the float64 path (tools/history/r64_phases.sh).  A first register version with one row strip of 32 columns
+// per thread still took 1.55 us per step: every thread read 33 doubles per step, 128 KB through the CU's LDS port (tools/history/r64_inv_bench.hip);
 // the 4 x 8 block reads 13.  The position of the pivot inside a thread's block must be a compile-time constant (a run-time register
 // index would put the block into scratch memory), hence the steps of a chunk of 32 pivots as a template pack.
 // `buf`: 640 doubles of LDS, 16-byte aligned (two row / column buffers and the pivots).
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(R64_NT) void k_refine64(Refine64Args a) { refine64_
 //
 // With A^-1, C, Sigma_q^-1 and e computed in float64 the remaining error of flagged tasks (cond 2e3 .. 5e3) sat in the float32
 // products and reductions downstream: Omega C, C^T (Omega C), (A^-1 B_v) A^-1 and the sums behind grad_phi f_out - 1.2x .. 2.3x the
-// tolerance on v and dL/dZ for 4 of 180 stress tasks, none when the emulation runs them in float64 (tools/emulate_precision.py,
+// tolerance on v and dL/dZ for 4 of 180 stress tasks, none when the emulation runs them in float64 (tools/history/emulate_precision.py,
 // configuration "all64w").  This kernel redoes exactly that algebra from the float64 matrices k_refine64 left in the workspace
 // region - W_ss (direct and mixed part), W_qs, W_qq, grad_phi f_out, v, w - and then dL/dZ itself, in the difference form
 //     dZs_i = sum_k 4 Wss_ik (z_i - z_k) + sum_q 2 Wqs_qi (z_i - zq_q),   dZq_i = sum_k 2 Wqs_ik (zq_i - z_k) + sum_q 4 Wqq_iq (zq_i - zq_q)
@@ -713,7 +713,7 @@ struct Cot64Args {
     double* w64; size_t w64_stride; float thresh; int T, with_hessian, flags; float dirscale, corrscale; float *g_phi_out, *v_out;
     float* H_out;   // [T, 9] or null: the float64 path's Hessian (k_refine64 leaves it in the scalars) for the caller
     int lds_stage;  // the launch carries R64_LDS_POINTS^2 doubles of dynamic LDS: the products stage their B operands there
-    int stop;       // diagnostics (ADKF_R64_STOP, tools/r64_phases.sh): leave after phase `stop` (0: run everything)
+    int stop;       // diagnostics (ADKF_R64_STOP, tools/history/r64_phases.sh): leave after phase `stop` (0: run everything)
 };
 
 __device__ __forceinline__ void cotangent64_task(const Cot64Args& a) {

@@ -1,5 +1,5 @@
 // Sweep<128, 512> in SIXTEEN-pivot block steps, everything on the matrix pipe.  EXPERIMENT, kept for A/B runs only
-// (-DADKF_SWEEP_M=2; tools/sweepm_bench.hip, tools/run_sweepm16.sh): correct for every n, but 43.0 k cycles per sweep against the
+// (-DADKF_SWEEP_M=2; tools/sweepm_bench.hip, tools/history/run_sweepm16.sh): correct for every n, but 43.0 k cycles per sweep against the
 // 37.0 k of factor_m.h, which stays the default.  Measured (round 3, cycles per block step of 16 pivots, s_memtime):
 //   * the chain alone, no bulk update at all: 3 400 (27.2 k per sweep) = barrier -> LDS reads -> -F (2 + 2 MFMAs) -> critical tile
 //     (2 + 2 MFMAs) -> piece stored ~1 000, then four in-wave sub-steps of ~630 (gj4 220, the turn of D^-1 and the pivot rows

@@ -21,7 +21,7 @@
 // with D - I at the pivot columns and M_PP := D - 2I, the owner of the next block postponing the rest of its update, raised
 // priority on the chain.
 //
-// What the ablations of tools/sweepw_bench.hip say about where a block step (1880 cycles) goes - the reason the layout
+// What the ablations of tools/history/sweepw_bench.hip say about where a block step (1880 cycles) goes - the reason the layout
 // alone bought only 3 %: removing the elimination, the bpermute AND the chain's row update together saves 2 %; the floor of
 // "publish -> s_waitcnt -> s_barrier -> wake up" with no arithmetic at all is 690 cycles; the chain's arithmetic adds 640;
 // the remaining 550 are the OTHER waves' bulk update (LDS reads + FMAs competing with the chain wave, 300) and the wave
@@ -29,7 +29,7 @@
 // per step, NSLOT = 6 slots keep the vectors alive), and the stamp sites double as scheduling fences.
 #pragma once
 #ifndef ADKF_W_ABLATE
-#define ADKF_W_ABLATE 0   // timing-only ablations for tools/sweepw_bench.hip (1: no elimination, 2: no bpermute, 4: no chain row update, 8: no postponed update, 16: no bulk update)
+#define ADKF_W_ABLATE 0   // timing-only ablations for tools/history/sweepw_bench.hip (1: no elimination, 2: no bpermute, 4: no chain row update, 8: no postponed update, 16: no bulk update)
 #endif
 
 namespace adkf {
@@ -51,11 +51,11 @@ template <> struct SweepSmem<128, 512> {
     __device__ __forceinline__ float* scratch() { return &cross[0][0][0]; }   // free for the caller between two sweeps
 };
 
-#if ADKF_STAMP   // diagnostic build (tools/sweepw_bench.hip -DADKF_STAMP=<step>): s_memtime of the phases of block step <step>, per wave
+#if ADKF_STAMP   // diagnostic build (tools/history/sweepw_bench.hip -DADKF_STAMP=<step>): s_memtime of the phases of block step <step>, per wave
 #define ADKF_WTS(slot_) do { if (s_stamp == ADKF_STAMP && (threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); sm.stamp[(threadIdx.x >> 6) * 16 + (slot_)] = t_; } } while (0)
 #elif !defined(ADKF_W_NO_SCHED)
 // the stamp sites double as scheduling fences in the product build: left free, hipcc hoists the bulk's LDS loads and sinks the
-// publishing stores across the phases of the chain (36.0 us per sweep against 28.1 with the fences, tools/sweepw_bench.hip)
+// publishing stores across the phases of the chain (36.0 us per sweep against 28.1 with the fences, tools/history/sweepw_bench.hip)
 #define ADKF_WTS(slot_) __builtin_amdgcn_sched_barrier(0)
 #else
 #define ADKF_WTS(slot_) do {} while (0)
