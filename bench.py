@@ -290,7 +290,28 @@ def main():
 
     # ---- parity of the metric's second half ("logML rel-err") on a few tasks, outside the timed region ----
     parity = None
-    if rank == 0 and not args.no_parity:
+    if rank == 0 and not args.no_parity and args.ard:
+        # ARD: the conjugate-gradient rounds of H v = grad_phi f_out, plain (no fit state promised to the call) against preconditioned
+        # with the L-BFGS history the fit left in this workspace (REUSE_INNER: what the meta-step's call carries), and how far the two
+        # solutions are apart.  (Value parity of the ARD path: tests/test_gpu_ard.py against the autograd fixtures.)
+        with torch.no_grad():
+            feats = features()
+            Zs, Zq = feats[0], feats[1]
+        pri = torch.empty(T, 4, device=dev)
+        b = gp_ops.GPBatch(Zs, y_s, pri, args.kernel, Z_q=Zq, y_q=y_q, ard=True)
+        phi0, _ = gp_ops.init_params_batch(b, args.regression, True)
+        phi_f, f_in, gn, nev, info = gp_ops.fit(b, phi0, cfg.inner_max_evals, exact_evals=cfg.inner_exact_evals)
+        out = gp_ops.ift_hypergrad(b, phi_f)
+        b.flags = gp_ops.REUSE_INNER
+        out_pc = gp_ops.ift_hypergrad(b, phi_f)
+        b.flags = 0
+        it0, it1 = out["cg_iters"].float(), out_pc["cg_iters"].float()
+        parity = {"fit_max_grad": float(gn.max().item()), "fit_mean_evals": float(nev.float().mean().item()),
+                  "cg_rounds_plain": {"mean": float(it0.mean().item()), "max": float(it0.max().item())},
+                  "cg_rounds_preconditioned": {"mean": float(it1.mean().item()), "max": float(it1.max().item())},
+                  "v_rel_diff_plain_vs_preconditioned": float(((out_pc["v"] - out["v"]).norm(dim=1) / out["v"].norm(dim=1)).max().item()),
+                  "dZ_rel_diff_plain_vs_preconditioned": float((out_pc["dZ_s"] - out["dZ_s"]).abs().max().item() / out["dZ_s"].abs().max().item())}
+    elif rank == 0 and not args.no_parity:
         from oracle import gp_oracle as O
         with torch.no_grad():
             feats = features()
@@ -310,21 +331,7 @@ def main():
             e_dz = max(e_dz, float((out["dZ_s"][t].double().cpu() - ref).abs().max() / ref.abs().max()))
         parity = {"logml_rel_err": e_in, "outer_nll_rel_err": e_out, "ift_dZ_rel_err": e_dz,
                   "fit_max_grad": float(gn.max().item()), "fit_mean_evals": float(nev.float().mean().item())}
-        if not args.ard:
-            parity["float64_path_fraction"] = float(gp_ops.double_path_tasks(b).float().mean().item())
-        else:
-            # conjugate-gradient rounds of H v = grad_phi f_out: plain (the call above: no fit state promised) against preconditioned with
-            # the L-BFGS history the fit left in this workspace (REUSE_INNER: what the meta-step's call carries), and how far the two
-            # solutions are apart
-            it0 = out["cg_iters"].float()
-            b.flags = gp_ops.REUSE_INNER
-            out_pc = gp_ops.ift_hypergrad(b, phi_f)
-            b.flags = 0
-            it1 = out_pc["cg_iters"].float()
-            parity["cg_rounds_plain"] = {"mean": float(it0.mean().item()), "max": float(it0.max().item())}
-            parity["cg_rounds_preconditioned"] = {"mean": float(it1.mean().item()), "max": float(it1.max().item())}
-            parity["v_rel_diff_plain_vs_preconditioned"] = float(((out_pc["v"] - out["v"]).norm(dim=1) / out["v"].norm(dim=1)).max().item())
-            parity["dZ_rel_diff_plain_vs_preconditioned"] = float((out_pc["dZ_s"] - out["dZ_s"]).abs().max().item() / out["dZ_s"].abs().max().item())
+        parity["float64_path_fraction"] = float(gp_ops.double_path_tasks(b).float().mean().item())
         if converged is not None:
             _, _, gn_c, nev_c, _ = gp_ops.fit(b, phi0, 200, exact_evals=False)
             converged["mean_evals"] = float(nev_c.float().mean().item())
