@@ -300,9 +300,11 @@ struct FitPoll {
         host = pinned;
         enabled = true;
     }
-    // true when every task has finished (call after the advance kernel of evaluation e)
-    bool finished(int e, const void* state, size_t stride, size_t phase_offset, int T, hipStream_t st, int done_value = PH_DONE) {
-        if (!enabled || (e + 1) % POLL_EVERY != 0) return false;
+    // true when every task has finished (call after the advance kernel of evaluation e).  every_after: once POLL_EVERY rounds are
+    // through, poll every that many (the CG loop: a round of empty launches costs more than a poll once most tasks have converged)
+    bool finished(int e, const void* state, size_t stride, size_t phase_offset, int T, hipStream_t st, int done_value = PH_DONE, int every_after = POLL_EVERY) {
+        if (!enabled) return false;
+        if (e + 1 < POLL_EVERY || (e + 1 - POLL_EVERY) % every_after != 0) return false;
         k_count_unfinished<<<1, 64, 0, st>>>(static_cast<const char*>(state), stride, phase_offset, T, done_value, dev);
         if (hipMemcpyAsync(host, dev, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
         if (hipStreamSynchronize(st) != hipSuccess) return false;
@@ -590,7 +592,7 @@ struct ArdWs {
     float *mu, *ell, *Zt_s, *Zt_q, *G, *Gd_s, *Gd_q, *Gdot, *phi3, *pri3, *f3, *g3, *g3o, *S1, *gt, *coldot;
     float *c, *ut2, *wn, *Ddot, *Wdot, *adot, *S2;
     ArdFitState* fst; float *x, *g, *p, *xe, *ge, *S, *Y, *fe; int32_t* info3;
-    ArdCgState* cst; float *cx, *cr, *cp, *cHp, *cz, *gout; int32_t* n_eff;
+    ArdCgState* cst; float *cx, *cr, *cp, *cHp, *gout; int32_t* n_eff;
     size_t bytes;
 };
 
@@ -611,7 +613,7 @@ ArdWs carve_ard(void* base, size_t off0, int T, int ns, int nq, int d) {
     a.S = take(Tz * ARD_M * h); a.Y = take(Tz * ARD_M * h); a.fe = take(Tz);
     a.info3 = reinterpret_cast<int32_t*>(take(Tz));
     a.cst = reinterpret_cast<ArdCgState*>(take(Tz * ((sizeof(ArdCgState) + 3) / 4)));
-    a.cx = take(Tz * h); a.cr = take(Tz * h); a.cp = take(Tz * h); a.cHp = take(Tz * h); a.cz = take(Tz * h); a.gout = take(Tz * h);
+    a.cx = take(Tz * h); a.cr = take(Tz * h); a.cp = take(Tz * h); a.cHp = take(Tz * h); a.gout = take(Tz * h);
     a.n_eff = reinterpret_cast<int32_t*>(take(Tz));
     a.bytes = off;
     return a;
@@ -807,18 +809,17 @@ int ard_ift(const adkf_batch_t* b, const float* phi, int flags, bool with_hessia
     if (g_phi_out) hipMemcpyAsync(g_phi_out, c.a.gout, hb, hipMemcpyDeviceToDevice, st);
     const bool correct = with_hessian && !(flags & ADKF_IGNORE_GRAD_CORRECTION);
     if (correct) {
-        // preconditioner: the L-BFGS history of the fit that has just run on this workspace (REUSE_INNER); ADKF_ARD_PRECOND=0 (read
-        // once, A/B measurements) keeps plain CG
-        static const bool precond_on = [] { const char* e = getenv("ADKF_ARD_PRECOND"); return !e || atoi(e) != 0; }();
-        const bool pc = precond_on && (b->flags & ADKF_BATCH_REUSE_INNER) != 0;
-        ArdCg cg{c.T, c.h, cg_tol, c.a.cst, c.a.gout, c.a.cx, c.a.cr, c.a.cp, c.a.cHp, b->n_s, c.ns, c.a.n_eff,
-                 c.a.cz, pc ? c.a.fst : nullptr, c.a.S, c.a.Y};
+        // (round 5, measured and dropped: CG preconditioned with the L-BFGS history the fit has just built at this point - two-loop
+        // recursion per round - needed MORE rounds than plain CG at the C2 shapes, h = 258: 10.1 on average, 17 at most, against 9.0 / 11
+        // (profiles/r05_bench_ard_pcg.json), and its step kernel took 19 us instead of 4.  Twenty evaluations of a 258-parameter fit do
+        // not leave a useful picture of the curvature; the lengthscale prior already keeps cond(H) near 1e3.)
+        ArdCg cg{c.T, c.h, cg_tol, c.a.cst, c.a.gout, c.a.cx, c.a.cr, c.a.cp, c.a.cHp, b->n_s, c.ns, c.a.n_eff};
         k_ard_cg_begin<<<c.T, 256, 0, st>>>(cg);
         FitPoll poll(true, cg_maxiter, c.a.info3, st);   // info3 was merged into info above; free as a counter now
         for (int it = 0; it < cg_maxiter; ++it) {
             ard_hvp(c, phi, c.a.cp, c.a.cHp, c.a.cst);
             k_ard_cg_step<<<c.T, 256, 0, st>>>(cg);
-            if (poll.finished(it, c.a.cst, sizeof(ArdCgState), offsetof(ArdCgState, done), c.T, st, 1)) break;
+            if (poll.finished(it, c.a.cst, sizeof(ArdCgState), offsetof(ArdCgState, done), c.T, st, 1, 2)) break;   // plain CG needs 9 rounds on average, 11 at most at the C2 shapes
         }
         k_ard_cg_info<<<ceil_div(c.T, 64), 64, 0, st>>>(c.a.cst, info, cg_iters, c.T);
         if (v_out) hipMemcpyAsync(v_out, c.a.cx, hb, hipMemcpyDeviceToDevice, st);

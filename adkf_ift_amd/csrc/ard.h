@@ -31,7 +31,7 @@ struct ArdFitState {
     float rho[ARD_M];
 };
 
-struct ArdCgState { float rs, b2, pHp; int done, iters, breakdown, pc; };   // pc: this task runs preconditioned (a usable L-BFGS history was found)
+struct ArdCgState { float rs, b2, pHp; int done, iters, breakdown; };
 
 struct ArdView {
     int T, d, h, ns_ld, nq_ld;
@@ -467,121 +467,47 @@ __global__ __launch_bounds__(256) void k_ard_hvp_fin(ArdHvp a) {
 }
 
 // ---- conjugate gradients (one workgroup per task) -------------------------------------------------------------------------
-// Round 5: PRECONDITIONED with the inverse-Hessian approximation the L-BFGS fit has just built at this very point (its last
-// <= ARD_M curvature pairs, two-loop recursion) when the fit's state is in the workspace (ADKF_BATCH_REUSE_INNER after adkf_fit) -
-// an SPD operator (pairs are only stored with s^T y > 0) that already knows the dominant curvature directions of H = d^2 f_in / d phi^2,
-// for the price of <= 20 dot products over h numbers per round.  Without a history (a hypergradient at a given phi, as the golden
-// fixtures ask for it) z = r and this is plain CG.  Stopping rule unchanged: |r|^2 <= tol^2 |b|^2.
 struct ArdCg { int T, h; float tol; ArdCgState* st; const float* b; float *x, *r, *p; const float* Hp;
-               const int32_t* n_s; int ns_ld; int32_t* n_eff;   // n_eff[t] = 0 once task t has converged: every kernel of the next HVP skips it
-               float* z; const ArdFitState* fst; const float *S, *Y; };   // fst = null: no preconditioner
-
-// z = H_lbfgs r (two-loop recursion over the fit's history; the same loops as k_ard_advance).  All 256 threads; barriers inside.
-__device__ __forceinline__ void ard_precond(const ArdCg& a, int t, const float* r, float* z, float* red, float* alpha_s) {
-    const int tid = threadIdx.x, h = a.h;
-    const int hist = (a.fst && a.st[t].pc) ? min(a.fst[t].hist, ARD_M) : 0;
-    for (int k = tid; k < h; k += 256) z[k] = r[k];
-    if (hist <= 0) { __syncthreads(); return; }
-    const ArdFitState& F = a.fst[t];
-    const int head = F.head;
-    const float *Sv = a.S + (size_t)t * ARD_M * h, *Yv = a.Y + (size_t)t * ARD_M * h;
-    __syncthreads();
-    for (int j = 0; j < hist; ++j) {
-        const int idx = (head - 1 - j + 2 * ARD_M) % ARD_M;
-        float s = 0.f;
-        for (int k = tid; k < h; k += 256) s += Sv[(size_t)idx * h + k] * z[k];
-        const float aj = F.rho[idx] * bsum256(s, red);
-        for (int k = tid; k < h; k += 256) z[k] -= aj * Yv[(size_t)idx * h + k];
-        if (tid == 0) alpha_s[j] = aj;
-    }
-    __syncthreads();
-    const float sc = F.gamma;
-    for (int k = tid; k < h; k += 256) z[k] *= sc;
-    for (int j = hist - 1; j >= 0; --j) {
-        const int idx = (head - 1 - j + 2 * ARD_M) % ARD_M;
-        float s = 0.f;
-        for (int k = tid; k < h; k += 256) s += Yv[(size_t)idx * h + k] * z[k];
-        const float bq = F.rho[idx] * bsum256(s, red);
-        const float cf = alpha_s[j] - bq;
-        for (int k = tid; k < h; k += 256) z[k] += cf * Sv[(size_t)idx * h + k];
-    }
-    __syncthreads();
-}
+               const int32_t* n_s; int ns_ld; int32_t* n_eff; };  // n_eff[t] = 0 once task t has converged: every kernel of the next HVP skips it
 
 __global__ __launch_bounds__(256) void k_ard_cg_begin(ArdCg a) {
     __shared__ float red[4];
-    __shared__ float alpha_s[ARD_M];
     const int t = blockIdx.x, tid = threadIdx.x, h = a.h;
-    float *r = a.r + (size_t)t * h, *p = a.p + (size_t)t * h, *z = a.z + (size_t)t * h;
     float s = 0.f;
     for (int k = tid; k < h; k += 256) {
         const float v = a.b[(size_t)t * h + k];
-        a.x[(size_t)t * h + k] = 0.f; r[k] = v;
+        a.x[(size_t)t * h + k] = 0.f; a.r[(size_t)t * h + k] = v; a.p[(size_t)t * h + k] = v;
         s += v * v;
     }
     s = bsum256(s, red);
-    // is there a usable history?  (the state may be what an EARLIER fit at another point left - still an SPD operator, fine - or
-    // memory no fit has ever written: every number is checked, and a preconditioned residual that is not a descent pairing
-    // (r^T z <= 0) sends the task back to plain CG)
     if (tid == 0) {
-        int ok = 0;
-        if (a.fst) {
-            const ArdFitState& F = a.fst[t];
-            ok = F.hist > 0 && F.hist <= ARD_M && F.head >= 0 && F.head < ARD_M && F.gamma > 0.f && F.gamma < INFINITY;
-            for (int j = 0; ok && j < F.hist; ++j) { const float rh = F.rho[(F.head - 1 - j + 2 * ARD_M) % ARD_M]; ok = rh > 0.f && rh < INFINITY; }
-        }
-        a.st[t].pc = ok;
-    }
-    __syncthreads();
-    ard_precond(a, t, r, z, red, alpha_s);
-    float rz = 0.f;
-    for (int k = tid; k < h; k += 256) rz += r[k] * z[k];
-    rz = bsum256(rz, red);
-    if (a.st[t].pc && !(rz > 0.f && rz < INFINITY)) {   // (uniform) unusable after all: plain CG
-        __syncthreads();
-        if (tid == 0) a.st[t].pc = 0;
-        for (int k = tid; k < h; k += 256) z[k] = r[k];
-        rz = s;
-        __syncthreads();
-    }
-    for (int k = tid; k < h; k += 256) p[k] = z[k];
-    if (tid == 0) {
-        ArdCgState& c = a.st[t]; c.rs = rz; c.b2 = s; c.pHp = 0.f; c.done = (s == 0.f) ? 1 : 0; c.iters = 0; c.breakdown = 0;
+        ArdCgState& c = a.st[t]; c.rs = s; c.b2 = s; c.pHp = 0.f; c.done = (s == 0.f) ? 1 : 0; c.iters = 0; c.breakdown = 0;
         a.n_eff[t] = c.done ? 0 : (a.n_s ? a.n_s[t] : a.ns_ld);
     }
 }
 
 __global__ __launch_bounds__(256) void k_ard_cg_step(ArdCg a) {
     __shared__ float red[4];
-    __shared__ float alpha_s[ARD_M];
     const int t = blockIdx.x, tid = threadIdx.x, h = a.h;
     ArdCgState& c = a.st[t];
     if (c.done) return;
-    float *x = a.x + (size_t)t * h, *r = a.r + (size_t)t * h, *p = a.p + (size_t)t * h, *z = a.z + (size_t)t * h;
+    float *x = a.x + (size_t)t * h, *r = a.r + (size_t)t * h, *p = a.p + (size_t)t * h;
     const float* Hp = a.Hp + (size_t)t * h;
     float pHp = 0.f;
     for (int k = tid; k < h; k += 256) pHp += p[k] * Hp[k];
     pHp = bsum256(pHp, red);
-    const float rz = c.rs;          // r^T z (= r^T r without a preconditioner)
+    const float rs = c.rs;
     if (!(pHp > 0.f)) {  // negative curvature or NaN: H is not positive definite along p - keep the current iterate
         if (tid == 0) { c.done = 1; c.breakdown = 1; a.n_eff[t] = 0; }
         return;
     }
-    const float al = rz / pHp;
+    const float al = rs / pHp;
     float rn = 0.f;
     for (int k = tid; k < h; k += 256) { x[k] += al * p[k]; const float v = r[k] - al * Hp[k]; r[k] = v; rn += v * v; }
     rn = bsum256(rn, red);
-    if (rn <= a.tol * a.tol * c.b2) {   // (uniform: rn and b2 are the same in every thread)
-        if (tid == 0) { c.pHp = pHp; c.iters += 1; c.done = 1; a.n_eff[t] = 0; }
-        return;
-    }
-    ard_precond(a, t, r, z, red, alpha_s);
-    float rzn = 0.f;
-    for (int k = tid; k < h; k += 256) rzn += r[k] * z[k];
-    rzn = bsum256(rzn, red);
-    const float beta = rzn / rz;
-    for (int k = tid; k < h; k += 256) p[k] = z[k] + beta * p[k];
-    if (tid == 0) { c.rs = rzn; c.pHp = pHp; c.iters += 1; }
+    const float beta = rn / rs;
+    for (int k = tid; k < h; k += 256) p[k] = r[k] + beta * p[k];
+    if (tid == 0) { c.rs = rn; c.pHp = pHp; c.iters += 1; if (rn <= a.tol * a.tol * c.b2) { c.done = 1; a.n_eff[t] = 0; } }
 }
 
 // ---- outer gradient in the h raw parameters, final feature gradients ------------------------------------------------------
