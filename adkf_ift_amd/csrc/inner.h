@@ -149,7 +149,15 @@ struct InnerEval {
     __device__ static __forceinline__ int run(SweepSmem<NMAX, NT>& sm, const D2& d2, float (&m)[RB][CB], int n,
                                               const float* x, const float* tr, const float* pri, float& f, float* g,
                                               float* extra, bool fast, float* cache) {
-        const int j0 = SW::bc() * CB, tid = threadIdx.x;
+        int j0 = SW::bc() * CB, i0 = SW::row(0);
+        const int tid = threadIdx.x;
+        if constexpr (LOW) {
+            // (two tasks per CU, <= 128 registers) row and column of this lane's block from copies the optimiser cannot see through:
+            // hoisted out of the fit's loop, the sixteen per-row values (row, row - column) of the unrolled passes below stayed alive
+            // across the whole fit and were what spilled
+            asm volatile("" : "+v"(j0), "+v"(i0));
+        }
+        auto row_of = [&](int r) { return LOW ? i0 + (r << 4) : SW::row(r); };
 #if ADKF_EVAL_STAMP
         const bool adkf_stamp_on = fast;   // the search evaluations (the final one uses libm expf)
 #endif
@@ -167,7 +175,7 @@ struct InnerEval {
             const float cm = -3.2259784787f;                                        // Matern: -sqrt(5) log2(e)
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                const int i = SW::row(r), dc = i - j0;   // the diagonal sits at column offset dc, if 0 <= dc < CB
+                const int i = row_of(r), dc = i - j0;   // the diagonal sits at column offset dc, if 0 <= dc < CB
 #pragma unroll
                 for (int c = 0; c < CB; ++c) {
                     if (c % 4 == 0) __builtin_amdgcn_sched_barrier(0);   // four exponentials in flight at a time: keeps the pressure of this loop out of the sweep's allocation
@@ -198,7 +206,7 @@ struct InnerEval {
 #pragma unroll
             for (int c = 0; c < CB; ++c) {
                 if (c % 4 == 0) __builtin_amdgcn_sched_barrier(0);   // four exponentials in flight at a time: keeps the pressure of this loop out of the sweep's allocation
-                const int i = SW::row(r), j = j0 + c;
+                const int i = row_of(r), j = j0 + c;
                 float k1u = 0.f;
                 if (i < n && j < n) {
                     const float u = d2.get(r, c) * il2;
@@ -223,7 +231,7 @@ struct InnerEval {
         float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float ai[RB], aj[CB];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) ai[r] = sm.vec_out[SW::row(r)];
+        for (int r = 0; r < RB; ++r) ai[r] = sm.vec_out[row_of(r)];
 #pragma unroll
         for (int c = 0; c < CB; ++c) aj[c] = sm.vec_out[j0 + c];
 #pragma unroll
@@ -236,7 +244,7 @@ struct InnerEval {
                 if (!LOW) k1u_ = cache[(r * CB + c) * NT + tid];
                 else {
                     const float d2v = d2.get(r, c);
-                    const bool in = SW::row(r) < n && j0 + c < n;
+                    const bool in = row_of(r) < n && j0 + c < n;
                     if (fast) {
                         // (the build's expressions, letter for letter: the two variants must run the same fit)
                         const float ce = -0.72134752044448170368f * il2, ck = -0.5f * il2, cm = -3.2259784787f;
@@ -259,7 +267,7 @@ struct InnerEval {
                 const float G = os * gl * k1u_;
                 acc[0] -= m[r][c] * G;
                 acc[1] += ai[r] * aj[c] * G;
-                if (SW::row(r) == j0 + c && SW::row(r) < n) acc[2] -= m[r][c];
+                if (row_of(r) == j0 + c && row_of(r) < n) acc[2] -= m[r][c];
             }
         if (tid < n) {
             const float a = sm.vec_out[tid];
@@ -534,18 +542,18 @@ __global__ __launch_bounds__(NT, LOW ? 4 : 1) void k_inner(InnerArgs a) {
     if (a.Ainv) {
         // the output addresses are formed HERE from opaque copies: hoisted to the kernel's head (they are loop-invariant) the
         // row offset was the one value (8 bytes) that spilled across the whole fit
-        int t_late = t, i_late = SW::row(0);
-        asm volatile("" : "+s"(t_late));
-        asm volatile("" : "+v"(i_late));
-        float* Ao = a.Ainv + (size_t)t_late * a.ld * a.ld;
-        const bool vec = rows_aligned16(Ao, a.ld);
+        int t_late = t, i_late = SW::row(0), ld_late = a.ld, j_late = j0;
+        asm volatile("" : "+s"(t_late), "+s"(ld_late));   // (the leading dimension too: the row offsets i * ld are the ones the loads of D^2 at the kernel's head use)
+        asm volatile("" : "+v"(i_late), "+v"(j_late));
+        float* Ao = a.Ainv + (size_t)t_late * ld_late * ld_late;
+        const bool vec = rows_aligned16(Ao, ld_late);
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int i = i_late + (SW::row(r) - SW::row(0));   // (a compile-time offset in every layout)
             float neg[CB];
 #pragma unroll
             for (int c = 0; c < CB; ++c) neg[c] = -m[r][c];
-            store_segment<CB>(Ao + (size_t)i * a.ld, j0, n, i < n, vec, neg);
+            store_segment<CB>(Ao + (size_t)i * ld_late, j_late, n, i < n, vec, neg);
         }
     }
 }
