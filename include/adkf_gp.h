@@ -21,8 +21,13 @@
  *     fs_mol/models/adaptive_dkt.py:94-100,112-119; a scale <= 0 disables that prior (DKLModel has no
  *     noise prior, fs_mol/models/dkl.py:86; use_lengthscale_prior=False);
  *   - every function is ASYNCHRONOUS on `stream` (a hipStream_t passed as void*), re-entrant across
- *     streams, holds no global mutable state and performs no allocation or synchronisation, so it may be
- *     captured into a hipGraph;
+ *     streams, and performs no allocation; no synchronisation either, with ONE documented exception: the
+ *     multi-launch fits (more than 128 points; ARD) poll a convergence counter every few evaluations in
+ *     convergence mode - never in exact-evals mode and never while the stream is being captured - so every
+ *     sequence may be captured into a hipGraph.  State kept across calls: a thread-local last-HIP-error
+ *     (adkf_last_hip_error), the outcome of the dynamic-LDS opt-ins (asked once per process; see
+ *     adkf_path_info) and read-once environment switches for experiments (ADKF_* in DESIGN.md section 1);
+ *     nothing a call leaves behind changes what a later call computes;
  *   - return value: 0 = enqueued, < 0 = rejected argument (ADKF_E_*).  Numerical failure is reported
  *     per task in the device array info[T]: 0 = ok, k > 0 = the k-th pivot of a Cholesky factorisation was
  *     not positive (the reference's NotPSDError after jitter retries; this library never adds jitter),
