@@ -419,6 +419,8 @@ def main():
         gp_side("c1", 64, 32, 64, 50, 10, f"C1: 64 tasks, N_support = N_query = 32, d = 64, exactly {I} evaluations (host-enqueue-bound: compare host_enqueue_ms_per_step)")
         gp_side("t512", 512, 128, 256, 20, 5, f"512 tasks/GPU/step at the C2 shape (two tasks per CU in the inner fit), exactly {I} evaluations")
         gp_side("c5", 8, 1024, 512, 5, 2, f"C5: 8 tasks, N_support = N_query = 1024, d = 512, blocked sweep, exactly {I} evaluations (a throughput point: not converged at {I})")
+        gp_side("c5_t32", 32, 1024, 512, 3, 1, f"the C5 shape with 32 tasks per step (four per XCD instead of one: the blocked sweep's diagonal chain of one task "
+                                                f"runs beside the updates of the others), exactly {I} evaluations")
         if "c5" in side:
             pm, src = profile_json("c5_fit_pmc.json")
             if pm is not None:

@@ -25,7 +25,7 @@ def golden_dir():
 # in the middle.
 _ORDER = ["test_gpu_parity.py", "test_gpu_reference_pins.py", "test_gpu_ard.py", "test_gpu_gnn.py", "test_evaluate.py",
           "test_gpu_stress.py", "test_gpu_surface.py"]
-_LAST = ["test_gpu_f3.py", "test_gpu_determinism.py", "test_zz_gpu_nccl.py"]
+_LAST = ["test_gpu_properties.py", "test_gpu_f3.py", "test_gpu_determinism.py", "test_zz_gpu_nccl.py"]
 
 
 def pytest_collection_modifyitems(session, config, items):

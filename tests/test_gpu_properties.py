@@ -1,0 +1,112 @@
+"""GPU: size-independent properties of the hot path at BASELINE.json's FULL sizes (where the float64 oracle takes minutes, not
+seconds): what the domain guarantees whatever the numbers are.
+
+  * tasks are independent units (fs_mol/utils/adaptive_dkt_utils.py:361-407): permuting the tasks of a meta-batch permutes every
+    output, BIT FOR BIT (a task's numbers must not depend on where it sits in the batch or on which XCD / CU it lands);
+  * a GP does not know the order of its points: permuting a task's support (query) points permutes dL/dZ_s (dL/dZ_q) rows and
+    leaves the fitted phi, f_in and f_out alone (to rounding: the sweep pivots in a different order);
+  * the median-heuristic re-initialisation makes the whole inner problem invariant under a rescaling of the features
+    (fs_mol/models/adaptive_dkt.py:128-131: l0 scales with Z; the kernel depends on Z / l only; the lengthscale prior is centred
+    at log l0): Z -> c Z gives the same f_in, f_out, noise and outputscale, lengthscale -> c l, dL/dZ -> dL/dZ / c.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _run(dev, Zs, ys, Zq, yq, kernel, evals):
+    from adkf_ift_amd import gp_ops
+
+    pri = torch.empty(Zs.shape[0], 4, device=dev)
+    b = gp_ops.GPBatch(Zs, ys, pri, kernel, Z_q=Zq, y_q=yq)
+    phi0, l0 = gp_ops.init_params_batch(b)
+    b.flags = gp_ops.REUSE_DIST
+    phi, f, gn, ne, info = gp_ops.fit(b, phi0, max_evals=evals, exact_evals=True)
+    gp_ops.check_info(info)
+    b.flags = gp_ops.REUSE_DIST | gp_ops.REUSE_INNER
+    out = gp_ops.ift_hypergrad(b, phi)
+    gp_ops.check_info(out["info"])
+    return dict(l0=l0, phi=phi, f_in=f, f_out=out["f_out"], H=out["H"], v=out["v"], dZ_s=out["dZ_s"], dZ_q=out["dZ_q"])
+
+
+@pytest.mark.parametrize("T,N,d,kernel", [(256, 128, 256, "rbf"), (64, 32, 64, "matern"), (8, 1024, 512, "rbf")])
+def test_permuting_the_tasks_permutes_every_output_bit_for_bit(dev, T, N, d, kernel):
+    """C2, C1 and C5 at full size."""
+    from adkf_ift_amd.synthetic import make_tasks
+
+    tasks = make_tasks(T, N, d, first_task=300)
+    Zs, Zq = (z.to(dev) for z in tasks.features())
+    ys, yq = tasks.y_s.to(dev), tasks.y_q.to(dev)
+    perm = torch.randperm(T, generator=torch.Generator().manual_seed(1)).to(dev)
+    a = _run(dev, Zs, ys, Zq, yq, kernel, 20 if N <= 128 else 6)
+    b = _run(dev, Zs[perm].contiguous(), ys[perm].contiguous(), Zq[perm].contiguous(), yq[perm].contiguous(), kernel, 20 if N <= 128 else 6)
+    for k in a:
+        assert torch.equal(a[k][perm], b[k]), k
+
+
+@pytest.mark.parametrize("T,N,d,kernel", [(256, 128, 256, "rbf"), (16, 128, 256, "matern")])
+def test_permuting_the_points_of_a_task_permutes_its_gradients(dev, T, N, d, kernel):
+    from adkf_ift_amd.synthetic import make_tasks
+
+    tasks = make_tasks(T, N, d, first_task=900)
+    Zs, Zq = (z.to(dev) for z in tasks.features())
+    ys, yq = tasks.y_s.to(dev), tasks.y_q.to(dev)
+    g = torch.Generator().manual_seed(2)
+    ps, pq = torch.randperm(N, generator=g).to(dev), torch.randperm(N, generator=g).to(dev)
+    a = _run(dev, Zs, ys, Zq, yq, kernel, 0)          # at the initial phi: the fit's path may legitimately differ by an ulp per step
+    b = _run(dev, Zs[:, ps].contiguous(), ys[:, ps].contiguous(), Zq[:, pq].contiguous(), yq[:, pq].contiguous(), kernel, 0)
+    rel = lambda x, y: ((x - y).abs().max() / y.abs().max()).item()
+    assert torch.equal(a["l0"], b["l0"])               # the median of the same multiset of squared distances
+    assert rel(b["f_in"], a["f_in"]) <= 2e-6 and rel(b["f_out"], a["f_out"]) <= 2e-5
+    assert rel(b["H"], a["H"]) <= 2e-5
+    assert rel(b["dZ_s"], a["dZ_s"][:, ps]) <= 1e-4 and rel(b["dZ_q"], a["dZ_q"][:, pq]) <= 1e-4
+
+
+def test_rescaling_the_features_rescales_the_lengthscale_and_nothing_else(dev):
+    """C2 shape, c = 4 (a power of two: the squared distances of the scaled problem are the same floating-point numbers up to their
+    exponents).  At the fitted parameters of the original problem, with the lengthscale multiplied by c for the scaled one and the
+    priors of each problem's own re-initialisation: f_out, the noise / outputscale gradients and c dL/dZ agree; f_in moves by
+    exactly log(c) / N (the -log x term of the LogNormal density of the lengthscale prior, fs_mol/models/adaptive_dkt.py:94-100)."""
+    from adkf_ift_amd import gp_ops
+    from adkf_ift_amd.synthetic import make_tasks
+
+    T, N, d, c = 64, 128, 256, 4.0
+    tasks = make_tasks(T, N, d, first_task=1500)
+    Zs, Zq = (z.to(dev) for z in tasks.features())
+    ys, yq = tasks.y_s.to(dev), tasks.y_q.to(dev)
+    sp = torch.nn.functional.softplus
+
+    def at(Zs_, Zq_, phi):
+        pri = torch.empty(T, 4, device=dev)
+        b = gp_ops.GPBatch(Zs_, ys, pri, "rbf", Z_q=Zq_, y_q=yq)
+        phi0, l0 = gp_ops.init_params_batch(b)                # fills the priors of THIS problem
+        if phi is None:
+            b.flags = gp_ops.REUSE_DIST
+            phi, *_ = gp_ops.fit(b, phi0, max_evals=20, exact_evals=True)
+        b.flags = gp_ops.REUSE_DIST
+        f_in, g_in, _, info = gp_ops.mll_value_grad(b, phi)
+        gp_ops.check_info(info)
+        out = gp_ops.ift_hypergrad(b, phi)
+        gp_ops.check_info(out["info"])
+        return phi, l0, f_in, g_in, out
+
+    phi_a, l0_a, f_a, g_a, out_a = at(Zs, Zq, None)
+    ls = c * sp(phi_a[:, 2].double())
+    phi_b = phi_a.clone()
+    phi_b[:, 2] = (ls + torch.log(-torch.expm1(-ls))).float()                     # inverse softplus
+    _, l0_b, f_b, g_b, out_b = at(c * Zs, c * Zq, phi_b)
+    rel = lambda x, y: ((x - y).abs().max() / y.abs().max()).item()
+    assert rel(l0_b, c * l0_a) <= 1e-6
+    assert (f_b - (f_a + math.log(c) / N)).abs().max().item() <= 2e-6 * f_a.abs().max().item()
+    assert rel(out_b["f_out"], out_a["f_out"]) <= 1e-5
+    assert rel(g_b[:, :2], g_a[:, :2]) <= 1e-4                                    # d f_in / d (raw noise, raw outputscale)
+    assert rel(c * out_b["dZ_s"], out_a["dZ_s"]) <= 1e-4 and rel(c * out_b["dZ_q"], out_a["dZ_q"]) <= 1e-4
