@@ -37,23 +37,14 @@ inline int grid_for(int T, int tiles) { return ((T + 7) / 8) * 8 * tiles; }
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Output-tile edge of the batched GEMMs.  The 128 x 128 variant (gemm.h) halves the operand traffic but leaves one
-// wave per SIMD: measured slower at every stage of C2 (ProbDist 33 -> 49 us, ProbP 22 -> 32 us, docs/DESIGN_rounds_1_to_4.md),
-// so 64 x 64 (four co-resident workgroups per CU) is the default.  ADKF_GEMM_TILE128_MIN (read once, experiments): products whose
-// M and N both reach this size take the 128 x 128 tile (round 5: measured at the C5 shape).
-inline int tile_edge(int M, int N) {
-    static const int min128 = [] { const char* e = getenv("ADKF_GEMM_TILE128_MIN"); return e ? atoi(e) : 0; }();
-    return (min128 > 0 && M >= min128 && N >= min128) ? GTL : GT;
-}
+// wave per SIMD: measured slower at every stage of C2 (ProbDist 33 -> 49 us, ProbP 22 -> 32 us, profiles/ notes in
+// DESIGN.md), so 64 x 64 (four co-resident workgroups per CU) is used throughout.
+inline int tile_edge(int, int) { return GT; }
 inline int tiles_of(int M, int N) { const int e = tile_edge(M, N); return ceil_div(M, e) * ceil_div(N, e); }
 
 template <class P>
 void launch_gemm(const P& p, int T, int M, int N, hipStream_t st) {
-    if (tile_edge(M, N) == GTL) {
-        const int tm = ceil_div(M, GTL), tn = ceil_div(N, GTL);
-        k_bgemm<P, GTL><<<((T + 7) / 8) * 8 * tm * tn, 256, 0, st>>>(p, T, tm, tn);
-        return;
-    }
-    const int tm = ceil_div(M, GT), tn = ceil_div(N, GT);
+    const int tm = ceil_div(M, GT), tn = ceil_div(N, GT);   // (k_bgemm<P, GTL> is not instantiated: see tile_edge)
     k_bgemm<P, GT><<<((T + 7) / 8) * 8 * tm * tn, 256, 0, st>>>(p, T, tm, tn);
 }
 

@@ -84,8 +84,6 @@ template <class P> struct has_deep<P, std::void_t<decltype(P::DEEP)>> : std::tru
 // pre4 / epi4p: the epilogue's own operand (the matrix tile a product is subtracted from) is fetched with the operands, not after the last MFMA
 template <class P, class = void> struct has_pre : std::false_type {};
 template <class P> struct has_pre<P, std::void_t<decltype(&P::pre4)>> : std::true_type {};
-template <class P, class = void> struct has_tile : std::false_type {};     // the functor wants to know the tile edge (mirror-image logic of symmetric results)
-template <class P> struct has_tile<P, std::void_t<decltype(P::tile)>> : std::true_type {};
 template <class P, class = void> struct has_raw : std::false_type {};
 template <class P> struct has_raw<P, std::void_t<decltype(P::A_NRAW)>> : std::true_type {};
 
@@ -203,7 +201,6 @@ __global__ __launch_bounds__(256) void k_bgemm(P p, int T, int tiles_m, int tile
         if (!task_tile(T, tiles_m * tiles_n, task, tile)) return;
     }
     if constexpr (has_select<P>::value) p.select(tile, tiles_n);   // several sub-problems in one launch (tiles_m = 1, tiles_n = all tiles)
-    if constexpr (has_tile<P>::value) p.tile = TM;
     if (!p.setup(task)) return;
     const int M = p.M(), N = p.N();
     int K = p.K();

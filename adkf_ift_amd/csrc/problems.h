@@ -158,7 +158,6 @@ struct ProbCfix {
 struct ProbS {
     static constexpr bool A_KCONTIG = true, B_KCONTIG = true;
     static constexpr int NRED = 0;
-    int tile = GT;   // output-tile edge of the launch (k_bgemm sets it): which tiles are written by their mirror images
     TaskView tv; const float* C; const float* D2qs; const float* D2qq; float* S;
     int n, m; float os, il2, noise; const float *Ci, *Dqs, *Dqq; float* So; bool vec;
     __device__ bool setup(int t) {
@@ -191,10 +190,10 @@ struct ProbS {
     __device__ void epi(int i, int j, float acc, float*) const {
         const float v = value(i, j, acc);
         So[(size_t)i * tv.nq_ld + j] = v;
-        if ((i / tile) < (j / tile)) So[(size_t)j * tv.nq_ld + i] = v;
+        if ((i / GT) < (j / GT)) So[(size_t)j * tv.nq_ld + i] = v;
     }
     __device__ void epi4(int i0, int j, const float (&acc)[4], float* red) const {
-        if (!(vec && (i0 / tile) < (j / tile))) {
+        if (!(vec && (i0 / GT) < (j / GT))) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) epi(i0 + r, j, acc[r], red);
             return;
