@@ -30,7 +30,11 @@ def _run(dev, Zs, ys, Zq, yq, kernel, evals):
     b = gp_ops.GPBatch(Zs, ys, pri, kernel, Z_q=Zq, y_q=yq)
     phi0, l0 = gp_ops.init_params_batch(b)
     b.flags = gp_ops.REUSE_DIST
-    phi, f, gn, ne, info = gp_ops.fit(b, phi0, max_evals=evals, exact_evals=True)
+    if evals > 0:
+        phi, f, gn, ne, info = gp_ops.fit(b, phi0, max_evals=evals, exact_evals=True)
+    else:   # at the freshly initialised parameters
+        phi = phi0
+        f, _, _, info = gp_ops.mll_value_grad(b, phi)
     gp_ops.check_info(info)
     b.flags = gp_ops.REUSE_DIST | gp_ops.REUSE_INNER
     out = gp_ops.ift_hypergrad(b, phi)
