@@ -69,7 +69,8 @@ def test_permuting_the_points_of_a_task_permutes_its_gradients(dev, T, N, d, ker
     a = _run(dev, Zs, ys, Zq, yq, kernel, 0)          # at the initial phi: the fit's path may legitimately differ by an ulp per step
     b = _run(dev, Zs[:, ps].contiguous(), ys[:, ps].contiguous(), Zq[:, pq].contiguous(), yq[:, pq].contiguous(), kernel, 0)
     rel = lambda x, y: ((x - y).abs().max() / y.abs().max()).item()
-    assert torch.equal(a["l0"], b["l0"])               # the median of the same multiset of squared distances
+    assert rel(b["l0"], a["l0"]) <= 1e-6               # the median of the same multiset of squared distances (the column means the features
+                                                       # are centred by are summed in another order: an ulp, not bit for bit)
     assert rel(b["f_in"], a["f_in"]) <= 2e-6 and rel(b["f_out"], a["f_out"]) <= 2e-5
     assert rel(b["H"], a["H"]) <= 2e-5
     assert rel(b["dZ_s"], a["dZ_s"][:, ps]) <= 1e-4 and rel(b["dZ_q"], a["dZ_q"][:, pq]) <= 1e-4
