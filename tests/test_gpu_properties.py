@@ -73,7 +73,8 @@ def test_permuting_the_points_of_a_task_permutes_its_gradients(dev, T, N, d, ker
                                                        # are centred by are summed in another order: an ulp, not bit for bit)
     assert rel(b["f_in"], a["f_in"]) <= 2e-6 and rel(b["f_out"], a["f_out"]) <= 2e-5
     assert rel(b["H"], a["H"]) <= 2e-5
-    assert rel(b["dZ_s"], a["dZ_s"][:, ps]) <= 1e-4 and rel(b["dZ_q"], a["dZ_q"][:, pq]) <= 1e-4
+    # two float32 evaluations, each held to 1e-4 of float64 by the parity tests: 2e-4 apart at worst, over 256 tasks (observed 1.5e-4)
+    assert rel(b["dZ_s"], a["dZ_s"][:, ps]) <= 2.5e-4 and rel(b["dZ_q"], a["dZ_q"][:, pq]) <= 2.5e-4
 
 
 def test_rescaling_the_features_rescales_the_lengthscale_and_nothing_else(dev):
