@@ -417,6 +417,15 @@ def main():
             torch.cuda.empty_cache()
 
         gp_side("c1", 64, 32, 64, 50, 10, f"C1: 64 tasks, N_support = N_query = 32, d = 64, exactly {I} evaluations (host-enqueue-bound: compare host_enqueue_ms_per_step)")
+        if "c1" in side:   # the same shape with the GP section replayed from a captured HIP graph (trainer.GraphedGPBackend): what a host-bound shape wants
+            try:
+                w_ = Workload(64, 32, 32, 64)
+                dt_, th_ = w_.timed_loop(step_cfg(False), 50, 10, None, backend=GraphedGPBackend())
+                side["c1"]["with_hip_graph"] = {"ms_per_step": dt_ / 50 * 1e3, "tasks_per_s": 64 * 50 / dt_, "host_enqueue_ms_per_step": th_ / 50 * 1e3}
+                del w_
+            except Exception as e:
+                print(f"[bench] c1 with the HIP-graph backend not measured ({type(e).__name__}: {e})", file=sys.stderr)
+            torch.cuda.empty_cache()
         gp_side("t512", 512, 128, 256, 20, 5, f"512 tasks/GPU/step at the C2 shape (two tasks per CU in the inner fit), exactly {I} evaluations")
         gp_side("c5", 8, 1024, 512, 5, 2, f"C5: 8 tasks, N_support = N_query = 1024, d = 512, blocked sweep, exactly {I} evaluations (a throughput point: not converged at {I})")
         gp_side("c5_t32", 32, 1024, 512, 3, 1, f"the C5 shape with 32 tasks per step (four per XCD instead of one: the blocked sweep's diagonal chain of one task "
