@@ -48,6 +48,9 @@ inline int tiles_of(int M, int N) { const int e = tile_edge(M, N); return ceil_d
 template <class P> struct use_x3 : std::false_type {};
 template <bool Q> struct use_x3<ProbDZ<Q>> : std::true_type {};
 template <> struct use_x3<ProbDistMulti> : std::true_type {};
+// (The N^3 products of the multi-launch outer stage beyond 128 points - ProbP, ProbC, ProbS, ProbOC, ProbMA, ProbMixed - were tried on
+// it as well: the same 1.99 ms for the eleven products of a C5 step, profiles/r05_c5_x3_kernel_stats.csv - at 64 x 64 tiles and
+// K = 1024 they wait for their operands, 6.9 TB/s out of L2 / MALL, not for the matrix pipe.)
 bool x3_enabled() {
     static const bool v = [] { const char* e = getenv("ADKF_X3"); return !(e && e[0] == '0'); }();
     return v;
@@ -59,7 +62,7 @@ bool x3_enabled() {
 inline bool x3_for(int d) { return x3_enabled() && d >= GK; }
 
 template <class P>
-void launch_gemm(const P& p, int T, int M, int N, hipStream_t st, bool x3 = true) {
+void launch_gemm(const P& p, int T, int M, int N, hipStream_t st, bool x3 = false) {
     const int tm = ceil_div(M, GT), tn = ceil_div(N, GT);   // (k_bgemm<P, GTL> is not instantiated: see tile_edge)
     if constexpr (use_x3<P>::value) {
         if (x3 && x3_enabled()) { k_bgemm3<P, GT, 256><<<((T + 7) / 8) * 8 * tm * tn, 256, 0, st>>>(p, T, tm, tn); return; }

@@ -23,8 +23,11 @@
 // of 64 x 32: half the splitting work per MFMA, two waves per SIMD).  LDS image per operand: three planes [TM][32] of bfloat16,
 // K-contiguous whatever the memory layout, rows 80 bytes apart (a lane's fragment is ONE ds_read_b128 - row l & 15, k = 8 (l >> 4) ..
 // + 7 - and the sixteen rows of a group of lanes fall on all 64 banks).  K-contiguous operands are staged by the thread -> element map
-// of gemm.h (row tid / 8 + 32 ps, four k per thread); MN-contiguous ones as GPT / 4 consecutive k rows of four columns per thread, so
-// that the transposition costs nothing but narrower LDS stores (4 or 8 bytes).
+// of gemm.h (row tid / 8 + 32 ps, four k per thread); MN-contiguous ones (dL/dZ's feature matrix: [k][column]) with a COLUMN per lane -
+// GPT consecutive k of it from GPT scalar loads, each a coalesced row segment across the wave - so that the transposition is free:
+// the lane holds exactly the k-run its LDS row wants and writes it as one 16-byte store per plane, on the conflict-free row stride.
+// (First version: four columns x two k per thread from 16-byte loads, twelve 4-byte LDS stores with four-way bank conflicts -
+// dL/dZ came out 5 % SLOWER than on the FP32 pipe.)
 #pragma once
 #include "gemm.h"
 
@@ -62,23 +65,22 @@ template <int TM, int NT> struct X3Cfg {
     static constexpr int GPT = TM * GK / NT;     // operand entries per thread and chunk (8 or 16)
     static constexpr int NG = GPT / 4;           // groups of four per thread
     static constexpr int ROWS = NT / 8;          // K-contiguous map: rows per pass (eight threads per row)
-    static constexpr int KB = GPT / 4;           // MN-contiguous map: consecutive k rows per thread (2 or 4)
-    static constexpr int MNQ = TM / 4;           // groups of four columns
+    static constexpr int KQ = NT / TM;           // MN-contiguous map: lane -> column tid % TM, k run (tid / TM) * GPT .. + GPT - 1
+    static_assert(KQ * GPT == GK && (GPT % 8) == 0, "a thread's k run is one or two 16-byte LDS stores");
     static constexpr int PLANE = TM * X3_RS;     // bfloat16 per plane
     static constexpr int WC = NT / 128, WR = 2;  // waves: WR x WC, each (TM / WR) x (TM / WC)
     static constexpr int MI = TM / WR / 16, MJ = TM / WC / 16;
 };
 
-// (row / column g, first k gk) of group ps of this thread
-template <bool KC, int TM, int NT>
+// K-contiguous map: (row g, first k gk) of group ps of this thread
+template <int TM, int NT>
 __device__ __forceinline__ void x3_group(int ps, int base, int k0, int& g, int& gk) {
     using C = X3Cfg<TM, NT>;
     const int tid = threadIdx.x;
-    if (KC) { g = base + (tid >> 3) + ps * C::ROWS; gk = k0 + (tid & 7) * 4; }
-    else { g = base + (tid % C::MNQ) * 4; gk = k0 + (tid / C::MNQ) * C::KB + ps; }
+    g = base + (tid >> 3) + ps * C::ROWS; gk = k0 + (tid & 7) * 4;
 }
 
-// v[ps][x]: K-contiguous - entry (row of group ps, k4 + x); MN-contiguous - entry (k of group ps, column n4 + x)
+// K-contiguous: v[ps][x] = entry (row of group ps, k4 + x).  MN-contiguous: v[h][x] = entry (k run position 4 h + x, this lane's column).
 template <bool KC, int TM, int NT, int SQ>
 __device__ __forceinline__ void x3_stage(unsigned short* S, const float (&v)[X3Cfg<TM, NT>::NG][4], float* sq) {
     using C = X3Cfg<TM, NT>;
@@ -101,72 +103,72 @@ __device__ __forceinline__ void x3_stage(unsigned short* S, const float (&v)[X3C
         }
     } else {
         static_assert(SQ == 0, "row sums ride the K-contiguous staging map");
-        const int n4 = (tid % C::MNQ) * 4, kb = (tid / C::MNQ) * C::KB;
+        unsigned short* d = S + (tid % TM) * X3_RS + (tid / TM) * C::GPT;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {   // column n4 + x: KB consecutive k
-            unsigned short* d = S + (n4 + x) * X3_RS + kb;
-            uint32_t p0[C::KB / 2], p1[C::KB / 2], p2[C::KB / 2];
-#pragma unroll
-            for (int h = 0; h < C::KB / 2; ++h) x3_split2(v[2 * h][x], v[2 * h + 1][x], p0[h], p1[h], p2[h]);
-            if constexpr (C::KB == 2) {
-                *reinterpret_cast<uint32_t*>(d) = p0[0];
-                *reinterpret_cast<uint32_t*>(d + C::PLANE) = p1[0];
-                *reinterpret_cast<uint32_t*>(d + 2 * C::PLANE) = p2[0];
-            } else {
-                *reinterpret_cast<uint2*>(d) = make_uint2(p0[0], p0[1]);
-                *reinterpret_cast<uint2*>(d + C::PLANE) = make_uint2(p1[0], p1[1]);
-                *reinterpret_cast<uint2*>(d + 2 * C::PLANE) = make_uint2(p2[0], p2[1]);
-            }
+        for (int h = 0; h < C::NG; h += 2) {   // eight consecutive k: one 16-byte store per plane
+            uint32_t p0[4], p1[4], p2[4];
+            x3_split2(v[h][0], v[h][1], p0[0], p1[0], p2[0]);
+            x3_split2(v[h][2], v[h][3], p0[1], p1[1], p2[1]);
+            x3_split2(v[h + 1][0], v[h + 1][1], p0[2], p1[2], p2[2]);
+            x3_split2(v[h + 1][2], v[h + 1][3], p0[3], p1[3], p2[3]);
+            *reinterpret_cast<uint4*>(d + 4 * h) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+            *reinterpret_cast<uint4*>(d + 4 * h + C::PLANE) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+            *reinterpret_cast<uint4*>(d + 4 * h + 2 * C::PLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
         }
     }
 }
 
+// MN-contiguous operand: this lane's column, its GPT consecutive k, by the functor's scalar accessor (CHECKED: range-checked)
+template <class P, bool IS_A, int TM, int NT, bool CHECKED>
+__device__ __forceinline__ void x3_fetch_col(const P& p, float (&v)[X3Cfg<TM, NT>::NG][4], int base, int k0, int lim, int K) {
+    using C = X3Cfg<TM, NT>;
+    const int g = base + (threadIdx.x % TM), kb = k0 + (threadIdx.x / TM) * C::GPT;
+#pragma unroll
+    for (int h = 0; h < C::NG; ++h)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int k = kb + 4 * h + x;
+            if (CHECKED) v[h][x] = (g < lim && k < K) ? (IS_A ? p.a(g, k) : p.b(k, g)) : 0.f;
+            else v[h][x] = IS_A ? p.a(g, k) : p.b(k, g);
+        }
+}
+
 template <class P, bool IS_A, int TM, int NT, int NR>
 __device__ __forceinline__ void x3_fetch_raw(const P& p, float4 (&raw)[X3Cfg<TM, NT>::NG][NR], int base, int k0) {
-    constexpr bool KC = IS_A ? P::A_KCONTIG : P::B_KCONTIG;
 #pragma unroll
     for (int ps = 0; ps < X3Cfg<TM, NT>::NG; ++ps) {
         int g, gk;
-        x3_group<KC, TM, NT>(ps, base, k0, g, gk);
+        x3_group<TM, NT>(ps, base, k0, g, gk);
         if constexpr (IS_A) p.a_raw(g, gk, raw[ps]); else p.b_raw(gk, g, raw[ps]);
     }
 }
 
 template <class P, bool IS_A, int TM, int NT, int NR, int SQ>
 __device__ __forceinline__ void x3_stage_raw(const P& p, unsigned short* S, const float4 (&raw)[X3Cfg<TM, NT>::NG][NR], int base, int k0, float* sq) {
-    constexpr bool KC = IS_A ? P::A_KCONTIG : P::B_KCONTIG;
     float v[X3Cfg<TM, NT>::NG][4];
 #pragma unroll
     for (int ps = 0; ps < X3Cfg<TM, NT>::NG; ++ps) {
         int g, gk;
-        x3_group<KC, TM, NT>(ps, base, k0, g, gk);
+        x3_group<TM, NT>(ps, base, k0, g, gk);
         if constexpr (IS_A) p.a_fin(g, gk, raw[ps], v[ps]); else p.b_fin(gk, g, raw[ps], v[ps]);
     }
-    x3_stage<KC, TM, NT, SQ>(S, v, sq);
+    x3_stage<true, TM, NT, SQ>(S, v, sq);
 }
 
-// range-checked fetch (ragged tiles, K not a multiple of the chunk, problems without the two-phase path)
+// range-checked fetch of a K-contiguous operand (ragged tiles, K not a multiple of the chunk, problems without the two-phase path)
 template <class P, bool IS_A, int TM, int NT>
 __device__ __forceinline__ void x3_fetch(const P& p, float (&v)[X3Cfg<TM, NT>::NG][4], int base, int k0, int lim, int K) {
     constexpr bool KC = IS_A ? P::A_KCONTIG : P::B_KCONTIG;
+    if constexpr (!KC) { x3_fetch_col<P, IS_A, TM, NT, true>(p, v, base, k0, lim, K); return; }
 #pragma unroll
     for (int ps = 0; ps < X3Cfg<TM, NT>::NG; ++ps) {
         int g, gk;
-        x3_group<KC, TM, NT>(ps, base, k0, g, gk);
-        if (KC) {
-            if (p.vec && g < lim && gk + 3 < K) {
-                if (IS_A) p.a4(g, gk, v[ps]); else p.b4(gk, g, v[ps]);
-            } else {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) v[ps][x] = (g < lim && gk + x < K) ? (IS_A ? p.a(g, gk + x) : p.b(gk + x, g)) : 0.f;
-            }
+        x3_group<TM, NT>(ps, base, k0, g, gk);
+        if (p.vec && g < lim && gk + 3 < K) {
+            if (IS_A) p.a4(g, gk, v[ps]); else p.b4(gk, g, v[ps]);
         } else {
-            if (p.vec && g + 3 < lim && gk < K) {
-                if (IS_A) p.a4(g, gk, v[ps]); else p.b4(gk, g, v[ps]);
-            } else {
 #pragma unroll
-                for (int x = 0; x < 4; ++x) v[ps][x] = (g + x < lim && gk < K) ? (IS_A ? p.a(g + x, gk) : p.b(gk, g + x)) : 0.f;
-            }
+            for (int x = 0; x < 4; ++x) v[ps][x] = (g < lim && gk + x < K) ? (IS_A ? p.a(g, gk + x) : p.b(gk + x, g)) : 0.f;
         }
     }
 }
@@ -261,17 +263,24 @@ __global__ __launch_bounds__(NT) void k_bgemm3(P p, int T, int tiles_m, int tile
     if constexpr (has_raw<P>::value) {
         fast = p.vec && m0 + TM <= M && n0 + TM <= N && K > 0 && (K % GK) == 0 && p.raw_ok();
         if (fast) {
-            float4 qa[NG][P::A_NRAW], qb[NG][P::B_NRAW];
-            x3_fetch_raw<P, true, TM, NT, P::A_NRAW>(p, qa, m0, 0);
-            x3_fetch_raw<P, false, TM, NT, P::B_NRAW>(p, qb, n0, 0);
+            // K-contiguous operands: the two-phase path of gemm.h (16-byte loads issued a chunk ahead, functor arithmetic while staging);
+            // MN-contiguous ones: the lane's k run by scalar loads, likewise a chunk ahead
+            float4 qa[P::A_KCONTIG ? NG : 1][P::A_NRAW], qb[P::B_KCONTIG ? NG : 1][P::B_NRAW];
+            float ca[P::A_KCONTIG ? 1 : NG][4], cb[P::B_KCONTIG ? 1 : NG][4];
+            auto fetch = [&](int k0) __attribute__((always_inline)) {
+                if constexpr (P::A_KCONTIG) x3_fetch_raw<P, true, TM, NT, P::A_NRAW>(p, qa, m0, k0);
+                else x3_fetch_col<P, true, TM, NT, false>(p, ca, m0, k0, M, K);
+                if constexpr (P::B_KCONTIG) x3_fetch_raw<P, false, TM, NT, P::B_NRAW>(p, qb, n0, k0);
+                else x3_fetch_col<P, false, TM, NT, false>(p, cb, n0, k0, N, K);
+            };
+            fetch(0);
             for (int k0 = 0; k0 < K; k0 += GK) {
-                x3_stage_raw<P, true, TM, NT, P::A_NRAW, SQA>(p, As, qa, m0, k0, sqa);
-                x3_stage_raw<P, false, TM, NT, P::B_NRAW, SQB>(p, Bs, qb, n0, k0, sqb);
+                if constexpr (P::A_KCONTIG) x3_stage_raw<P, true, TM, NT, P::A_NRAW, SQA>(p, As, qa, m0, k0, sqa);
+                else x3_stage<false, TM, NT, 0>(As, ca, sqa);
+                if constexpr (P::B_KCONTIG) x3_stage_raw<P, false, TM, NT, P::B_NRAW, SQB>(p, Bs, qb, n0, k0, sqb);
+                else x3_stage<false, TM, NT, 0>(Bs, cb, sqb);
                 __syncthreads();
-                if (k0 + GK < K && !(ADKF_X3_ABLATE & 4)) {
-                    x3_fetch_raw<P, true, TM, NT, P::A_NRAW>(p, qa, m0, k0 + GK);
-                    x3_fetch_raw<P, false, TM, NT, P::B_NRAW>(p, qb, n0, k0 + GK);
-                }
+                if (k0 + GK < K && !(ADKF_X3_ABLATE & 4)) fetch(k0 + GK);
                 __builtin_amdgcn_sched_barrier(0);   // the loads above are in flight before the first MFMA issues
                 multiply_chunk();
                 __syncthreads();
