@@ -46,7 +46,9 @@ inline int tiles_of(int M, int N) { const int e = tile_edge(M, N); return ceil_d
 // Which problems run on the BF16 matrix pipe (gemm_x3.h: FP32 products out of three-way split operands).  ADKF_X3=0 (read once) sends
 // them back to the FP32-input MFMA kernel for A/B runs.
 template <class P> struct use_x3 : std::false_type {};
-template <bool Q> struct use_x3<ProbDZ<Q>> : std::true_type {};
+// (ProbDZ ran on it as well - every parity test green, MN-contiguous staging with a column per lane - at the same time as on the FP32
+// pipe, 62.5 + 54.4 against 61 + 56.5 us at C2: it is bound by its strided W_qs^T operand and the staging, not by the matrix pipe; left
+// on the FP32 form.)
 template <> struct use_x3<ProbDistMulti> : std::true_type {};
 // (The N^3 products of the multi-launch outer stage beyond 128 points - ProbP, ProbC, ProbS, ProbOC, ProbMA, ProbMixed - were tried on
 // it as well: the same 1.99 ms for the eleven products of a C5 step, profiles/r05_c5_x3_kernel_stats.csv - at 64 x 64 tiles and
