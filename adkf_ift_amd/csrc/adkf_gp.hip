@@ -16,6 +16,7 @@
 #include "hyper.h"
 #include "large_fused.h"
 #include "gemm_x3.h"
+#include "dense_x3.h"
 #if ADKF_VARIANT_DZ   // A/B experiment only (measured slower than the two ProbDZ launches: see its header)
 #include "../../tools/variants/dz.h"
 #endif
@@ -1340,6 +1341,34 @@ int adkf_block_combine_backward(const float* p, const float* x1, const float* am
     }
     const int n = 3 * hid + 1;
     k_block_reduce<<<ceil_div(n, 64), 64, 0, st>>>(a.part, nwg, n, d_bias, d_gamma, d_beta, d_alpha, hid);
+    LAUNCH_OK();
+    return 0;
+}
+
+int adkf_split_planes(const float* x, uint16_t* planes, int64_t rows, int64_t K, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !planes || rows <= 0 || K <= 0 || (K & 1)) return ADKF_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(x) & 7) || (reinterpret_cast<uintptr_t>(planes) & 15) || ((rows * K) & 7)) return ADKF_E_BADARG;
+    const size_t pairs = (size_t)rows * (size_t)K / 2;
+    if (pairs > (size_t)0x7fffffff * 256) return ADKF_E_SIZE;
+    k_split3<<<(unsigned)((pairs + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(x, planes, pairs, (size_t)rows * (size_t)K);
+    LAUNCH_OK();
+    return 0;
+}
+
+int adkf_dense_forward(const float* x, int32_t ldx, const uint16_t* w_planes, const float* bias, float* y, int32_t ldy, int32_t M,
+                       int32_t N, int32_t K, void* stream) {
+    (void)hipGetLastError();
+    if (!x || !w_planes || !y || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldy < N) return ADKF_E_BADARG;
+    if ((K % GK) || (ldx & 3)) return ADKF_E_SIZE;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_planes)) & 15) return ADKF_E_BADARG;
+    static const bool optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  D3_LDS_BYTES) == hipSuccess;
+    if (!optin) { g_last_hip_error = hipErrorInvalidValue; (void)hipGetLastError(); return ADKF_E_LAUNCH; }
+    const long long tiles = (long long)ceil_div(M, D3_TM) * ceil_div(N, D3_TN);
+    if (tiles > 0x7fffffffLL) return ADKF_E_SIZE;
+    Dense3Args a{x, ldx, w_planes, (size_t)N * (size_t)K, bias, y, ldy, M, N, K};
+    k_dense3<<<(unsigned)tiles, D3_NT, D3_LDS_BYTES, static_cast<hipStream_t>(stream)>>>(a);
     LAUNCH_OK();
     return 0;
 }

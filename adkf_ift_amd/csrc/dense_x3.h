@@ -1,0 +1,163 @@
+// k_dense3: C[M, N] = A[M, K] B[N, K]^T (+ bias) - a dense layer in torch's F.linear layout - with FP32 products on the BF16 matrix pipe
+// (gemm_x3.h: three-way split operands, six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block, the leading term in an accumulator of its
+// own), as a PIPELINED kernel: what gemm_x3.h section "what would take it further" describes.
+//
+//   * B (the weights: small, shared by every row tile) arrives PRE-SPLIT - three planes [N][K] of bfloat16 written once per weight
+//     update by k_split3 - so staging it is three 16-byte loads and three 16-byte LDS stores per lane and chunk, no arithmetic;
+//   * A (the activations) is split on the fly, eight consecutive k per lane from two 16-byte loads, one 16-byte LDS store per plane;
+//   * 128 x 128 output tile, 512 lanes = 2 x 4 waves of 64 x 32 (accumulators 2 x 32 registers), K chunks of 32, LDS DOUBLE-buffered:
+//     one barrier per chunk; the loads of chunk c + 2 are issued in iteration c and consumed in iteration c + 1;
+//   * the two waves that share a SIMD run the halves of an iteration in OPPOSITE order (waves 0 - 3: stage chunk c + 1, then the MFMAs
+//     of chunk c; waves 4 - 7: MFMAs first), so that one's splitting arithmetic and LDS traffic sit under the other's matrix instructions.
+#pragma once
+#include "gemm_x3.h"
+
+namespace adkf {
+
+#ifndef D3_PINGPONG
+#define D3_PINGPONG 1
+#endif
+#ifndef D3_EAGER_A
+#define D3_EAGER_A 0
+#endif
+constexpr int D3_TM = 128, D3_TN = 128, D3_NT = 512, D3_PLANE = D3_TM * X3_RS;
+constexpr int D3_LDS_BYTES = 2 * 2 * 3 * D3_PLANE * (int)sizeof(unsigned short);   // two buffers x (A, B) x three planes: 122 880
+
+// x [rows, K] float -> three planes [3][rows][K] of bfloat16 (K a multiple of 2)
+__global__ void k_split3(const float* __restrict__ x, unsigned short* __restrict__ planes, size_t n_pairs, size_t plane_elems) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    const float2 v = reinterpret_cast<const float2*>(x)[i];
+    uint32_t p0, p1, p2;
+    x3_split2(v.x, v.y, p0, p1, p2);
+    reinterpret_cast<uint32_t*>(planes)[i] = p0;
+    reinterpret_cast<uint32_t*>(planes + plane_elems)[i] = p1;
+    reinterpret_cast<uint32_t*>(planes + 2 * plane_elems)[i] = p2;
+}
+
+struct Dense3Args {
+    const float* A; int lda;                    // [M, K] activations, row stride lda (multiple of 4, 16-byte aligned rows)
+    const unsigned short* Bp; size_t b_plane;   // pre-split weights: planes [3][N][K] (k_split3), plane stride in elements
+    const float* bias;                          // [N] or null
+    float* C; int ldc;                          // [M, N]
+    int M, N, K;                                // K a multiple of 32; M, N arbitrary
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned short d3_lds[];
+
+__global__ __launch_bounds__(D3_NT) void k_dense3(Dense3Args a) {
+    constexpr int MI = 4, MJ = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 2, wc = wv & 3;            // 2 x 4 waves of 64 x 32
+    const int fi = lane & 15, fk = lane >> 4;
+    const int tiles_n = (a.N + D3_TN - 1) / D3_TN;
+    const int m0 = (blockIdx.x / tiles_n) * D3_TM, n0 = (blockIdx.x % tiles_n) * D3_TN;
+    unsigned short* const As = d3_lds;                       // [2][3][PLANE]
+    unsigned short* const Bs = d3_lds + 2 * 3 * D3_PLANE;    // [2][3][PLANE]
+
+    // staging maps: row / column r = tid / 4 of the tile, k run 8 (tid % 4) .. + 7
+    const int sr = tid >> 2, sk = (tid & 3) * 8;
+    const bool a_ok = m0 + sr < a.M, b_ok = n0 + sr < a.N;
+    const float* ap = a.A + (size_t)(a_ok ? m0 + sr : 0) * a.lda + sk;
+    const unsigned short* bp = a.Bp + (size_t)(b_ok ? n0 + sr : 0) * a.K + sk;
+    const int sdst = sr * X3_RS + sk;
+
+    float4 ra0, ra1; uint4 rb0, rb1, rb2;
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+        ra0 = *reinterpret_cast<const float4*>(ap + k0); ra1 = *reinterpret_cast<const float4*>(ap + k0 + 4);
+        rb0 = *reinterpret_cast<const uint4*>(bp + k0); rb1 = *reinterpret_cast<const uint4*>(bp + a.b_plane + k0);
+        rb2 = *reinterpret_cast<const uint4*>(bp + 2 * a.b_plane + k0);
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        // (rows / columns beyond M / N read row 0 instead - valid memory - and are staged like the others: a row of A only reaches its
+        // own row of C, a column of B only its own column, and the epilogue stores neither)
+        uint32_t p0[4], p1[4], p2[4];
+        x3_split2(ra0.x, ra0.y, p0[0], p1[0], p2[0]); x3_split2(ra0.z, ra0.w, p0[1], p1[1], p2[1]);
+        x3_split2(ra1.x, ra1.y, p0[2], p1[2], p2[2]); x3_split2(ra1.z, ra1.w, p0[3], p1[3], p2[3]);
+        unsigned short* da = As + buf * 3 * D3_PLANE + sdst;
+        *reinterpret_cast<uint4*>(da) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+        *reinterpret_cast<uint4*>(da + D3_PLANE) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+        *reinterpret_cast<uint4*>(da + 2 * D3_PLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+        unsigned short* db = Bs + buf * 3 * D3_PLANE + sdst;
+        *reinterpret_cast<uint4*>(db) = rb0;
+        *reinterpret_cast<uint4*>(db + D3_PLANE) = rb1;
+        *reinterpret_cast<uint4*>(db + 2 * D3_PLANE) = rb2;
+    };
+
+    f32x4 acc[MI][MJ], small[MI][MJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; small[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    auto multiply = [&](int buf) __attribute__((always_inline)) {
+        const unsigned short* Ab = As + buf * 3 * D3_PLANE + (wr * 64 + fi) * X3_RS + 8 * fk;
+        const unsigned short* Bb = Bs + buf * 3 * D3_PLANE + (wc * 32 + fi) * X3_RS + 8 * fk;
+        bf16x8 b0[MJ], b1[MJ], b2[MJ], ax[MI];
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            b0[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 16 * X3_RS);
+            b1[j] = *reinterpret_cast<const bf16x8*>(Bb + D3_PLANE + j * 16 * X3_RS);
+            b2[j] = *reinterpret_cast<const bf16x8*>(Bb + 2 * D3_PLANE + j * 16 * X3_RS);
+        }
+#if D3_EAGER_A
+        bf16x8 a0[MI], a1[MI], a2[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            a0[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 16 * X3_RS);
+            a1[i] = *reinterpret_cast<const bf16x8*>(Ab + D3_PLANE + i * 16 * X3_RS);
+            a2[i] = *reinterpret_cast<const bf16x8*>(Ab + 2 * D3_PLANE + i * 16 * X3_RS);
+        }
+#define ADKF_D3_TERM(dst_, aq_, bq_)                                                                      \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < MJ; ++j)       \
+        dst_[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq_[i], bq_[j], dst_[i][j], 0, 0, 0);
+        ADKF_D3_TERM(small, a2, b0) ADKF_D3_TERM(small, a1, b1) ADKF_D3_TERM(small, a0, b2)
+        ADKF_D3_TERM(small, a1, b0) ADKF_D3_TERM(small, a0, b1) ADKF_D3_TERM(acc, a0, b0)
+        (void)ax;
+#else
+#define ADKF_D3_LOADA(q_) _Pragma("unroll") for (int i = 0; i < MI; ++i) ax[i] = *reinterpret_cast<const bf16x8*>(Ab + (q_) * D3_PLANE + i * 16 * X3_RS);
+#define ADKF_D3_TERM(dst_, bq_)                                                                           \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < MJ; ++j)       \
+        dst_[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[i], bq_[j], dst_[i][j], 0, 0, 0);
+        ADKF_D3_LOADA(2) ADKF_D3_TERM(small, b0)                               // x2 y0
+        ADKF_D3_LOADA(1) ADKF_D3_TERM(small, b1) ADKF_D3_TERM(small, b0)       // x1 y1, x1 y0
+        ADKF_D3_LOADA(0) ADKF_D3_TERM(small, b2) ADKF_D3_TERM(small, b1) ADKF_D3_TERM(acc, b0)   // x0 y2, x0 y1, x0 y0
+#undef ADKF_D3_LOADA
+#endif
+#undef ADKF_D3_TERM
+#undef ADKF_D3_LOADA
+    };
+
+    const int nc = a.K / GK;
+    fetch(0);
+    stage(0);
+    if (nc > 1) fetch(GK);
+    __syncthreads();
+    const bool stage_first = D3_PINGPONG ? wv < 4 : true;   // the two waves of a SIMD (wv, wv + 4) take the halves of an iteration in opposite order
+    for (int c = 0; c < nc; ++c) {
+        const int cur = c & 1;
+        if (stage_first) {
+            if (c + 1 < nc) { stage(cur ^ 1); if (c + 2 < nc) fetch((c + 2) * GK); }
+            multiply(cur);
+        } else {
+            multiply(cur);
+            if (c + 1 < nc) { stage(cur ^ 1); if (c + 2 < nc) fetch((c + 2) * GK); }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D map col = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            const int gi0 = m0 + wr * 64 + i * 16 + fk * 4, gj = n0 + wc * 32 + j * 16 + fi;
+            if (gj >= a.N) continue;
+            const float bv = a.bias ? a.bias[gj] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (gi0 + r < a.M) a.C[(size_t)(gi0 + r) * a.ldc + gj] = (acc[i][j][r] + small[i][j][r]) + bv;
+        }
+}
+
+}  // namespace adkf

@@ -30,6 +30,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import dense
+
 SMALL_NUMBER = 1e-7
 _FUSED_BLOCK = __import__("os").environ.get("ADKF_GNN_FUSED_BLOCK", "1") != "0"   # diagnostics: 0 keeps the PyTorch ops in the middle of a block
 _FUSED_MP = __import__("os").environ.get("ADKF_GNN_FUSED_MP", "1") != "0"   # diagnostics: 0 keeps message functions and aggregation as two autograd nodes
@@ -481,7 +483,7 @@ class BOOMLayer(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):
-        return self.linear2(self.dropout(F.leaky_relu(self.linear1(x))))
+        return dense.linear(self.dropout(F.leaky_relu(self.linear1(x))), self.linear2.weight, self.linear2.bias)
 
 
 class GNNBlock(nn.Module):
@@ -508,7 +510,7 @@ class GNNBlock(nn.Module):
             # per-node combination, instead of writing and re-reading the [V, H 12m] (3072-wide) concatenation
             H, q, hid = self.mp.H, 4 * self.mp.msg, self.config.hidden_dim
             w = self.msg_out_projection.weight.view(hid, H, 3, q).permute(2, 0, 1, 3).reshape(3 * hid, H * q)
-            p = F.linear(self.mp(x, plan, scale=False), w)
+            p = dense.linear(self.mp(x, plan, scale=False), w)
             fused = (_FUSED_BLOCK and x.is_cuda and x.dtype == torch.float32 and self.config.use_rezero_scaling and self.boom_layer is not None
                      and self.config.dropout_rate == 0.0 and hid % 64 == 0 and hid <= 256 and isinstance(self.boom_norm_layer, nn.LayerNorm))
             if fused:
@@ -699,7 +701,7 @@ class CombinedGraphReadout(nn.Module):
 
     def forward(self, node_embeddings: torch.Tensor, node_to_graph_id: torch.Tensor, num_graphs: int, plan: Optional[_GraphPlan] = None) -> torch.Tensor:
         V, hid = node_embeddings.shape[0], self.nh * self.hd
-        h = F.relu(self.first(node_embeddings))
+        h = F.relu(dense.linear(node_embeddings, self.first.weight, self.first.bias))
         h_ms, h_mv, h_ss, h_sv = h.split(hid, dim=1)
         if node_embeddings.is_cuda and node_embeddings.dtype == torch.float32 and self.nh <= 64:
             # GPU: one fused, order-fixed pooling kernel (no fallback: a missing library raises); more than 64 heads

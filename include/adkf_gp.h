@@ -313,6 +313,20 @@ int adkf_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const
                         float scale, float clip, double lr, double beta1, double beta2, double eps, double weight_decay,
                         int32_t step, void* stream);
 
+/* a1 / a2 (the dense layers of the feature extractor and of the fc head: torch.nn.Linear, fs_mol/modules/gnn.py:477-515,
+ * fs_mol/modules/graph_readout.py, fs_mol/models/adaptive_dkt.py:50-65) with FP32 products on the BF16 matrix pipe (csrc/dense_x3.h,
+ * csrc/gemm_x3.h: a float is the exact sum of three bfloat16 values; six BF16 MFMAs per product block; errors below the FP32 GEMM's).
+ *   adkf_split_planes         planes[q][r][k], q = 0..2: the three bfloat16 pieces of x[r][k] (x0 = bf16(x), x1 = bf16(x - x0), x2 = the rest:
+ *                       their sum is x exactly).  `planes`: 3 * rows * K uint16, 16-byte aligned; K even.
+ *   adkf_dense_forward  y[M, N] = x[M, K] w[N, K]^T (+ bias[N]): torch's F.linear, with w given as the planes adkf_split_planes wrote
+ *                       (weights are split once per update, activations on the fly).  K a multiple of 32; ldx, ldy the row strides
+ *                       of x, y in floats (ldx a multiple of 4); x, y, w_planes 16-byte aligned.  The backward product with respect to x is
+ *                       the same call on the planes of w^T.  Returns ADKF_E_LAUNCH when the device refuses the kernel's 120 KB of
+ *                       dynamic LDS. */
+int adkf_split_planes(const float* x, uint16_t* planes, int64_t rows, int64_t K, void* stream);
+int adkf_dense_forward(const float* x, int32_t ldx, const uint16_t* w_planes, const float* bias, float* y, int32_t ldy, int32_t M,
+                       int32_t N, int32_t K, void* stream);
+
 /* Synchronises `stream`, then returns 0 or (index+1) of the first task with info != 0. */
 int adkf_check_info(const int32_t* info, int32_t T, void* stream);
 

@@ -1,0 +1,67 @@
+"""GPU: the dense layer on the BF16 matrix pipe (csrc/dense_x3.h through adkf_dense_forward) against float64 and against F.linear."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("M,K,N,bias", [(4096, 512, 64, True), (5000, 1408, 3072, True), (4099, 1024, 384, False), (8192, 1024, 128, True)])
+def test_linear_matches_float64_at_least_as_well_as_the_library_gemm(dev, M, K, N, bias, monkeypatch):
+    from adkf_ift_amd import dense
+
+    monkeypatch.setattr(dense, "MIN_N", 64)    # (the kernel takes any width; linear() only sends it the wide ones, where it pays)
+
+    g = torch.Generator(device="cpu").manual_seed(M + K + N)
+    x = (torch.randn(M, K, generator=g) * 1.5).to(dev).requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(dev).requires_grad_(True) if bias else None
+    gy = torch.randn(M, N, generator=g).to(dev)
+    assert dense.takes_hip_kernel(x, w)
+    y = dense.linear(x, w, b)
+    gx, gw, *gb = torch.autograd.grad(y, [x, w] + ([b] if bias else []), gy)
+    y0 = F.linear(x, w, b)
+    gx0, gw0, *gb0 = torch.autograd.grad(y0, [x, w] + ([b] if bias else []), gy)
+    xd, wd, gyd = x.detach().double(), w.detach().double(), gy.double()
+    yr = xd @ wd.t() + (b.detach().double() if bias else 0.0)
+    gxr, gwr = gyd @ wd, gyd.t() @ xd
+    # error against float64, in units of sum_k |a_k||b_k| (what an FP32 inner product's rounding scales with)
+    sy = xd.abs() @ wd.abs().t() + 1e-30
+    sx = gyd.abs() @ wd.abs() + 1e-30
+    e_y, e_y0 = ((y.double() - yr).abs() / sy).max().item(), ((y0.double() - yr).abs() / sy).max().item()
+    e_x, e_x0 = ((gx.double() - gxr).abs() / sx).max().item(), ((gx0.double() - gxr).abs() / sx).max().item()
+    assert e_y <= 5e-7 and e_x <= 5e-7, (e_y, e_x)                 # FP32 accuracy (the library product itself reaches 3e-7 on these shapes) ...
+    assert e_y <= 1.5 * e_y0 + 1e-8 and e_x <= 1.5 * e_x0 + 1e-8, (e_y, e_y0, e_x, e_x0)   # ... at least the library's
+    assert torch.allclose(gw, gw0, rtol=1e-5, atol=1e-5 * gw0.abs().max().item())          # (the same library product either way)
+    if bias:
+        assert torch.allclose(gb[0], gb0[0], rtol=1e-5, atol=1e-4)
+
+
+def test_small_and_odd_shapes_take_the_library(dev):
+    from adkf_ift_amd import dense
+
+    x = torch.randn(100, 512, device=dev)
+    assert not dense.takes_hip_kernel(x, torch.randn(64, 512, device=dev))                              # few rows
+    assert not dense.takes_hip_kernel(torch.randn(8192, 100, device=dev), torch.randn(64, 100, device=dev))   # K not a multiple of 32
+    y = dense.linear(x, torch.ones(64, 512, device=dev))
+    assert y.shape == (100, 64)
+
+
+def test_non_contiguous_rows_are_handled(dev, monkeypatch):
+    from adkf_ift_amd import dense
+
+    monkeypatch.setattr(dense, "MIN_N", 64)
+
+    big = torch.randn(6000, 2048, device=dev)
+    x = big[:, 512:1536]                       # row stride 2048, 16-byte aligned start
+    w = torch.randn(128, 1024, device=dev) / 32
+    assert dense.takes_hip_kernel(x, w)
+    y = dense.linear(x, w)
+    ref = (x.double() @ w.double().t())
+    assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 1e-6
