@@ -1373,6 +1373,48 @@ int adkf_dense_forward(const float* x, int32_t ldx, const uint16_t* w_planes, co
     return 0;
 }
 
+// row ranges of the weight gradient: enough workgroups for ~4 rounds of the chip, ranges a multiple of the chunk, at most 64 of them
+static int dense_tn_splits(int M, int N, int K, int* rows_per_split) {
+    const long long tiles = (long long)ceil_div(N, D3_TM) * ceil_div(K, D3_TN);
+    long long s = (4LL * num_cus() + tiles - 1) / tiles;
+    const long long max_s = (M + 4 * GK - 1) / (4 * GK);          // at least four chunks per range
+    if (s > max_s) s = max_s;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    int rps = (int)((M + s - 1) / s);
+    rps = (rps + GK - 1) / GK * GK;
+    *rows_per_split = rps;
+    return ceil_div(M, rps);
+}
+
+size_t adkf_dense_weight_grad_scratch_bytes(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    int rps;
+    const int splits = dense_tn_splits(M, N, K, &rps);
+    return sizeof(float) * (size_t)splits * (size_t)N * (size_t)K;
+}
+
+int adkf_dense_weight_grad(const float* g, int32_t ldg, const float* x, int32_t ldx, float* dw, int32_t M, int32_t N, int32_t K,
+                           void* scratch, size_t scratch_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!g || !x || !dw || !scratch || M <= 0 || N <= 0 || K <= 0 || ldg < N || ldx < K) return ADKF_E_BADARG;
+    if (scratch_bytes < adkf_dense_weight_grad_scratch_bytes(M, N, K)) return ADKF_E_WORKSPACE;
+    static const bool optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense3_tn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  D3_LDS_BYTES) == hipSuccess;
+    if (!optin) { g_last_hip_error = hipErrorInvalidValue; (void)hipGetLastError(); return ADKF_E_LAUNCH; }
+    int rps;
+    const int splits = dense_tn_splits(M, N, K, &rps);
+    const long long tiles = (long long)ceil_div(N, D3_TM) * ceil_div(K, D3_TN);
+    if (tiles > 0x7fffffffLL) return ADKF_E_SIZE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Dense3TnArgs a{g, ldg, x, ldx, static_cast<float*>(scratch), M, N, K, rps};
+    k_dense3_tn<<<dim3((unsigned)tiles, (unsigned)splits), D3_NT, D3_LDS_BYTES, st>>>(a);
+    const size_t n = (size_t)N * (size_t)K;
+    k_dense3_reduce<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(static_cast<const float*>(scratch), dw, n, splits);
+    LAUNCH_OK();
+    return 0;
+}
+
 int adkf_grad_sumsq(const float* g, int64_t n, float* partials, void* stream) {
     (void)hipGetLastError();
     if (!g || !partials || n <= 0 || (reinterpret_cast<uintptr_t>(g) & 15)) return ADKF_E_BADARG;

@@ -163,4 +163,128 @@ __global__ __launch_bounds__(D3_NT) void k_dense3(Dense3Args a) {
         }
 }
 
+// ---- k_dense3_tn: the weight gradient dW[N, K] = G[M, N]^T X[M, K] (contraction over the ROWS of both operands) ----------------------
+// Same tile, waves, product scheme and pipeline as k_dense3.  Both operands are activations (split on the fly) and both are strided
+// along the contraction, so each lane takes a COLUMN (of G for the A image, of X for the B image) and eight consecutive rows of it per
+// chunk: eight scalar loads, each a coalesced 256-byte row segment across the wave, and the lane holds exactly the k run its LDS row
+// wants (one 16-byte store per plane; gemm_x3.h's column staging).  The contraction is long (all rows) and the output small, so it is
+// cut into `splits` row ranges (blockIdx.y) whose partial products go to part[split][N][K]; k_dense3_reduce adds them in a fixed order
+// (no atomics: bit-reproducible).  Rows beyond M are read clamped and contribute zeros.
+struct Dense3TnArgs {
+    const float* G; int ldg;      // [M, N]
+    const float* X; int ldx;      // [M, K]
+    float* part;                  // [splits, N, K]
+    int M, N, K, rows_per_split;  // rows_per_split a multiple of 32
+};
+
+__global__ __launch_bounds__(D3_NT) void k_dense3_tn(Dense3TnArgs a) {
+    constexpr int MI = 4, MJ = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 2, wc = wv & 3;
+    const int fi = lane & 15, fk = lane >> 4;
+    const int tiles_k = (a.K + D3_TN - 1) / D3_TN;
+    const int n0 = (blockIdx.x / tiles_k) * D3_TM, k0 = (blockIdx.x % tiles_k) * D3_TN;   // output tile: rows n0.. of dW, columns k0..
+    const int r_begin = blockIdx.y * a.rows_per_split, r_end = min(a.M, r_begin + a.rows_per_split);
+    unsigned short* const As = d3_lds;
+    unsigned short* const Bs = d3_lds + 2 * 3 * D3_PLANE;
+
+    const int sc = tid & 127, srun = (tid >> 7) * 8;     // this lane's column of the tile and its run of eight rows inside a chunk
+    const float* gp = a.G + (n0 + sc < a.N ? n0 + sc : 0);
+    const float* xp = a.X + (k0 + sc < a.K ? k0 + sc : 0);
+    const int sdst = sc * X3_RS + srun;
+
+    float rg[8], rx[8];
+    auto fetch = [&](int row0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = row0 + srun + q;
+            const int rc = r < r_end ? r : r_end - 1;
+            const float g = gp[(size_t)rc * a.ldg], x = xp[(size_t)rc * a.ldx];
+            rg[q] = r < r_end ? g : 0.f; rx[q] = r < r_end ? x : 0.f;
+        }
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        uint32_t p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) x3_split2(rg[2 * h], rg[2 * h + 1], p0[h], p1[h], p2[h]);
+        unsigned short* da = As + buf * 3 * D3_PLANE + sdst;
+        *reinterpret_cast<uint4*>(da) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+        *reinterpret_cast<uint4*>(da + D3_PLANE) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+        *reinterpret_cast<uint4*>(da + 2 * D3_PLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) x3_split2(rx[2 * h], rx[2 * h + 1], p0[h], p1[h], p2[h]);
+        unsigned short* db = Bs + buf * 3 * D3_PLANE + sdst;
+        *reinterpret_cast<uint4*>(db) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+        *reinterpret_cast<uint4*>(db + D3_PLANE) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+        *reinterpret_cast<uint4*>(db + 2 * D3_PLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+    };
+
+    f32x4 acc[MI][MJ], small[MI][MJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; small[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    auto multiply = [&](int buf) __attribute__((always_inline)) {
+        const unsigned short* Ab = As + buf * 3 * D3_PLANE + (wr * 64 + fi) * X3_RS + 8 * fk;
+        const unsigned short* Bb = Bs + buf * 3 * D3_PLANE + (wc * 32 + fi) * X3_RS + 8 * fk;
+        bf16x8 b0[MJ], b1[MJ], b2[MJ], ax[MI];
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            b0[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 16 * X3_RS);
+            b1[j] = *reinterpret_cast<const bf16x8*>(Bb + D3_PLANE + j * 16 * X3_RS);
+            b2[j] = *reinterpret_cast<const bf16x8*>(Bb + 2 * D3_PLANE + j * 16 * X3_RS);
+        }
+#define ADKF_D3_LOADA(q_) _Pragma("unroll") for (int i = 0; i < MI; ++i) ax[i] = *reinterpret_cast<const bf16x8*>(Ab + (q_) * D3_PLANE + i * 16 * X3_RS);
+#define ADKF_D3_TERM(dst_, bq_)                                                                           \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < MJ; ++j)       \
+        dst_[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[i], bq_[j], dst_[i][j], 0, 0, 0);
+        ADKF_D3_LOADA(2) ADKF_D3_TERM(small, b0)
+        ADKF_D3_LOADA(1) ADKF_D3_TERM(small, b1) ADKF_D3_TERM(small, b0)
+        ADKF_D3_LOADA(0) ADKF_D3_TERM(small, b2) ADKF_D3_TERM(small, b1) ADKF_D3_TERM(acc, b0)
+#undef ADKF_D3_TERM
+#undef ADKF_D3_LOADA
+    };
+
+    const int nc = r_end > r_begin ? (r_end - r_begin + GK - 1) / GK : 0;
+    if (nc > 0) {
+        fetch(r_begin);
+        stage(0);
+        if (nc > 1) fetch(r_begin + GK);
+        __syncthreads();
+        const bool stage_first = wv < 4;
+        for (int c = 0; c < nc; ++c) {
+            const int cur = c & 1;
+            if (stage_first) {
+                if (c + 1 < nc) { stage(cur ^ 1); if (c + 2 < nc) fetch(r_begin + (c + 2) * GK); }
+                multiply(cur);
+            } else {
+                multiply(cur);
+                if (c + 1 < nc) { stage(cur ^ 1); if (c + 2 < nc) fetch(r_begin + (c + 2) * GK); }
+            }
+            __syncthreads();
+        }
+    }
+    float* out = a.part + (size_t)blockIdx.y * a.N * a.K;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            const int gi0 = n0 + wr * 64 + i * 16 + fk * 4, gj = k0 + wc * 32 + j * 16 + fi;
+            if (gj >= a.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (gi0 + r < a.N) out[(size_t)(gi0 + r) * a.K + gj] = acc[i][j][r] + small[i][j][r];
+        }
+}
+
+// dW = part[0] + part[1] + ... in that order
+__global__ void k_dense3_reduce(const float* __restrict__ part, float* __restrict__ dw, size_t n, int splits) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = part[i];
+    for (int q = 1; q < splits; ++q) s += part[(size_t)q * n + i];
+    dw[i] = s;
+}
+
 }  // namespace adkf

@@ -12,6 +12,9 @@ import torch
 import torch.nn.functional as F
 
 ENABLED = os.environ.get("ADKF_X3_DENSE", "1") != "0"
+# the weight gradient on the BF16 pipe as well (k_dense3_tn): measured EQUAL to the library GEMM on the C3 step (51.0 - 51.1 ms either way,
+# tools/r05_dense.sh), so the library product stays the default; 1 selects the kernel (fixed-order partial sums: bit-reproducible)
+WEIGHT_GRAD = os.environ.get("ADKF_X3_DENSE_WGRAD", "0") == "1"
 MIN_ROWS, MIN_K, MIN_N = 4096, 512, 128   # measured at C3 (tools/r05_dense.sh): 52.1 -> 50.9 ms per step with every such layer, 51.2 with the wide (>= 512) ones only
 
 
@@ -36,6 +39,21 @@ def _dense(x: torch.Tensor, planes: torch.Tensor, bias, N: int) -> torch.Tensor:
                                       C.c_void_p(bias.data_ptr()) if bias is not None else None, C.c_void_p(y.data_ptr()), N, M, N, K, st),
                "adkf_dense_forward")
     return y
+
+
+def _weight_grad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """g^T x on the BF16 pipe (csrc/dense_x3.h::k_dense3_tn): row ranges, partial products added in a fixed order."""
+    from . import _lib
+    lib = _lib.load()
+    M, N = g.shape
+    K = x.shape[1]
+    dw = torch.empty(N, K, dtype=torch.float32, device=g.device)
+    need = lib.adkf_dense_weight_grad_scratch_bytes(M, N, K)
+    scratch = torch.empty(need, dtype=torch.uint8, device=g.device)
+    st = C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)
+    _lib.check(lib.adkf_dense_weight_grad(C.c_void_p(g.data_ptr()), g.stride(0), C.c_void_p(x.data_ptr()), x.stride(0), C.c_void_p(dw.data_ptr()),
+                                          M, N, K, C.c_void_p(scratch.data_ptr()), need, st), "adkf_dense_weight_grad")
+    return dw
 
 
 def _rows_ok(t: torch.Tensor) -> bool:
@@ -64,7 +82,7 @@ class _X3Linear(torch.autograd.Function):
             else:
                 gx = g2 @ weight
         if ctx.needs_input_grad[1]:
-            gw = g2.t() @ x
+            gw = _weight_grad(g2, x) if WEIGHT_GRAD else g2.t() @ x
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum(0)
         return gx, gw, gb

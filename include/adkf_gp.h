@@ -326,6 +326,12 @@ int adkf_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const
 int adkf_split_planes(const float* x, uint16_t* planes, int64_t rows, int64_t K, void* stream);
 int adkf_dense_forward(const float* x, int32_t ldx, const uint16_t* w_planes, const float* bias, float* y, int32_t ldy, int32_t M,
                        int32_t N, int32_t K, void* stream);
+ /*   adkf_dense_weight_grad  dw[N, K] = g[M, N]^T x[M, K] (torch: g.t() @ x), the contraction over the rows cut into row ranges whose
+ *                       partial products are added in a fixed order (bit-reproducible); `scratch`: adkf_dense_weight_grad_scratch_bytes(M, N, K)
+ *                       bytes.  Any M, N, K; ldg, ldx the row strides of g, x in floats. */
+size_t adkf_dense_weight_grad_scratch_bytes(int32_t M, int32_t N, int32_t K);
+int adkf_dense_weight_grad(const float* g, int32_t ldg, const float* x, int32_t ldx, float* dw, int32_t M, int32_t N, int32_t K,
+                           void* scratch, size_t scratch_bytes, void* stream);
 
 /* Synchronises `stream`, then returns 0 or (index+1) of the first task with info != 0. */
 int adkf_check_info(const int32_t* info, int32_t T, void* stream);

@@ -17,6 +17,7 @@ def test_linear_matches_float64_at_least_as_well_as_the_library_gemm(dev, M, K, 
     from adkf_ift_amd import dense
 
     monkeypatch.setattr(dense, "MIN_N", 64)    # (the kernel takes any width; linear() only sends it the wide ones, where it pays)
+    monkeypatch.setattr(dense, "WEIGHT_GRAD", True)   # (off by default: no faster than the library product)
 
     g = torch.Generator(device="cpu").manual_seed(M + K + N)
     x = (torch.randn(M, K, generator=g) * 1.5).to(dev).requires_grad_(True)
@@ -38,9 +39,23 @@ def test_linear_matches_float64_at_least_as_well_as_the_library_gemm(dev, M, K, 
     e_x, e_x0 = ((gx.double() - gxr).abs() / sx).max().item(), ((gx0.double() - gxr).abs() / sx).max().item()
     assert e_y <= 5e-7 and e_x <= 5e-7, (e_y, e_x)                 # FP32 accuracy (the library product itself reaches 3e-7 on these shapes) ...
     assert e_y <= 1.5 * e_y0 + 1e-8 and e_x <= 1.5 * e_x0 + 1e-8, (e_y, e_y0, e_x, e_x0)   # ... at least the library's
-    assert torch.allclose(gw, gw0, rtol=1e-5, atol=1e-5 * gw0.abs().max().item())          # (the same library product either way)
+    sw = gyd.abs().t() @ xd.abs() + 1e-30                       # the weight gradient: a contraction over all M rows, in row ranges
+    e_w, e_w0 = ((gw.double() - gwr).abs() / sw).max().item(), ((gw0.double() - gwr).abs() / sw).max().item()
+    assert e_w <= 1e-6 and e_w <= 1.5 * e_w0 + 1e-8, (e_w, e_w0)
     if bias:
         assert torch.allclose(gb[0], gb0[0], rtol=1e-5, atol=1e-4)
+
+
+def test_weight_gradient_is_reproducible_and_handles_ragged_sizes(dev):
+    from adkf_ift_amd import dense
+
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for M, N, K in ((5003, 200, 136), (4096, 128, 1024), (9999, 33, 70)):
+        gy, x = torch.randn(M, N, generator=g).to(dev), torch.randn(M, K, generator=g).to(dev)
+        a, b = dense._weight_grad(gy, x), dense._weight_grad(gy, x)
+        assert torch.equal(a, b)
+        ref = gy.double().t() @ x.double()
+        assert ((a.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6, (M, N, K)
 
 
 def test_small_and_odd_shapes_take_the_library(dev):
