@@ -71,6 +71,7 @@ class _X3Linear(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable   # (library calls inside: a second differentiation must fail loudly, not silently drop terms)
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g2 = g if _rows_ok(g) else g.contiguous()
