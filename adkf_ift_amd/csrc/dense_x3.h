@@ -12,6 +12,11 @@
 // Measured and not kept: a PERSISTENT form (one workgroup per CU walking its tiles with one pipeline over all their chunks, the next
 // tile's first chunks staged under the last ones of the current tile): 73.5 against 73.7 us at 65 536 x 256 x 256, 2.65 against 2.50 - 2.57 ms
 // at 56 554 x 3 072 x 1 408 - the short-K shape is bound by its 134 MB of HBM traffic plus the products, not by the tile boundaries.
+// What bounds it (tools/x3_gemm_bench.hip with -DD3_ABLATE builds, 56 554 x 3 072 x 1 408: 2.50 ms): without the MFMAs 1.86 ms, without the
+// operand loads after the first chunk 2.38, without the stores 2.42, with none of the three 0.73 - the operand traffic out of L2 (40 KB per
+// tile and chunk: 18.7 GB per call, ~10 TB/s while nothing else runs; 3.7 GB of it from beyond L2, rocprofv3 FETCH_SIZE) takes as long as
+// the products, and the two only partly overlap.  A second register set (loads three chunks ahead) changed nothing (2.54 ms); larger
+// tiles would (256 x 128 needs a swizzled 64-byte row stride to fit the double buffer into 160 KB) - not built.
 #pragma once
 #include "gemm_x3.h"
 
