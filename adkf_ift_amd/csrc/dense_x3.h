@@ -25,6 +25,9 @@ namespace adkf {
 #ifndef D3_PINGPONG
 #define D3_PINGPONG 1
 #endif
+#ifndef D3_ABLATE   // diagnostics (tools/x3_gemm_bench.hip): 1 no operand loads after the first chunk, 2 no stores of the result, 4 no MFMAs
+#define D3_ABLATE 0
+#endif
 #ifndef D3_EAGER_A
 #define D3_EAGER_A 0
 #endif
@@ -145,11 +148,11 @@ __global__ __launch_bounds__(D3_NT) void k_dense3(Dense3Args a) {
     for (int c = 0; c < nc; ++c) {
         const int cur = c & 1;
         if (stage_first) {
-            if (c + 1 < nc) { stage(cur ^ 1); if (c + 2 < nc) fetch((c + 2) * GK); }
-            multiply(cur);
+            if (c + 1 < nc) { stage(cur ^ 1); if (c + 2 < nc && !(D3_ABLATE & 1)) fetch((c + 2) * GK); }
+            if (!(D3_ABLATE & 4)) multiply(cur);
         } else {
-            multiply(cur);
-            if (c + 1 < nc) { stage(cur ^ 1); if (c + 2 < nc) fetch((c + 2) * GK); }
+            if (!(D3_ABLATE & 4)) multiply(cur);
+            if (c + 1 < nc) { stage(cur ^ 1); if (c + 2 < nc && !(D3_ABLATE & 1)) fetch((c + 2) * GK); }
         }
         __syncthreads();
     }
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(D3_NT) void k_dense3(Dense3Args a) {
         for (int j = 0; j < MJ; ++j) {
             const int gi0 = m0 + wr * 64 + i * 16 + fk * 4, gj = n0 + wc * 32 + j * 16 + fi;
             if (gj >= a.N) continue;
+            if ((D3_ABLATE & 2) && acc[i][j][0] != 123.456f) continue;
             const float bv = a.bias ? a.bias[gj] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
