@@ -40,7 +40,8 @@ class OracleBackend:
 def _run_rank(rank, world, port, fixture, ret, split=None, stated_total=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))   # (default: 30 min)
     torch.set_num_threads(1)
     g = np.load(fixture)
     T, N, d, kind = int(g["T"]), int(g["N"]), int(g["d"]), int(g["kind"])
