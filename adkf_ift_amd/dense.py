@@ -15,6 +15,7 @@ ENABLED = os.environ.get("ADKF_X3_DENSE", "1") != "0"
 # the weight gradient on the BF16 pipe as well (k_dense3_tn): measured EQUAL to the library GEMM on the C3 step (51.0 - 51.1 ms either way,
 # tools/r05_dense.sh), so the library product stays the default; 1 selects the kernel (fixed-order partial sums: bit-reproducible)
 WEIGHT_GRAD = os.environ.get("ADKF_X3_DENSE_WGRAD", "0") == "1"
+# (the fc head - 2 304 rows at C3 - measured on the kernel too: 51.1 -> 51.5 ms per step: its few row tiles do not fill the chip)
 MIN_ROWS, MIN_K, MIN_N = 4096, 512, 128   # measured at C3 (tools/r05_dense.sh): 52.1 -> 50.9 ms per step with every such layer, 51.2 with the wide (>= 512) ones only
 
 
