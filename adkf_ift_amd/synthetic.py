@@ -66,6 +66,9 @@ def make_tasks(T: int, N: int, d: int, N_q: Optional[int] = None, regression: bo
     return SyntheticTasks(torch.stack(Xs), torch.stack(Xq), torch.stack(ys), torch.stack(yq), W)
 
 
+_X3_DW = __import__("os").environ.get("ADKF_X3_DW", "1") != "0"   # A/B: 0 keeps the chunked bmm + sum
+
+
 class _ChunkedLinear(torch.autograd.Function):
     """Z = X W for rows X that already carry the 1 / sqrt(d) of the feature map (the inputs are constants: scaling them once
     replaces an element-wise pass over W before the forward product and one over dW behind the backward one, two launches
@@ -84,6 +87,10 @@ class _ChunkedLinear(torch.autograd.Function):
         ch = ctx.chunks
         R, d = X2.shape
         g = g.reshape(R, -1)
+        if _X3_DW and X2.is_cuda and X2.dtype == torch.float32 and g.dtype == torch.float32 and R >= 4096:
+            # the same row-range scheme in one kernel, on the BF16 matrix pipe at FP32 accuracy (csrc/dense_x3.h::k_dense3_tn)
+            from .dense import _weight_grad
+            return None, _weight_grad(X2.contiguous(), g.contiguous()), None
         if R % ch or ch == 1:
             return None, X2.t() @ g, None
         part = torch.bmm(X2.view(ch, R // ch, d).transpose(1, 2), g.view(ch, R // ch, -1))

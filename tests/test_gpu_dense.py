@@ -80,3 +80,22 @@ def test_non_contiguous_rows_are_handled(dev, monkeypatch):
     y = dense.linear(x, w)
     ref = (x.double() @ w.double().t())
     assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 1e-6
+
+
+def test_stand_in_feature_map_weight_gradient_both_ways(dev, monkeypatch):
+    """adkf_ift_amd.synthetic.LinearFeatureMap's dW = X^T dZ at the C2 shape: the row-range kernel against the chunked bmm + sum."""
+    from adkf_ift_amd import synthetic
+
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(2, 64, 128, 256, generator=g).to(dev)
+    W = (torch.randn(256, 256, generator=g) / 16).to(dev).requires_grad_(True)
+    gz = torch.randn(2, 64, 128, 256, generator=g).to(dev)
+    out = []
+    for flag in (True, False):
+        monkeypatch.setattr(synthetic, "_X3_DW", flag)
+        fm = synthetic.LinearFeatureMap(X[0], X[1], W)
+        (dW,) = torch.autograd.grad(fm(), [W], gz)
+        out.append(dW)
+    ref = (X.reshape(-1, 256).double() / 16.0).t() @ gz.reshape(-1, 256).double()
+    e = [((o.double() - ref).abs().max() / ref.abs().max()).item() for o in out]
+    assert e[0] < 2e-6 and e[0] <= 1.5 * e[1] + 1e-7, e
