@@ -291,8 +291,18 @@ __global__ __launch_bounds__(D3_NT) void k_dense3_tn(Dense3TnArgs a) {
 __global__ void k_dense3_reduce(const float* __restrict__ part, float* __restrict__ dw, size_t n, int splits) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // (the ORDER of the additions is fixed; the loads are independent and issued eight at a time - one by one, each waiting for the
+    // one before, the 64 ranges of the C2 feature map took 16.7 us)
     float s = part[i];
-    for (int q = 1; q < splits; ++q) s += part[(size_t)q * n + i];
+    int q = 1;
+    for (; q + 8 <= splits; q += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(q + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; q < splits; ++q) s += part[(size_t)q * n + i];
     dw[i] = s;
 }
 
