@@ -1356,6 +1356,13 @@ int adkf_split_planes(const float* x, uint16_t* planes, int64_t rows, int64_t K,
     return 0;
 }
 
+// ADKF_DENSE_STREAM=0 (read once): the forms of round 5's first sessions (k_dense3 for every K, k_dense3_tn) for A/B runs; results are
+// bit-identical either way
+static bool dense_stream_forms() {
+    static const bool on = [] { const char* e = getenv("ADKF_DENSE_STREAM"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int adkf_dense_forward(const float* x, int32_t ldx, const uint16_t* w_planes, const float* bias, float* y, int32_t ldy, int32_t M,
                        int32_t N, int32_t K, void* stream) {
     (void)hipGetLastError();
@@ -1368,6 +1375,23 @@ int adkf_dense_forward(const float* x, int32_t ldx, const uint16_t* w_planes, co
     const long long tiles = (long long)ceil_div(M, D3_TM) * ceil_div(N, D3_TN);
     if (tiles > 0x7fffffffLL) return ADKF_E_SIZE;
     Dense3Args a{x, ldx, w_planes, (size_t)N * (size_t)K, bias, y, ldy, M, N, K};
+    // short contractions over many rows: the persistent form that keeps a row tile's whole K extent in registers (bit-identical
+    // results; 79 -> 63 us at 65 536 x 256 x 256, tools/x3_stream_bench.hip)
+    const int tiles_m = ceil_div(M, D3_TM);
+    if ((K == 64 || K == 128 || K == 256) && tiles_m >= num_cus() && dense_stream_forms()) {
+        static const bool optin_sk = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense3_sk<2>), hipFuncAttributeMaxDynamicSharedMemorySize, D3_LDS_BYTES) == hipSuccess &&
+                                     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense3_sk<4>), hipFuncAttributeMaxDynamicSharedMemorySize, D3_LDS_BYTES) == hipSuccess &&
+                                     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense3_sk<8>), hipFuncAttributeMaxDynamicSharedMemorySize, D3_LDS_BYTES) == hipSuccess;
+        if (optin_sk) {
+            const unsigned grid = (unsigned)num_cus();
+            hipStream_t st = static_cast<hipStream_t>(stream);
+            if (K == 256) k_dense3_sk<8><<<grid, D3_NT, D3_LDS_BYTES, st>>>(a);
+            else if (K == 128) k_dense3_sk<4><<<grid, D3_NT, D3_LDS_BYTES, st>>>(a);
+            else k_dense3_sk<2><<<grid, D3_NT, D3_LDS_BYTES, st>>>(a);
+            LAUNCH_OK();
+            return 0;
+        }
+    }
     k_dense3<<<(unsigned)tiles, D3_NT, D3_LDS_BYTES, static_cast<hipStream_t>(stream)>>>(a);
     LAUNCH_OK();
     return 0;
@@ -1399,16 +1423,24 @@ int adkf_dense_weight_grad(const float* g, int32_t ldg, const float* x, int32_t 
     (void)hipGetLastError();
     if (!g || !x || !dw || !scratch || M <= 0 || N <= 0 || K <= 0 || ldg < N || ldx < K) return ADKF_E_BADARG;
     if (scratch_bytes < adkf_dense_weight_grad_scratch_bytes(M, N, K)) return ADKF_E_WORKSPACE;
-    static const bool optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense3_tn), hipFuncAttributeMaxDynamicSharedMemorySize,
+    // (k_dense3_tnd<4>: k_dense3_tn's products and row ranges with four chunks of operand loads in flight per lane and an XCD-aware
+    // workgroup order - bit-identical partial sums, 73 -> 60 us at the C2 feature map: tools/x3_stream_bench.hip)
+    static const bool optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense3_tnd<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   D3_LDS_BYTES) == hipSuccess;
     if (!optin) { g_last_hip_error = hipErrorInvalidValue; (void)hipGetLastError(); return ADKF_E_LAUNCH; }
     int rps;
     const int splits = dense_tn_splits(M, N, K, &rps);
     const long long tiles = (long long)ceil_div(N, D3_TM) * ceil_div(K, D3_TN);
-    if (tiles > 0x7fffffffLL) return ADKF_E_SIZE;
+    if (tiles * splits > 0x7fffffffLL) return ADKF_E_SIZE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     Dense3TnArgs a{g, ldg, x, ldx, static_cast<float*>(scratch), M, N, K, rps};
-    k_dense3_tn<<<dim3((unsigned)tiles, (unsigned)splits), D3_NT, D3_LDS_BYTES, st>>>(a);
+    static const bool stream_form = dense_stream_forms();
+    if (stream_form) k_dense3_tnd<4><<<(unsigned)(tiles * splits), D3_NT, D3_LDS_BYTES, st>>>(a, (int)tiles, splits);
+    else {
+        static const bool optin_tn = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense3_tn), hipFuncAttributeMaxDynamicSharedMemorySize, D3_LDS_BYTES) == hipSuccess;
+        if (!optin_tn) { g_last_hip_error = hipErrorInvalidValue; (void)hipGetLastError(); return ADKF_E_LAUNCH; }
+        k_dense3_tn<<<dim3((unsigned)tiles, (unsigned)splits), D3_NT, D3_LDS_BYTES, st>>>(a);
+    }
     const size_t n = (size_t)N * (size_t)K;
     k_dense3_reduce<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(static_cast<const float*>(scratch), dw, n, splits);
     LAUNCH_OK();

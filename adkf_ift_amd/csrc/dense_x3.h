@@ -287,6 +287,259 @@ __global__ __launch_bounds__(D3_NT) void k_dense3_tn(Dense3TnArgs a) {
         }
 }
 
+// ---- the streaming forms (round 5, last session): short contractions and the weight gradient are bound by LOAD LATENCY, not by traffic ---
+// At 65 536 x 256 x 256 (the C2 stand-in feature map) k_dense3 takes 74 us and k_dense3_tn 67.5: 1.8 TB/s of an 8 TB/s memory and a
+// third of the matrix-pipe rate.  Both have ONE chunk of operand loads in flight per lane (16 - 32 KB per CU, 4 - 8 MB over the chip,
+// where ~16 MB are needed to cover a 2 us trip to HBM at full rate): with eight chunks per tile, or every chunk's operands coming from
+// HBM, each chunk pays most of a memory round trip (8 x 2 us + epilogue = the 18.5 us a workgroup takes).
+//
+#ifndef D3S_ABLATE   // diagnostics (tools/x3_stream_bench.hip): 1 no operand loads behind the prologue, 2 no stores of the result, 4 no MFMAs, 8 no LDS stores of the staging
+#define D3S_ABLATE 0
+#endif
+// d3_multiply: the product of one staged chunk (both kernels below; the same instruction order as k_dense3's).
+// SWAP: the MFMA takes the B fragment as its first operand, i.e. computes the transposed 16 x 16 block - the same products summed in the same
+// order, but a lane then holds FOUR CONSECUTIVE COLUMNS of one output row (row = lane & 15, columns 4 (lane >> 4) + reg): one 16-byte store
+// instead of four 4-byte ones.
+template <bool SWAP = false>
+__device__ __forceinline__ void d3_multiply(const unsigned short* Ab, const unsigned short* Bb, f32x4 (&acc)[4][2], f32x4 (&small)[4][2]) {
+    constexpr int MI = 4, MJ = 2;
+    bf16x8 b0[MJ], b1[MJ], b2[MJ], ax[MI];
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+        b0[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 16 * X3_RS);
+        b1[j] = *reinterpret_cast<const bf16x8*>(Bb + D3_PLANE + j * 16 * X3_RS);
+        b2[j] = *reinterpret_cast<const bf16x8*>(Bb + 2 * D3_PLANE + j * 16 * X3_RS);
+    }
+#define ADKF_D3_LOADA(q_) _Pragma("unroll") for (int i = 0; i < MI; ++i) ax[i] = *reinterpret_cast<const bf16x8*>(Ab + (q_) * D3_PLANE + i * 16 * X3_RS);
+#define ADKF_D3_TERM(dst_, bq_)                                                                           \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < MJ; ++j)       \
+        dst_[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq_[j], ax[i], dst_[i][j], 0, 0, 0)  \
+                          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[i], bq_[j], dst_[i][j], 0, 0, 0);
+    if (D3S_ABLATE & 4) return;
+    ADKF_D3_LOADA(2) ADKF_D3_TERM(small, b0)
+    ADKF_D3_LOADA(1) ADKF_D3_TERM(small, b1) ADKF_D3_TERM(small, b0)
+    ADKF_D3_LOADA(0) ADKF_D3_TERM(small, b2) ADKF_D3_TERM(small, b1) ADKF_D3_TERM(acc, b0)
+#undef ADKF_D3_TERM
+#undef ADKF_D3_LOADA
+}
+
+// k_dense3_sk<NC>: C = A B^T (+ bias) for a SHORT contraction K = 32 NC (NC <= 8) and many rows.  Persistent: workgroup b walks the row
+// tiles b, b + grid, ...; a row tile's WHOLE K extent of A sits in registers (NC x 8 floats per lane), is staged chunk by chunk for
+// each column tile in turn, and - during the pass over the last column tile - every register set is refilled with the NEXT row tile's
+// chunk as soon as it has been staged for the last time: A is read from HBM once, NC chunks (a whole tile pass) ahead of its use, and
+// the chunk pipeline (double-buffered LDS, one barrier per chunk, ping-pong waves: k_dense3's) runs through tile boundaries without
+// draining.  B (pre-split planes, small, L2-resident) keeps its one-chunk-ahead fetch.  The result of a tile goes out between two
+// chunks of the pipeline (registers only).  Same products in the same order as k_dense3: bit-identical results.
+template <int NC>
+__global__ __launch_bounds__(D3_NT) void k_dense3_sk(Dense3Args a) {
+    static_assert(NC >= 2 && NC <= 8, "K = 32 NC, 64 .. 256");
+    constexpr int MI = 4, MJ = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 2, wc = wv & 3;
+    const int fi = lane & 15, fk = lane >> 4;
+    const int tiles_m = (a.M + D3_TM - 1) / D3_TM, tiles_n = (a.N + D3_TN - 1) / D3_TN;
+    unsigned short* const As = d3_lds;
+    unsigned short* const Bs = d3_lds + 2 * 3 * D3_PLANE;
+    const int sr = tid >> 2, sk = (tid & 3) * 8, sdst = sr * X3_RS + sk;
+    const int frag_a = (wr * 64 + fi) * X3_RS + 8 * fk, frag_b = (wc * 32 + fi) * X3_RS + 8 * fk;
+
+    int mt = blockIdx.x, nt = 0;
+    if (mt >= tiles_m) return;
+    float4 ra[NC][2]; uint4 rb0, rb1, rb2;
+    // (rows / columns beyond M / N read row 0 instead - valid memory - as in k_dense3: they only reach outputs that are not stored)
+    auto a_row = [&](int mt_) { const int r = mt_ * D3_TM + sr; return a.A + (size_t)(r < a.M ? r : 0) * a.lda + sk; };
+    auto b_row = [&](int nt_) { const int r = nt_ * D3_TN + sr; return a.Bp + (size_t)(r < a.N ? r : 0) * a.K + sk; };
+    auto fetch_a = [&](const float* ap, int c) __attribute__((always_inline)) {
+        ra[c][0] = *reinterpret_cast<const float4*>(ap + c * GK); ra[c][1] = *reinterpret_cast<const float4*>(ap + c * GK + 4);
+    };
+    auto fetch_b = [&](const unsigned short* bp, int c) __attribute__((always_inline)) {
+        rb0 = *reinterpret_cast<const uint4*>(bp + c * GK); rb1 = *reinterpret_cast<const uint4*>(bp + a.b_plane + c * GK);
+        rb2 = *reinterpret_cast<const uint4*>(bp + 2 * a.b_plane + c * GK);
+    };
+    auto stage = [&](int buf, int c) __attribute__((always_inline)) {
+        if (D3S_ABLATE & 8) return;
+        uint32_t p0[4], p1[4], p2[4];
+        x3_split2(ra[c][0].x, ra[c][0].y, p0[0], p1[0], p2[0]); x3_split2(ra[c][0].z, ra[c][0].w, p0[1], p1[1], p2[1]);
+        x3_split2(ra[c][1].x, ra[c][1].y, p0[2], p1[2], p2[2]); x3_split2(ra[c][1].z, ra[c][1].w, p0[3], p1[3], p2[3]);
+        unsigned short* da = As + buf * 3 * D3_PLANE + sdst;
+        *reinterpret_cast<uint4*>(da) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+        *reinterpret_cast<uint4*>(da + D3_PLANE) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+        *reinterpret_cast<uint4*>(da + 2 * D3_PLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+        unsigned short* db = Bs + buf * 3 * D3_PLANE + sdst;
+        *reinterpret_cast<uint4*>(db) = rb0;
+        *reinterpret_cast<uint4*>(db + D3_PLANE) = rb1;
+        *reinterpret_cast<uint4*>(db + 2 * D3_PLANE) = rb2;
+    };
+
+    const unsigned short* bp = b_row(0);
+    {
+        const float* ap = a_row(mt);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) fetch_a(ap, c);
+    }
+    fetch_b(bp, 0);
+    stage(0, 0);
+    fetch_b(bp, 1);
+    __syncthreads();
+    const bool stage_first = wv < 4;
+    const bool c_vec = !(a.ldc & 3) && !(reinterpret_cast<uintptr_t>(a.C) & 15);   // 16-byte stores of the result
+    int p = 0;
+    for (;;) {   // one output tile (mt, nt) per trip
+        const bool last_n = nt + 1 == tiles_n;
+        const int nt2 = last_n ? 0 : nt + 1, mt2 = last_n ? mt + (int)gridDim.x : mt;
+        const bool have2 = mt2 < tiles_m;            // there is a tile behind this one
+        const bool refill = last_n && have2;         // this pass is the last use of the row tile's registers
+        const unsigned short* bp2 = b_row(nt2);
+        const float* ap2 = a_row(have2 ? mt2 : mt);
+        f32x4 acc[MI][MJ], small[MI][MJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; small[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        if (refill && !(D3S_ABLATE & 1)) fetch_a(ap2, 0);   // (chunk 0 was staged for this tile in the previous trip)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int c1 = (c + 1) % NC, c2 = (c + 2) % NC;
+            const bool have_next = c + 1 < NC || have2;
+            auto advance = [&]() __attribute__((always_inline)) {
+                if (have_next) {
+                    stage(p ^ 1, c1);
+                    if (!(D3S_ABLATE & 1)) {
+                        if (refill && c1 != 0) fetch_a(ap2, c1);
+                        if (c + 2 < NC) fetch_b(bp, c2);
+                        else if (have2) fetch_b(bp2, c2);
+                    }
+                }
+            };
+            if (stage_first) { advance(); d3_multiply<true>(As + p * 3 * D3_PLANE + frag_a, Bs + p * 3 * D3_PLANE + frag_b, acc, small); }
+            else { d3_multiply<true>(As + p * 3 * D3_PLANE + frag_a, Bs + p * 3 * D3_PLANE + frag_b, acc, small); advance(); }
+            __syncthreads();
+            p ^= 1;
+        }
+        // the tile's result (transposed blocks: row = lane & 15, columns 4 (lane >> 4) + reg)
+        const int m0 = mt * D3_TM, n0 = nt * D3_TN;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int gi = m0 + wr * 64 + i * 16 + fi;
+            if (gi >= a.M) continue;
+            float* crow = a.C + (size_t)gi * a.ldc;
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) {
+                const int gj0 = n0 + wc * 32 + j * 16 + fk * 4;
+                if (gj0 >= a.N) continue;
+                if ((D3S_ABLATE & 2) && acc[i][j][0] != 123.456f) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (acc[i][j][r] + small[i][j][r]) + ((a.bias && gj0 + r < a.N) ? a.bias[gj0 + r] : 0.f);
+                if (c_vec && gj0 + 3 < a.N) *reinterpret_cast<float4*>(crow + gj0) = make_float4(o[0], o[1], o[2], o[3]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (gj0 + r < a.N) crow[gj0 + r] = o[r];
+                }
+            }
+        }
+        if (!have2) break;
+        mt = mt2; nt = nt2; bp = bp2;
+    }
+}
+
+// k_dense3_tnd<DEPTH>: k_dense3_tn with DEPTH chunks of operand loads in flight per lane (register sets used round robin; the chunk loop
+// is unrolled DEPTH times so that the sets are static), and an XCD-aware order of the workgroups: the output tiles of one row range
+// land on ONE XCD next to each other in time, so the second reader of an operand half finds it in that XCD's L2.  Products, chunk
+// order and row ranges are k_dense3_tn's: bit-identical partial sums.
+template <int DEPTH>
+__global__ __launch_bounds__(D3_NT) void k_dense3_tnd(Dense3TnArgs a, int tiles, int splits) {
+    constexpr int MI = 4, MJ = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 2, wc = wv & 3;
+    const int fi = lane & 15, fk = lane >> 4;
+    const int tiles_k = (a.K + D3_TN - 1) / D3_TN;
+    // workgroup id -> (tile, row range): ids b, b + 8, b + 16, ... share an XCD (round-robin dispatch); a multiple-of-8 prefix of the
+    // grid is renumbered XCD-major so that consecutive logical indices - the tiles of one row range - share an XCD
+    const int total = tiles * splits, per = total >> 3, b = blockIdx.x;
+    const int logical = b < 8 * per ? (b & 7) * per + (b >> 3) : b;
+    const int tile = logical % tiles, split = logical / tiles;
+    const int n0 = (tile / tiles_k) * D3_TM, k0 = (tile % tiles_k) * D3_TN;
+    const int r_begin = split * a.rows_per_split, r_end = min(a.M, r_begin + a.rows_per_split);
+    unsigned short* const As = d3_lds;
+    unsigned short* const Bs = d3_lds + 2 * 3 * D3_PLANE;
+    const int sc = tid & 127, srun = (tid >> 7) * 8;
+    const float* gp = a.G + (n0 + sc < a.N ? n0 + sc : 0);
+    const float* xp = a.X + (k0 + sc < a.K ? k0 + sc : 0);
+    const int sdst = sc * X3_RS + srun;
+    const int frag_a = (wr * 64 + fi) * X3_RS + 8 * fk, frag_b = (wc * 32 + fi) * X3_RS + 8 * fk;
+
+    float rg[DEPTH][8], rx[DEPTH][8];
+    auto fetch = [&](int set, int row0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = row0 + srun + q;
+            const int rc = r < r_end ? r : r_end - 1;
+            const float g = gp[(size_t)rc * a.ldg], x = xp[(size_t)rc * a.ldx];
+            rg[set][q] = r < r_end ? g : 0.f; rx[set][q] = r < r_end ? x : 0.f;
+        }
+    };
+    auto stage = [&](int buf, int set) __attribute__((always_inline)) {
+        if (D3S_ABLATE & 8) return;
+        uint32_t p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) x3_split2(rg[set][2 * h], rg[set][2 * h + 1], p0[h], p1[h], p2[h]);
+        unsigned short* da = As + buf * 3 * D3_PLANE + sdst;
+        *reinterpret_cast<uint4*>(da) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+        *reinterpret_cast<uint4*>(da + D3_PLANE) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+        *reinterpret_cast<uint4*>(da + 2 * D3_PLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) x3_split2(rx[set][2 * h], rx[set][2 * h + 1], p0[h], p1[h], p2[h]);
+        unsigned short* db = Bs + buf * 3 * D3_PLANE + sdst;
+        *reinterpret_cast<uint4*>(db) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+        *reinterpret_cast<uint4*>(db + D3_PLANE) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+        *reinterpret_cast<uint4*>(db + 2 * D3_PLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+    };
+
+    f32x4 acc[MI][MJ], small[MI][MJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; small[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int nc = r_end > r_begin ? (r_end - r_begin + GK - 1) / GK : 0;
+    if (nc > 0) {
+        // chunk q travels in set q % DEPTH; chunks 1 .. DEPTH are in flight when the loop starts
+#pragma unroll
+        for (int q = 0; q < DEPTH; ++q) if (q < nc) fetch(q, r_begin + q * GK);
+        stage(0, 0);
+        if (DEPTH < nc) fetch(0, r_begin + DEPTH * GK);
+        __syncthreads();
+        const bool stage_first = wv < 4;
+        for (int c0 = 0; c0 < nc; c0 += DEPTH) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                const int c = c0 + u;
+                if (c < nc) {   // (uniform over the workgroup: the barrier below is reached by everybody or nobody)
+                    const int cur = (DEPTH & 1) ? (c & 1) : (u & 1), set1 = (u + 1) % DEPTH;
+                    auto advance = [&]() __attribute__((always_inline)) {
+                        if (c + 1 < nc) { stage(cur ^ 1, set1); if (c + 1 + DEPTH < nc && !(D3S_ABLATE & 1)) fetch(set1, r_begin + (c + 1 + DEPTH) * GK); }
+                    };
+                    if (stage_first) { advance(); d3_multiply(As + cur * 3 * D3_PLANE + frag_a, Bs + cur * 3 * D3_PLANE + frag_b, acc, small); }
+                    else { d3_multiply(As + cur * 3 * D3_PLANE + frag_a, Bs + cur * 3 * D3_PLANE + frag_b, acc, small); advance(); }
+                    __syncthreads();
+                }
+            }
+        }
+    }
+    float* out = a.part + (size_t)split * a.N * a.K;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            const int gi0 = n0 + wr * 64 + i * 16 + fk * 4, gj = k0 + wc * 32 + j * 16 + fi;
+            if (gj >= a.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (gi0 + r < a.N) out[(size_t)(gi0 + r) * a.K + gj] = acc[i][j][r] + small[i][j][r];
+        }
+}
+
 // dW = part[0] + part[1] + ... in that order
 __global__ void k_dense3_reduce(const float* __restrict__ part, float* __restrict__ dw, size_t n, int splits) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -43,7 +43,7 @@ def _dense(x: torch.Tensor, planes: torch.Tensor, bias, N: int) -> torch.Tensor:
 
 
 def _weight_grad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """g^T x on the BF16 pipe (csrc/dense_x3.h::k_dense3_tn): row ranges, partial products added in a fixed order."""
+    """g^T x on the BF16 pipe (csrc/dense_x3.h::k_dense3_tnd): row ranges, partial products added in a fixed order."""
     from . import _lib
     lib = _lib.load()
     M, N = g.shape

@@ -88,7 +88,7 @@ class _ChunkedLinear(torch.autograd.Function):
         R, d = X2.shape
         g = g.reshape(R, -1)
         if _X3_DW and X2.is_cuda and X2.dtype == torch.float32 and g.dtype == torch.float32 and R >= 4096:
-            # the same row-range scheme in one kernel, on the BF16 matrix pipe at FP32 accuracy (csrc/dense_x3.h::k_dense3_tn)
+            # the same row-range scheme in one kernel, on the BF16 matrix pipe at FP32 accuracy (csrc/dense_x3.h::k_dense3_tnd)
             from .dense import _weight_grad
             return None, _weight_grad(X2.contiguous(), g.contiguous()), None
         if R % ch or ch == 1:

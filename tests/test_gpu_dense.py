@@ -58,6 +58,30 @@ def test_weight_gradient_is_reproducible_and_handles_ragged_sizes(dev):
         assert ((a.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6, (M, N, K)
 
 
+@pytest.mark.parametrize("K,N,bias", [(256, 256, False), (256, 200, True), (128, 202, True), (64, 130, False)])
+def test_short_contraction_over_many_rows_takes_the_persistent_form(dev, K, N, bias):
+    """adkf_dense_forward with K in {64, 128, 256} and at least one row tile per CU runs k_dense3_sk (a row tile's whole K extent in
+    registers, tiles walked by a persistent workgroup, 16-byte stores of the transposed MFMA blocks; N = 202: the 4-byte store path):
+    FP32 accuracy against float64, ragged last row tile and last column tile, and the same bits as the tile-per-workgroup kernel
+    (which a batch of few rows still takes) on the rows both compute."""
+    from adkf_ift_amd import dense
+
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    M = cus * 128 + 77
+    g = torch.Generator(device="cpu").manual_seed(K + N)
+    x = (torch.randn(M, K, generator=g) * 1.5).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev) if bias else None
+    planes = dense._split(w)
+    y = dense._dense(x, planes, b, N)
+    ref = x.double() @ w.double().t() + (b.double() if bias else 0.0)
+    scale = x.double().abs() @ w.double().abs().t() + 1e-30
+    assert (((y.double() - ref).abs() / scale).max().item()) <= 5e-7
+    few = dense._dense(x[:1000].contiguous(), planes, b, N)     # 8 row tiles: the tile-per-workgroup kernel
+    assert torch.equal(few, y[:1000])
+    assert torch.equal(dense._dense(x, planes, b, N), y)
+
+
 def test_small_and_odd_shapes_take_the_library(dev):
     from adkf_ift_amd import dense
 
