@@ -82,6 +82,7 @@ SIGNATURES = {
     "adkf_block_combine_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "adkf_block_combine_backward": (C.c_int, [C.c_void_p] * 11 + [C.c_int32, C.c_int32] + [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]),
     "adkf_split_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "adkf_split_planes_t": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "adkf_dense_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_void_p]),
     "adkf_dense_weight_grad_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

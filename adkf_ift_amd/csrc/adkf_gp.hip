@@ -1356,8 +1356,19 @@ int adkf_split_planes(const float* x, uint16_t* planes, int64_t rows, int64_t K,
     return 0;
 }
 
-// ADKF_DENSE_STREAM=0 (read once): the forms of round 5's first sessions (k_dense3 for every K, k_dense3_tn) for A/B runs; results are
-// bit-identical either way
+int adkf_split_planes_t(const float* w, uint16_t* planes, int64_t K, int64_t N, void* stream) {
+    (void)hipGetLastError();
+    if (!w || !planes || K <= 0 || N <= 0 || (K & 1)) return ADKF_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(w) & 3) || (reinterpret_cast<uintptr_t>(planes) & 15) || ((N * K) & 7)) return ADKF_E_BADARG;
+    if (K > 0x7fffffffLL || N > 0x7fffffffLL) return ADKF_E_SIZE;
+    const size_t pairs = (size_t)(K / 2) * (size_t)N;
+    if (pairs > (size_t)0x7fffffff * 256) return ADKF_E_SIZE;
+    k_split3_t<<<(unsigned)((pairs + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(w, planes, (int)K, (int)N);
+    LAUNCH_OK();
+    return 0;
+}
+
+// ADKF_DENSE_STREAM=0 (read once): k_dense3 for every K (A/B runs against k_dense3_sk; bit-identical results)
 static bool dense_stream_forms() {
     static const bool on = [] { const char* e = getenv("ADKF_DENSE_STREAM"); return !(e && e[0] == '0'); }();
     return on;
@@ -1423,9 +1434,7 @@ int adkf_dense_weight_grad(const float* g, int32_t ldg, const float* x, int32_t 
     (void)hipGetLastError();
     if (!g || !x || !dw || !scratch || M <= 0 || N <= 0 || K <= 0 || ldg < N || ldx < K) return ADKF_E_BADARG;
     if (scratch_bytes < adkf_dense_weight_grad_scratch_bytes(M, N, K)) return ADKF_E_WORKSPACE;
-    // (k_dense3_tnd<4>: k_dense3_tn's products and row ranges with four chunks of operand loads in flight per lane and an XCD-aware
-    // workgroup order - bit-identical partial sums, 73 -> 60 us at the C2 feature map: tools/x3_stream_bench.hip)
-    static const bool optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense3_tnd<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    static const bool optin = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense3_tn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   D3_LDS_BYTES) == hipSuccess;
     if (!optin) { g_last_hip_error = hipErrorInvalidValue; (void)hipGetLastError(); return ADKF_E_LAUNCH; }
     int rps;
@@ -1434,13 +1443,20 @@ int adkf_dense_weight_grad(const float* g, int32_t ldg, const float* x, int32_t 
     if (tiles * splits > 0x7fffffffLL) return ADKF_E_SIZE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     Dense3TnArgs a{g, ldg, x, ldx, static_cast<float*>(scratch), M, N, K, rps};
-    static const bool stream_form = dense_stream_forms();
-    if (stream_form) k_dense3_tnd<4><<<(unsigned)(tiles * splits), D3_NT, D3_LDS_BYTES, st>>>(a, (int)tiles, splits);
-    else {
-        static const bool optin_tn = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense3_tn), hipFuncAttributeMaxDynamicSharedMemorySize, D3_LDS_BYTES) == hipSuccess;
-        if (!optin_tn) { g_last_hip_error = hipErrorInvalidValue; (void)hipGetLastError(); return ADKF_E_LAUNCH; }
-        k_dense3_tn<<<dim3((unsigned)tiles, (unsigned)splits), D3_NT, D3_LDS_BYTES, st>>>(a);
-    }
+    // ADKF_DENSE_TN_DEPTH (read once): 0 / unset = k_dense3_tn; 2 or 4 = k_dense3_tnd<2 | 4> (deeper prefetch, XCD-aware order; -2 / -4:
+    // dispatch order).  Bit-identical partial sums.  Measured (tools/x3_stream_bench.hip, tools/r05_stream_prof.sh): alone on the chip
+    // with its operands resident in the 256 MB MALL 73 -> 60 us at the C2 feature map, INSIDE the C2 step (operands from HBM) 66.9 / 68.4 /
+    // 69.5 / 67.0 us for tn / tnd<4> / tnd<4> in dispatch order / tnd<2>: no gain where it is used, so the default stays k_dense3_tn.
+    static const int tn_depth = [] { const char* e = getenv("ADKF_DENSE_TN_DEPTH"); return e ? atoi(e) : 0; }();
+    const int depth = tn_depth < 0 ? -tn_depth : tn_depth;
+    if (depth == 2 || depth == 4) {
+        static const bool optin_d = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense3_tnd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, D3_LDS_BYTES) == hipSuccess &&
+                                    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense3_tnd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, D3_LDS_BYTES) == hipSuccess;
+        if (!optin_d) { g_last_hip_error = hipErrorInvalidValue; (void)hipGetLastError(); return ADKF_E_LAUNCH; }
+        const int sp = tn_depth < 0 ? -splits : splits;
+        if (depth == 2) k_dense3_tnd<2><<<(unsigned)(tiles * splits), D3_NT, D3_LDS_BYTES, st>>>(a, (int)tiles, sp);
+        else k_dense3_tnd<4><<<(unsigned)(tiles * splits), D3_NT, D3_LDS_BYTES, st>>>(a, (int)tiles, sp);
+    } else k_dense3_tn<<<dim3((unsigned)tiles, (unsigned)splits), D3_NT, D3_LDS_BYTES, st>>>(a);
     const size_t n = (size_t)N * (size_t)K;
     k_dense3_reduce<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(static_cast<const float*>(scratch), dw, n, splits);
     LAUNCH_OK();

@@ -46,6 +46,20 @@ __global__ void k_split3(const float* __restrict__ x, unsigned short* __restrict
     reinterpret_cast<uint32_t*>(planes + 2 * plane_elems)[i] = p2;
 }
 
+// the same from the TRANSPOSE: w [K, N] float (a weight stored input-major, as torch.matmul(x, w) wants it) -> planes [3][N][K];
+// lanes run along n (coalesced reads of a row of w), each writes the pair (k, k + 1) of its plane rows
+__global__ void k_split3_t(const float* __restrict__ w, unsigned short* __restrict__ planes, int K, int N) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)(K / 2) * N) return;
+    const int n = (int)(i % N), kp = (int)(i / N);
+    uint32_t p0, p1, p2;
+    x3_split2(w[(size_t)(2 * kp) * N + n], w[(size_t)(2 * kp + 1) * N + n], p0, p1, p2);
+    const size_t o = ((size_t)n * K + 2 * kp) / 2, plane_words = (size_t)N * K / 2;
+    reinterpret_cast<uint32_t*>(planes)[o] = p0;
+    reinterpret_cast<uint32_t*>(planes)[plane_words + o] = p1;
+    reinterpret_cast<uint32_t*>(planes)[2 * plane_words + o] = p2;
+}
+
 struct Dense3Args {
     const float* A; int lda;                    // [M, K] activations, row stride lda (multiple of 4, 16-byte aligned rows)
     const unsigned short* Bp; size_t b_plane;   // pre-split weights: planes [3][N][K] (k_split3), plane stride in elements
@@ -293,6 +307,9 @@ __global__ __launch_bounds__(D3_NT) void k_dense3_tn(Dense3TnArgs a) {
 // where ~16 MB are needed to cover a 2 us trip to HBM at full rate): with eight chunks per tile, or every chunk's operands coming from
 // HBM, each chunk pays most of a memory round trip (8 x 2 us + epilogue = the 18.5 us a workgroup takes).
 //
+#ifndef D3SK_ORDER
+#define D3SK_ORDER 2
+#endif
 #ifndef D3S_ABLATE   // diagnostics (tools/x3_stream_bench.hip): 1 no operand loads behind the prologue, 2 no stores of the result, 4 no MFMAs, 8 no LDS stores of the staging
 #define D3S_ABLATE 0
 #endif
@@ -381,7 +398,9 @@ __global__ __launch_bounds__(D3_NT) void k_dense3_sk(Dense3Args a) {
     stage(0, 0);
     fetch_b(bp, 1);
     __syncthreads();
-    const bool stage_first = wv < 4;
+    // (measured at 65 536 x 256 x 256, tools/x3_stream_bench.hip: k_dense3's ping-pong order 61.7 us, everybody staging first 59.6, everybody
+    // multiplying first 58.0 - with the operand loads long in flight there is no load latency left for a partner wave to cover)
+    const bool stage_first = D3SK_ORDER == 0 ? wv < 4 : D3SK_ORDER == 1;   // 0: ping-pong, 1: everybody stages first, 2: everybody multiplies first
     const bool c_vec = !(a.ldc & 3) && !(reinterpret_cast<uintptr_t>(a.C) & 15);   // 16-byte stores of the result
     int p = 0;
     for (;;) {   // one output tile (mt, nt) per trip
@@ -456,8 +475,10 @@ __global__ __launch_bounds__(D3_NT) void k_dense3_tnd(Dense3TnArgs a, int tiles,
     const int tiles_k = (a.K + D3_TN - 1) / D3_TN;
     // workgroup id -> (tile, row range): ids b, b + 8, b + 16, ... share an XCD (round-robin dispatch); a multiple-of-8 prefix of the
     // grid is renumbered XCD-major so that consecutive logical indices - the tiles of one row range - share an XCD
+    const bool remap = splits > 0;   // (splits < 0: dispatch order, for A/B runs)
+    if (splits < 0) splits = -splits;
     const int total = tiles * splits, per = total >> 3, b = blockIdx.x;
-    const int logical = b < 8 * per ? (b & 7) * per + (b >> 3) : b;
+    const int logical = (remap && b < 8 * per) ? (b & 7) * per + (b >> 3) : b;
     const int tile = logical % tiles, split = logical / tiles;
     const int n0 = (tile / tiles_k) * D3_TM, k0 = (tile % tiles_k) * D3_TN;
     const int r_begin = split * a.rows_per_split, r_end = min(a.M, r_begin + a.rows_per_split);

@@ -30,6 +30,18 @@ def _split(w: torch.Tensor) -> torch.Tensor:
     return planes
 
 
+def _split_t(w: torch.Tensor) -> torch.Tensor:
+    """[K, N] float32 (a weight as ``x @ w`` takes it) -> planes [3, N, K]: the planes of w^T without forming w^T."""
+    from . import _lib
+    lib = _lib.load()
+    w = w.contiguous()
+    K, N = w.shape
+    planes = torch.empty((3, N, K), dtype=torch.int16, device=w.device)
+    st = C.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)
+    _lib.check(lib.adkf_split_planes_t(C.c_void_p(w.data_ptr()), C.c_void_p(planes.data_ptr()), K, N, st), "adkf_split_planes_t")
+    return planes
+
+
 def _dense(x: torch.Tensor, planes: torch.Tensor, bias, N: int) -> torch.Tensor:
     from . import _lib
     lib = _lib.load()

@@ -67,6 +67,7 @@ def make_tasks(T: int, N: int, d: int, N_q: Optional[int] = None, regression: bo
 
 
 _X3_DW = __import__("os").environ.get("ADKF_X3_DW", "1") != "0"   # A/B: 0 keeps the chunked bmm + sum
+_X3_FWD = __import__("os").environ.get("ADKF_X3_FWD", "1") != "0"   # A/B: 0 keeps the forward product on the library GEMM
 
 
 class _ChunkedLinear(torch.autograd.Function):
@@ -79,6 +80,11 @@ class _ChunkedLinear(torch.autograd.Function):
     def forward(ctx, X2, W, chunks):
         ctx.save_for_backward(X2)
         ctx.chunks = chunks
+        if _X3_FWD and X2.is_cuda and X2.dtype == torch.float32 and W.shape[0] in (64, 128, 256) and X2.shape[0] >= 32768:
+            # the forward product on the BF16 pipe too (csrc/dense_x3.h::k_dense3_sk: FP32-accurate, 61 us against the library GEMM's 69
+            # inside the C2 step); the planes of W^T are written by one small launch per step (adkf_split_planes_t)
+            from .dense import _dense, _split_t
+            return _dense(X2, _split_t(W.detach()), None, W.shape[1])
         return X2 @ W
 
     @staticmethod

@@ -318,12 +318,16 @@ int adkf_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const
  * csrc/gemm_x3.h: a float is the exact sum of three bfloat16 values; six BF16 MFMAs per product block; errors below the FP32 GEMM's).
  *   adkf_split_planes         planes[q][r][k], q = 0..2: the three bfloat16 pieces of x[r][k] (x0 = bf16(x), x1 = bf16(x - x0), x2 = the rest:
  *                       their sum is x exactly).  `planes`: 3 * rows * K uint16, 16-byte aligned; K even.
+ *   adkf_split_planes_t       the same from the transpose: w[K][N] (a weight stored input-major, as torch.matmul(x, w) takes it) ->
+ *                       planes[q][n][k], i.e. the planes adkf_dense_forward wants for y = x w.  K even; N * K a multiple of 8.
  *   adkf_dense_forward  y[M, N] = x[M, K] w[N, K]^T (+ bias[N]): torch's F.linear, with w given as the planes adkf_split_planes wrote
  *                       (weights are split once per update, activations on the fly).  K a multiple of 32; ldx, ldy the row strides
  *                       of x, y in floats (ldx a multiple of 4); x, y, w_planes 16-byte aligned.  The backward product with respect to x is
  *                       the same call on the planes of w^T.  Returns ADKF_E_LAUNCH when the device refuses the kernel's 120 KB of
- *                       dynamic LDS. */
+ *                       dynamic LDS.  Short contractions over many rows (K = 64, 128 or 256 and at least one 128-row tile per CU) take a
+ *                       persistent form of the kernel (k_dense3_sk: a row tile's whole K extent in registers); the results are the same bits. */
 int adkf_split_planes(const float* x, uint16_t* planes, int64_t rows, int64_t K, void* stream);
+int adkf_split_planes_t(const float* w, uint16_t* planes, int64_t K, int64_t N, void* stream);
 int adkf_dense_forward(const float* x, int32_t ldx, const uint16_t* w_planes, const float* bias, float* y, int32_t ldy, int32_t M,
                        int32_t N, int32_t K, void* stream);
  /*   adkf_dense_weight_grad  dw[N, K] = g[M, N]^T x[M, K] (torch: g.t() @ x), the contraction over the rows cut into row ranges whose

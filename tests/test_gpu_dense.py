@@ -123,3 +123,24 @@ def test_stand_in_feature_map_weight_gradient_both_ways(dev, monkeypatch):
     ref = (X.reshape(-1, 256).double() / 16.0).t() @ gz.reshape(-1, 256).double()
     e = [((o.double() - ref).abs().max() / ref.abs().max()).item() for o in out]
     assert e[0] < 2e-6 and e[0] <= 1.5 * e[1] + 1e-7, e
+
+
+def test_stand_in_feature_map_forward_both_ways(dev, monkeypatch):
+    """LinearFeatureMap's Z = X W at the C2 shape (65 536 rows): k_dense3_sk through adkf_split_planes_t against the library GEMM, both
+    against float64 in units of sum |x||w|; and the transposing split against the plain one on W^T, bit for bit."""
+    from adkf_ift_amd import dense, synthetic
+
+    g = torch.Generator().manual_seed(4)
+    X = torch.randn(2, 256, 128, 256, generator=g).to(dev)
+    W = (torch.randn(256, 256, generator=g) / 16).to(dev).requires_grad_(True)
+    assert torch.equal(dense._split_t(W.detach()), dense._split(W.detach().t().contiguous()))
+    out = []
+    for flag in (True, False):
+        monkeypatch.setattr(synthetic, "_X3_FWD", flag)
+        fm = synthetic.LinearFeatureMap(X[0], X[1], W)
+        out.append(fm().detach())
+    rows = torch.arange(0, 65536, 97, device=dev)
+    x2 = (X.reshape(-1, 256)[rows].double() / 16.0)
+    ref, scale = x2 @ W.detach().double(), x2.abs() @ W.detach().double().abs() + 1e-30
+    e = [((o.reshape(-1, 256)[rows].double() - ref).abs() / scale).max().item() for o in out]
+    assert e[0] <= 5e-7 and e[0] <= 1.5 * e[1] + 1e-8, e
