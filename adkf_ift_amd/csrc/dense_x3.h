@@ -307,6 +307,9 @@ __global__ __launch_bounds__(D3_NT) void k_dense3_tn(Dense3TnArgs a) {
 // where ~16 MB are needed to cover a 2 us trip to HBM at full rate): with eight chunks per tile, or every chunk's operands coming from
 // HBM, each chunk pays most of a memory round trip (8 x 2 us + epilogue = the 18.5 us a workgroup takes).
 //
+#ifndef D3TN_ORDER
+#define D3TN_ORDER 0
+#endif
 #ifndef D3SK_ORDER
 #define D3SK_ORDER 2
 #endif
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(D3_NT) void k_dense3_tnd(Dense3TnArgs a, int tiles,
         stage(0, 0);
         if (DEPTH < nc) fetch(0, r_begin + DEPTH * GK);
         __syncthreads();
-        const bool stage_first = wv < 4;
+        const bool stage_first = D3TN_ORDER == 0 ? wv < 4 : D3TN_ORDER == 1;   // as D3SK_ORDER
         for (int c0 = 0; c0 < nc; c0 += DEPTH) {
 #pragma unroll
             for (int u = 0; u < DEPTH; ++u) {
