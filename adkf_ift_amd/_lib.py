@@ -91,6 +91,9 @@ SIGNATURES = {
     "adkf_grad_sumsq": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "adkf_clip_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_float,
                                       C.c_float, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_void_p]),
+    "adkf_clip_adam_step_one": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_double,
+                                          C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                          C.c_void_p]),
     "adkf_ift_hypergrad_cg": (C.c_int, [C.POINTER(Batch), C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                         C.c_void_p]),

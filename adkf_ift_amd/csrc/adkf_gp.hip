@@ -1490,6 +1490,27 @@ int adkf_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const
     return 0;
 }
 
+int adkf_clip_adam_step_one(float* p, float* g, float* m, float* v, int64_t n, float scale, float clip, double lr, double beta1, double beta2,
+                            double eps, double weight_decay, int32_t step, uint16_t* planes_t, int32_t K, int32_t N, void* stream) {
+    (void)hipGetLastError();
+    if (!p || !g || !m || !v || n <= 0 || step <= 0) return ADKF_E_BADARG;
+    if (n > CLIP_ADAM_ONE_MAX) return ADKF_E_SIZE;
+    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
+        return ADKF_E_BADARG;
+    if (planes_t && (K <= 0 || N <= 0 || (int64_t)K * N != n || (K % STEP1_TILE) || (N % STEP1_TILE) || (reinterpret_cast<uintptr_t>(planes_t) & 3))) return ADKF_E_BADARG;
+    const double bias1 = 1.0 - pow(beta1, (double)step);
+    const double bias2_sqrt = sqrt(1.0 - pow(beta2, (double)step));
+    AdamOneArgs o{{p, g, m, v, (long)n, nullptr, 0, scale, clip, (float)(lr / bias1), (float)(1.0 - beta1), (float)beta2,
+                   (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)bias2_sqrt}, planes_t, K, N};
+    const long n4 = (n + 3) / 4;
+    int grid = (int)((n4 + STEP1_NT - 1) / STEP1_NT);
+    if (grid < 1) grid = 1;
+    if (planes_t) grid = (K / STEP1_TILE) * (N / STEP1_TILE);
+    k_clip_adam_one<<<grid, STEP1_NT, 0, static_cast<hipStream_t>(stream)>>>(o);
+    LAUNCH_OK();
+    return 0;
+}
+
 int adkf_check_info(const int32_t* info, int32_t T, void* stream) {
     if (!info || T <= 0) return ADKF_E_BADARG;
     int32_t* host = static_cast<int32_t*>(malloc(sizeof(int32_t) * (size_t)T));

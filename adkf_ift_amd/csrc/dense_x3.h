@@ -60,6 +60,13 @@ __global__ void k_split3_t(const float* __restrict__ w, unsigned short* __restri
     reinterpret_cast<uint32_t*>(planes)[2 * plane_words + o] = p2;
 }
 
+// one float -> its three pieces (outer_step.h: the optimiser's kernel writes the planes of the weights it has just updated)
+__device__ __forceinline__ void split_one(float x, unsigned short& q0, unsigned short& q1, unsigned short& q2) {
+    uint32_t p0, p1, p2;
+    x3_split2(x, 0.f, p0, p1, p2);
+    q0 = (unsigned short)(p0 & 0xffffu); q1 = (unsigned short)(p1 & 0xffffu); q2 = (unsigned short)(p2 & 0xffffu);
+}
+
 struct Dense3Args {
     const float* A; int lda;                    // [M, K] activations, row stride lda (multiple of 4, 16-byte aligned rows)
     const unsigned short* Bp; size_t b_plane;   // pre-split weights: planes [3][N][K] (k_split3), plane stride in elements

@@ -77,14 +77,15 @@ class _ChunkedLinear(torch.autograd.Function):
     leaves most CUs idle (measured 265 us on MI355X at C2), as a 32-way chunked bmm + sum it takes 140 us."""
 
     @staticmethod
-    def forward(ctx, X2, W, chunks):
+    def forward(ctx, X2, W, chunks, planes=None):
         ctx.save_for_backward(X2)
         ctx.chunks = chunks
         if _X3_FWD and X2.is_cuda and X2.dtype == torch.float32 and W.shape[0] in (64, 128, 256) and X2.shape[0] >= 32768:
             # the forward product on the BF16 pipe too (csrc/dense_x3.h::k_dense3_sk: FP32-accurate, 61 us against the library GEMM's 69
             # inside the C2 step); the planes of W^T are written by one small launch per step (adkf_split_planes_t)
+            # - or none at all when the optimiser's step wrote them with the weights (ClipAdam.attach_planes: ``planes``)
             from .dense import _dense, _split_t
-            return _dense(X2, _split_t(W.detach()), None, W.shape[1])
+            return _dense(X2, planes if planes is not None else _split_t(W.detach()), None, W.shape[1])
         return X2 @ W
 
     @staticmethod
@@ -96,11 +97,11 @@ class _ChunkedLinear(torch.autograd.Function):
         if _X3_DW and X2.is_cuda and X2.dtype == torch.float32 and g.dtype == torch.float32 and R >= 4096:
             # the same row-range scheme in one kernel, on the BF16 matrix pipe at FP32 accuracy (csrc/dense_x3.h::k_dense3_tnd)
             from .dense import _weight_grad
-            return None, _weight_grad(X2.contiguous(), g.contiguous()), None
+            return None, _weight_grad(X2.contiguous(), g.contiguous()), None, None
         if R % ch or ch == 1:
-            return None, X2.t() @ g, None
+            return None, X2.t() @ g, None, None
         part = torch.bmm(X2.view(ch, R // ch, d).transpose(1, 2), g.view(ch, R // ch, -1))
-        return None, part.sum(0), None
+        return None, part.sum(0), None, None
 
 
 class LinearFeatureMap:
@@ -109,6 +110,7 @@ class LinearFeatureMap:
 
     def __init__(self, X_s: torch.Tensor, X_q: torch.Tensor, W: torch.Tensor, chunks: int = 32):
         self.W, self.chunks = W, chunks
+        self.optimizer = None
         self.c = 1.0 / math.sqrt(W.shape[0])
         self.same = X_s.shape == X_q.shape
         if self.same:
@@ -116,10 +118,20 @@ class LinearFeatureMap:
         else:
             self.X_s, self.X_q = X_s, X_q
 
+    def planes_from(self, optimizer) -> None:
+        """``optimizer`` (a ``trainer.ClipAdam`` over ``W``) writes the bfloat16 planes of the updated weights in the launch that updates
+        them (``adkf_clip_adam_step_one``); the forward product then needs no split launch of its own.  Any step that did not write them
+        (the first one, another optimiser form, an in-place change of ``W``) falls back to splitting: ``ClipAdam.fresh_planes``."""
+        W = self.W
+        if W.is_cuda and W.dtype == torch.float32 and W.dim() == 2 and W.shape[0] % 64 == 0 and W.shape[1] % 64 == 0 and W.numel() <= optimizer.ONE_MAX:
+            optimizer.attach_planes(W, torch.empty(3, W.shape[1], W.shape[0], dtype=torch.int16, device=W.device))
+            self.optimizer = optimizer
+
     def __call__(self):
         if self.same:
             sh = self.X.shape
-            return _ChunkedLinear.apply(self.X.view(-1, sh[-1]), self.W, self.chunks).view(sh[0], sh[1], sh[2], -1)
+            planes = self.optimizer.fresh_planes(self.W) if self.optimizer is not None else None
+            return _ChunkedLinear.apply(self.X.view(-1, sh[-1]), self.W, self.chunks, planes).view(sh[0], sh[1], sh[2], -1)
         return (self.X_s @ self.W) * self.c, (self.X_q @ self.W) * self.c
 
 

@@ -14,6 +14,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -161,10 +163,30 @@ class ClipAdam(torch.optim.Adam):
     ``MAX_TENSORS`` parameters); a 300-tensor model is better served by torch's multi-tensor kernels."""
 
     MAX_TENSORS = 8
+    ONE_MAX = 131072   # ADKF_CLIP_ADAM_ONE_MAX: a single tensor up to this size takes ONE launch (``adkf_clip_adam_step_one``)
+    FUSE_ONE = os.environ.get("ADKF_CLIP_ADAM_ONE", "1") != "0"   # A/B: 0 keeps the two launches
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False)
         self._partials = None
+        self._planes = {}   # id(param) -> [planes_t, param version the planes were written for]
+
+    def attach_planes(self, p: torch.Tensor, planes_t: torch.Tensor) -> None:
+        """``p`` is a row-major weight ``w[K, N]`` used as ``x @ w`` on the BF16 matrix pipe (``dense._split_t``): let the step that
+        updates it also write the three bfloat16 planes of the NEW weights into ``planes_t`` ([3, N, K] int16) - the split launch of the
+        next forward pass goes away.  Only the one-launch form does this (one tensor, at most ``ONE_MAX`` elements); ``fresh_planes``
+        says whether the planes belong to the weights as they are now."""
+        if p.dim() != 2 or tuple(planes_t.shape) != (3, p.shape[1], p.shape[0]) or planes_t.dtype != torch.int16 or not planes_t.is_contiguous():
+            raise ValueError("attach_planes: planes_t must be a contiguous int16 tensor [3, N, K] for a weight [K, N]")
+        self._planes[id(p)] = [planes_t, None]
+
+    def fresh_planes(self, p: torch.Tensor):
+        """The attached planes if the last one-launch step wrote them and nothing has modified ``p`` in place since (torch's version
+        counter), else None."""
+        ent = self._planes.get(id(p))
+        if ent is None or ent[1] is None or ent[1] != p._version:
+            return None
+        return ent[0]
 
     def _tensors(self):
         out = []
@@ -173,6 +195,15 @@ class ClipAdam(torch.optim.Adam):
                 if p.grad is not None:
                     out.append((group, p))
         return out
+
+    def _adam_state(self, p):
+        state = self.state[p]
+        if len(state) == 0:
+            state["step"] = torch.tensor(0.0)
+            state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        state["step"] += 1
+        return state
 
     def clip_step(self, scale: float, clip_value: Optional[float]) -> None:
         import ctypes as C
@@ -195,17 +226,28 @@ class ClipAdam(torch.optim.Adam):
             self._partials = torch.empty(parts * len(todo), dtype=torch.float32, device=dev)
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         ptr = lambda t: C.c_void_p(t.data_ptr())
+        clip = float("inf") if clip_value is None else float(clip_value)
+        if self.FUSE_ONE and len(todo) == 1 and todo[0][1].numel() <= self.ONE_MAX:
+            group, p = todo[0]
+            state = self._adam_state(p)
+            b1, b2 = group["betas"]
+            ent = self._planes.get(id(p))
+            use_planes = ent is not None and p.dim() == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0 and ent[0].device == p.device
+            _lib.check(lib.adkf_clip_adam_step_one(ptr(p), ptr(p.grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]), p.numel(), float(scale),
+                                                   clip, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                   float(group["weight_decay"]), int(state["step"].item()),
+                                                   ptr(ent[0]) if use_planes else None, p.shape[0] if use_planes else 0,
+                                                   p.shape[1] if use_planes else 0, st), "adkf_clip_adam_step_one")
+            if ent is not None:
+                ent[1] = p._version if use_planes else None
+            return
         for k, (_, p) in enumerate(todo):
             _lib.check(lib.adkf_grad_sumsq(ptr(p.grad), p.numel(), C.c_void_p(self._partials.data_ptr() + 4 * parts * k), st),
                        "adkf_grad_sumsq")
-        clip = float("inf") if clip_value is None else float(clip_value)
+        for ent in self._planes.values():
+            ent[1] = None    # (the two-launch form does not write planes)
         for group, p in todo:
-            state = self.state[p]
-            if len(state) == 0:
-                state["step"] = torch.tensor(0.0)
-                state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            state["step"] += 1
+            state = self._adam_state(p)
             b1, b2 = group["betas"]
             _lib.check(lib.adkf_clip_adam_step(ptr(p), ptr(p.grad), ptr(state["exp_avg"]), ptr(state["exp_avg_sq"]), p.numel(),
                                                ptr(self._partials), self._partials.numel(), float(scale), clip, float(group["lr"]),

@@ -306,12 +306,22 @@ int adkf_block_combine_backward(const float* p, const float* x1, const float* am
  *                        g <- g * scale * min(1, clip / (scale |g| + 1e-6));  then Adam step number `step` (1-based;
  *                        exp_avg m, exp_avg_sq v, no amsgrad, weight_decay added to g as torch does).  clip = +inf
  *                        disables clipping.  Hyper-parameters are doubles: 1 - beta and lr / (1 - beta1^step) are formed in double
- *                        and rounded once, as torch does.  All pointers 16-byte aligned, n elements each. */
+ *                        and rounded once, as torch does.  All pointers 16-byte aligned, n elements each.
+ *   adkf_clip_adam_step_one  the two calls above as ONE launch for ONE tensor of at most ADKF_CLIP_ADAM_ONE_MAX elements (every
+ *                        workgroup re-adds the whole gradient's squares in the same fixed order: deterministic, identical on every rank;
+ *                        ADKF_E_SIZE beyond the limit).  planes_t (or NULL): the tensor is a row-major weight w[K][N] (n = K * N, K and N
+ *                        multiples of 64) and the three bfloat16 pieces of every UPDATED weight are also written as planes[q][n][k] - what
+ *                        adkf_split_planes_t(w) would give after the step, bit for bit - so that the next adkf_dense_forward of y = x w
+ *                        needs no split launch. */
 #define ADKF_SUMSQ_PARTS 256
+#define ADKF_CLIP_ADAM_ONE_MAX 131072
 int adkf_grad_sumsq(const float* g, int64_t n, float* partials, void* stream);
 int adkf_clip_adam_step(float* p, float* g, float* m, float* v, int64_t n, const float* partials, int32_t n_partials,
                         float scale, float clip, double lr, double beta1, double beta2, double eps, double weight_decay,
                         int32_t step, void* stream);
+int adkf_clip_adam_step_one(float* p, float* g, float* m, float* v, int64_t n, float scale, float clip, double lr, double beta1,
+                            double beta2, double eps, double weight_decay, int32_t step, uint16_t* planes_t, int32_t K, int32_t N,
+                            void* stream);
 
 /* a1 / a2 (the dense layers of the feature extractor and of the fc head: torch.nn.Linear, fs_mol/modules/gnn.py:477-515,
  * fs_mol/modules/graph_readout.py, fs_mol/models/adaptive_dkt.py:50-65) with FP32 products on the BF16 matrix pipe (csrc/dense_x3.h,

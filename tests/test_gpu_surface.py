@@ -550,3 +550,81 @@ def test_awkward_shapes_match_oracle(dev, T, N, Nq, d, kern):
         assert np.abs(out["dZ_s"][t].cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
         refq = np.asarray(q["dZq_total"])
         assert np.abs(out["dZ_q"][t].cpu().numpy() - refq).max() <= 1e-4 * max(np.abs(refq).max(), 1e-30)
+
+
+@pytest.mark.parametrize("shape, clip, wd", [((256, 256), 1.0, 0.0), ((64, 128), None, 0.01), ((1027,), 0.3, 0.0), ((512, 256), 1e9, 0.0)])
+def test_one_launch_clip_adam_and_the_planes_it_writes(dev, shape, clip, wd):
+    """H: adkf_clip_adam_step_one (one tensor, one launch) == {grad *= 1/T, clip_grad_norm_, torch.optim.Adam.step}; the bfloat16 planes
+    it writes for a [K, N] weight are adkf_split_planes_t of the UPDATED weight bit for bit; fresh_planes goes stale on an in-place
+    change of the weight; beyond ADKF_CLIP_ADAM_ONE_MAX the two-launch form runs and writes no planes."""
+    from adkf_ift_amd import dense
+    from adkf_ift_amd.trainer import ClipAdam
+
+    assert ClipAdam.FUSE_ONE
+    g = torch.Generator().manual_seed(11)
+    p = torch.randn(shape, generator=g).to(dev).requires_grad_(True)
+    q = p.detach().clone().requires_grad_(True)
+    o_ref = torch.optim.Adam([p], lr=1e-2, weight_decay=wd)
+    o_new = ClipAdam([q], lr=1e-2, weight_decay=wd)
+    two_d = len(shape) == 2
+    one_launch = q.numel() <= ClipAdam.ONE_MAX
+    if two_d:
+        planes = torch.full((3, shape[1], shape[0]), -1, dtype=torch.int16, device=dev)
+        o_new.attach_planes(q, planes)
+        assert o_new.fresh_planes(q) is None
+    scale = 1.0 / 16.0
+    for step in range(3):
+        gr = torch.randn(shape, generator=g).to(dev) * 10.0 ** (step - 1)
+        p.grad, q.grad = gr.clone(), gr.clone()
+        p.grad.mul_(scale)
+        if clip is not None:
+            torch.nn.utils.clip_grad_norm_([p], clip)
+        o_ref.step()
+        o_new.clip_step(scale, clip)
+        assert (q.grad - p.grad).abs().max() <= 2e-6 * p.grad.abs().max(), step
+        assert (q - p).abs().max() <= 2e-6 * p.abs().max() + 1e-7, step
+        if two_d and one_launch:
+            got = o_new.fresh_planes(q)
+            assert got is planes
+            assert torch.equal(got, dense._split_t(q.detach())), step
+        elif two_d:
+            assert o_new.fresh_planes(q) is None
+    sr, sn = o_ref.state[p], o_new.state[q]
+    assert float(sr["step"]) == float(sn["step"]) == 3.0
+    assert (sr["exp_avg"] - sn["exp_avg"]).abs().max() <= 2e-6 * sr["exp_avg"].abs().max()
+    assert (sr["exp_avg_sq"] - sn["exp_avg_sq"]).abs().max() <= 4e-6 * sr["exp_avg_sq"].abs().max()
+    if two_d and one_launch:
+        with torch.no_grad():
+            q.mul_(1.0)      # any in-place change: the planes no longer belong to the weights
+        assert o_new.fresh_planes(q) is None
+    # same gradient, same bits: every workgroup (and every rank) re-adds the squares in one fixed order
+    outs = []
+    for _ in range(2):
+        a = torch.zeros(shape, device=dev).requires_grad_(True)
+        a.grad = gr.clone()
+        ClipAdam([a], lr=1e-2).clip_step(1.0, 1.0)
+        outs.append(a.detach().clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_feature_map_forward_on_the_optimisers_planes_is_the_split_one_bit_for_bit(dev):
+    """The C2 stand-in feature map: with planes_from(opt) the forward product after an optimiser step reads the planes that step wrote;
+    Z is identical to the one computed through adkf_split_planes_t."""
+    from adkf_ift_amd.synthetic import LinearFeatureMap
+    from adkf_ift_amd.trainer import ClipAdam
+
+    g = torch.Generator().manual_seed(3)
+    T, N, d = 128, 128, 256
+    X_s, X_q = torch.randn(T, N, d, generator=g).to(dev), torch.randn(T, N, d, generator=g).to(dev)
+    W = torch.randn(d, d, generator=g).to(dev).requires_grad_(True)
+    opt = ClipAdam([W], lr=1e-2)
+    fm, fm_split = LinearFeatureMap(X_s, X_q, W), LinearFeatureMap(X_s, X_q, W)
+    fm.planes_from(opt)
+    for step in range(2):
+        Z = fm()
+        assert torch.equal(Z, fm_split()), step
+        W.grad = None
+        Z.square().mean().backward()
+        opt.clip_step(1.0, 1.0)
+        assert opt.fresh_planes(W) is not None
+    assert torch.equal(fm(), fm_split())
