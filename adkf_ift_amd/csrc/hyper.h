@@ -65,7 +65,20 @@ struct HyperArgs {
 };
 
 // ---- the kernel function through its exponential factor (the same expressions as kappa3, device_utils.h) -------------------
+#ifndef ADKF_HY_FAST_EXP
+#define ADKF_HY_FAST_EXP 0   // 1: ONE v_exp_f32 of a pre-scaled argument (what k_inner's search evaluations use, inner.h) instead of libm's expf.
+                             // Experiment switch only (tools/r05_fastexp_ab.sh): REJECTED on parity - the golden Matern case gp_N128_Nq128_d256_k1_r1_s0
+                             // goes from 1.9e-5 to 1.1e-4 on v (tolerance 1e-4): the outer stage needs the libm factor
+#endif
+#if ADKF_HY_FAST_EXP
+// absolute error of the factor <= 2^-24 |arg| e^-|arg| <= 2.2e-8 (the rounding of the pre-scaled argument) + 1 ulp of the hardware exp2:
+// below the float32 rounding of the matrix entries the factor goes into
+__device__ __forceinline__ float hy_ex(int kind, float u) {
+    return kind == 0 ? __builtin_amdgcn_exp2f(u * -0.72134752044448170368f) : __builtin_amdgcn_exp2f(__builtin_amdgcn_sqrtf(u) * -3.2259784787f);
+}
+#else
 __device__ __forceinline__ float hy_ex(int kind, float u) { return kind == 0 ? expf(-0.5f * u) : expf(-SQRT5 * sqrtf(u)); }
+#endif
 __device__ __forceinline__ float hy_k0(int kind, float u, float ex) { return kind == 0 ? ex : (1.f + SQRT5 * sqrtf(u) + (5.f / 3.f) * u) * ex; }
 __device__ __forceinline__ float hy_ex_of_k0(int kind, float u, float k0) { return kind == 0 ? k0 : k0 / (1.f + SQRT5 * sqrtf(u) + (5.f / 3.f) * u); }
 __device__ __forceinline__ void hy_k3(int kind, float u, float ex, float& k0, float& k1, float& k2) {
