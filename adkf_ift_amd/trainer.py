@@ -157,7 +157,9 @@ class ClipAdam(torch.optim.Adam):
     """``torch.optim.Adam`` whose ``clip_step(scale, clip_value)`` does {task-mean, clip-by-global-norm, Adam update}
     (fs_mol/utils/adaptive_dkt_utils.py:402-413) in the HIP library: ``adkf_grad_sumsq`` + ``adkf_clip_adam_step`` per
     tensor, i.e. 2 launches for the benchmark's single d x d parameter instead of norm + clamp + mul + a fused Adam
-    whose one 64 K chunk runs on a single workgroup (70 us -> 8 us).  State layout (``exp_avg``, ``exp_avg_sq``,
+    whose one 64 K chunk runs on a single workgroup (70 us -> 8 us); a SINGLE tensor of at most ``ONE_MAX`` elements (the benchmark's
+    case) takes ONE launch, ``adkf_clip_adam_step_one``, which can also write the bfloat16 planes of the updated weight for the next
+    forward product (``attach_planes``).  State layout (``exp_avg``, ``exp_avg_sq``,
     ``step``) is torch's, so ``state_dict`` / ``load_state_dict`` interchange with ``torch.optim.Adam`` and a plain
     ``.step()`` still works.  Meant for a handful of tensors (``meta_step`` uses it when there are at most
     ``MAX_TENSORS`` parameters); a 300-tensor model is better served by torch's multi-tensor kernels."""
